@@ -1,0 +1,5 @@
+"""MI355X-native implementation of the FFT-LMU hot path (LMUFFT layer)."""
+from .lmu import LMU, LMUFFT  # noqa: F401
+from .functional import causal_conv, causal_conv_adjoint, lmufft_layer  # noqa: F401
+
+__all__ = ["LMUFFT", "LMU", "lmufft_layer", "causal_conv", "causal_conv_adjoint"]

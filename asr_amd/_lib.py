@@ -1,0 +1,90 @@
+"""ctypes binding of liblmufft_hip.so (C ABI declared in include/lmufft.h).
+
+There is no fallback: if the shared library is missing this module raises at
+import time, and every entry point raises RuntimeError when the library
+reports an error.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblmufft_hip.so")
+
+F32 = 0
+BF16 = 1
+CONV_AUTO = 0
+CONV_TOEPLITZ = 1
+CONV_FFT = 2
+ABI_VERSION = 1
+
+
+class Shape(ctypes.Structure):
+    """Mirror of `lmufft_shape` (include/lmufft.h)."""
+
+    _fields_ = [
+        ("B", ctypes.c_int32),
+        ("T", ctypes.c_int32),
+        ("D", ctypes.c_int32),
+        ("M", ctypes.c_int32),
+        ("Hd", ctypes.c_int32),
+        ("ldH", ctypes.c_int32),
+    ]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C asr_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "asr_amd has no CPU or eager fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    sp = ctypes.POINTER(Shape)
+    lib.lmufft_abi_version.restype = ci
+    lib.lmufft_abi_version.argtypes = []
+    lib.lmufft_last_error.restype = ctypes.c_char_p
+    lib.lmufft_last_error.argtypes = []
+    lib.lmufft_forward_workspace_bytes.restype = sz
+    lib.lmufft_forward_workspace_bytes.argtypes = [sp, ci]
+    lib.lmufft_backward_workspace_bytes.restype = sz
+    lib.lmufft_backward_workspace_bytes.argtypes = [sp, ci]
+    lib.lmufft_conv_workspace_bytes.restype = sz
+    lib.lmufft_conv_workspace_bytes.argtypes = [sp, ci, ci]
+    lib.lmufft_forward_f32.restype = ci
+    lib.lmufft_forward_f32.argtypes = [sp] + [vp] * 10 + [ci, vp, sz, vp]
+    lib.lmufft_backward_f32.restype = ci
+    lib.lmufft_backward_f32.argtypes = [sp] + [vp] * 15 + [ci, vp, sz, vp]
+    lib.lmufft_conv_forward_f32.restype = ci
+    lib.lmufft_conv_forward_f32.argtypes = [sp, vp, vp, vp, ci, vp, sz, vp]
+    lib.lmufft_conv_backward_f32.restype = ci
+    lib.lmufft_conv_backward_f32.argtypes = [sp, vp, vp, vp, ci, vp, sz, vp]
+    got = lib.lmufft_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {got}, expected {ABI_VERSION}; rebuild it")
+    return lib
+
+
+lib = _load()
+
+# every symbol include/lmufft.h declares (checked by tests/test_abi.py)
+EXPORTS = (
+    "lmufft_abi_version",
+    "lmufft_last_error",
+    "lmufft_forward_workspace_bytes",
+    "lmufft_forward_f32",
+    "lmufft_backward_workspace_bytes",
+    "lmufft_backward_f32",
+    "lmufft_conv_workspace_bytes",
+    "lmufft_conv_forward_f32",
+    "lmufft_conv_backward_f32",
+)
+
+
+def check(rc: int, what: str) -> None:
+    """Turn a non-zero return code into the RuntimeError the reference's users expect."""
+    if rc != 0:
+        msg = lib.lmufft_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what}: {msg}")

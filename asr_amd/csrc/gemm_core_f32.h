@@ -1,0 +1,209 @@
+// Block-level f32 GEMM building block for gfx950 (CDNA4), shared by every
+// GEMM-shaped kernel of the LMUFFT layer.
+//
+// One 256-thread workgroup (4 waves, one per SIMD) computes a BM x BN tile of
+// C = A * B with v_mfma_f32_32x32x2_f32, whose result is bit-for-bit a
+// k-ordered fp32 fma chain -- the fp32 path therefore has the same numerics
+// class as the reference's fp32 GEMMs.
+//
+// Operands are described by loader functors, so that a kernel can generate an
+// operand on the fly (Toeplitz matrix from u, ReLU-masked gradient, [m;x]
+// concatenation) instead of materialising it in HBM:
+//
+//   layout KC ("k contiguous"): load(r, k) returns elements k..k+3 of tile row r.
+//       LDS image [rows][BK+4]; fragments are read with ds_read_b128 (4 k per
+//       lane).  Row stride 36 floats = 144 B puts 16 consecutive rows on 16
+//       different 16-byte slots of the 256-byte bank row: conflict-free.
+//   layout NC ("row contiguous"): load(r, k) returns rows r..r+3 at depth k.
+//       LDS image [BK][rows]; fragments are read with ds_read_b32 (consecutive
+//       lanes -> consecutive rows: conflict-free), i.e. the transposition that
+//       a k-strided source needs costs nothing.
+//
+// Both layouts feed MFMA step j of k-group kk with k = 8*kk + 4*(lane>>5) + j,
+// so a KC operand may be paired with an NC operand.
+//
+// Staging is global -> registers -> LDS with the next tile's global loads
+// issued before the current tile's MFMAs (their latency hides under the
+// 64-cycle f32 MFMAs).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace lmufft {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kThreads = 256;
+enum Layout { KC = 0, NC = 1 };
+
+template <int BM_, int BN_, int BK_, int WGM_, int WGN_, int ALAY_, int BLAY_>
+struct Tile {
+  static constexpr int BM = BM_, BN = BN_, BK = BK_, WGM = WGM_, WGN = WGN_;
+  static constexpr int ALAY = ALAY_, BLAY = BLAY_;
+  static_assert(WGM_ * WGN_ == 4, "four waves per workgroup");
+  static constexpr int WM = BM / WGM, WN = BN / WGN;  // per-wave output
+  static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile is made of 32x32 MFMA tiles");
+  static constexpr int TM = WM / 32, TN = WN / 32;
+  static constexpr int LDK = BK + 4;  // KC row stride in floats
+  static_assert(BK % 8 == 0, "k-groups of 8");
+  static constexpr int A_FLOATS = ALAY == KC ? BM * LDK : BK * BM;
+  static constexpr int B_FLOATS = BLAY == KC ? BN * LDK : BK * BN;
+  static_assert((BM * BK / 4) % kThreads == 0 && (BN * BK / 4) % kThreads == 0,
+                "each thread stages a whole number of float4");
+  static constexpr int A_VECS = BM * BK / 4 / kThreads;
+  static constexpr int B_VECS = BN * BK / 4 / kThreads;
+  static constexpr int SMEM_FLOATS = A_FLOATS + B_FLOATS;
+};
+
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+// base[idx .. idx+3], elements at or beyond `limit` read as zero.  With VEC the
+// caller guarantees idx % 4 == 0, limit % 4 == 0 and a 16-byte aligned row.
+template <bool VEC>
+__device__ __forceinline__ f32x4 load4(const float* __restrict__ base, long idx, int pos, int limit) {
+  if (VEC) {
+    if (pos < limit) return *reinterpret_cast<const f32x4*>(base + idx);
+    return zero4();
+  } else {
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (pos + j < limit) ? base[idx + j] : 0.f;
+    return v;
+  }
+}
+
+template <int R, int BK, int LAY, int NV, class Load>
+__device__ __forceinline__ void tile_fetch(f32x4 (&regs)[NV], Load& load, int k0) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = tid + i * kThreads;
+    if (LAY == KC) {
+      const int r = idx / (BK / 4), c = idx % (BK / 4);
+      regs[i] = load(r, k0 + c * 4);
+    } else {
+      const int k = idx / (R / 4), r4 = idx % (R / 4);
+      regs[i] = load(r4 * 4, k0 + k);
+    }
+  }
+}
+
+template <int R, int BK, int LAY, int NV>
+__device__ __forceinline__ void tile_store(float* S, const f32x4 (&regs)[NV]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = tid + i * kThreads;
+    if (LAY == KC) {
+      const int r = idx / (BK / 4), c = idx % (BK / 4);
+      *reinterpret_cast<f32x4*>(&S[r * (BK + 4) + c * 4]) = regs[i];
+    } else {
+      const int k = idx / (R / 4), r4 = idx % (R / 4);
+      *reinterpret_cast<f32x4*>(&S[k * R + r4 * 4]) = regs[i];
+    }
+  }
+}
+
+template <class T>
+struct WavePos {
+  int wm0, wn0, r, hh;
+  __device__ __forceinline__ WavePos() {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    wm0 = (wave / T::WGN) * T::WM;
+    wn0 = (wave % T::WGN) * T::WN;
+    r = lane & 31;
+    hh = lane >> 5;
+  }
+};
+
+template <class T>
+__device__ __forceinline__ void tile_zero(f32x16 (&acc)[T::TM][T::TN]) {
+#pragma unroll
+  for (int a = 0; a < T::TM; ++a)
+#pragma unroll
+    for (int b = 0; b < T::TN; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+}
+
+template <class T>
+__device__ __forceinline__ void tile_compute(const float* As, const float* Bs,
+                                             f32x16 (&acc)[T::TM][T::TN], const WavePos<T>& w) {
+#pragma unroll
+  for (int kk = 0; kk < T::BK / 8; ++kk) {
+    f32x4 a[T::TM], b[T::TN];
+    const int kb = kk * 8 + w.hh * 4;
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm) {
+      const int row = w.wm0 + tm * 32 + w.r;
+      if (T::ALAY == KC) {
+        a[tm] = *reinterpret_cast<const f32x4*>(&As[row * T::LDK + kb]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[tm][j] = As[(kb + j) * T::BM + row];
+      }
+    }
+#pragma unroll
+    for (int tn = 0; tn < T::TN; ++tn) {
+      const int col = w.wn0 + tn * 32 + w.r;
+      if (T::BLAY == KC) {
+        b[tn] = *reinterpret_cast<const f32x4*>(&Bs[col * T::LDK + kb]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[tn][j] = Bs[(kb + j) * T::BN + col];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < T::TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[tn][j], acc[tm][tn], 0, 0, 0);
+  }
+}
+
+// acc += A[:, kbeg:kend] * B[kbeg:kend, :] for this workgroup's tile.  Loaders
+// must return zero outside the real operand.  Every thread of the workgroup
+// must call it with the same kbeg/kend (it contains barriers).
+template <class T, class LA, class LB>
+__device__ __forceinline__ void gemm_tile(float* smem, f32x16 (&acc)[T::TM][T::TN], LA& la, LB& lb,
+                                          int kbeg, int kend, const WavePos<T>& w) {
+  float* As = smem;
+  float* Bs = smem + T::A_FLOATS;
+  f32x4 ra[T::A_VECS], rb[T::B_VECS];
+  if (kbeg < kend) {
+    tile_fetch<T::BM, T::BK, T::ALAY>(ra, la, kbeg);
+    tile_fetch<T::BN, T::BK, T::BLAY>(rb, lb, kbeg);
+  }
+  for (int k0 = kbeg; k0 < kend; k0 += T::BK) {
+    tile_store<T::BM, T::BK, T::ALAY>(As, ra);
+    tile_store<T::BN, T::BK, T::BLAY>(Bs, rb);
+    __syncthreads();
+    if (k0 + T::BK < kend) {
+      tile_fetch<T::BM, T::BK, T::ALAY>(ra, la, k0 + T::BK);
+      tile_fetch<T::BN, T::BK, T::BLAY>(rb, lb, k0 + T::BK);
+    }
+    tile_compute<T>(As, Bs, acc, w);
+    __syncthreads();
+  }
+}
+
+// f(m, n, value) for every accumulator element; m, n are tile-local.
+// C/D map of v_mfma_f32_32x32x2_f32: column = lane & 31,
+// row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+template <class T, class F>
+__device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[T::TM][T::TN], const WavePos<T>& w, F&& f) {
+#pragma unroll
+  for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < T::TN; ++tn)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int m = w.wm0 + tm * 32 + (i & 3) + 8 * (i >> 2) + 4 * w.hh;
+        const int n = w.wn0 + tn * 32 + w.r;
+        f(m, n, acc[tm][tn][i]);
+      }
+}
+
+}  // namespace lmufft

@@ -1,0 +1,721 @@
+// fp32 kernels of the LMUFFT layer for gfx950 (MI355X) and their C ABI.
+//
+// Reference arithmetic: src/lmu.py:297-320 (forward); the backward is what
+// autograd derives from those lines.  Kernel inventory (all fp32, f32-MFMA):
+//
+//   k_encode_fwd   u = relu(x . w_u + b_u)                      HBM-bound
+//   k_conv_fwd     m = Toeplitz(u) * H^T  (causal conv)         MFMA f32
+//   k_proj_fwd     h = relu([m;x] W_h^T + b_h), h_n             MFMA f32
+//   k_dgrad        [gm;gx1] = (g*(h>0)) W_h                     MFMA f32
+//   k_wgrad        gW_h, gb_h partial slabs (split over rows)   MFMA f32
+//   k_conv_bwd     gu partial = diag-sums of gm * H             MFMA f32
+//   k_gu_reduce    gu = sum of partial slabs, ga = gu*(u>0)
+//   k_encode_bwd   gx += ga w_u ; gw_u, gb_u partial slabs      HBM-bound
+//   k_reduce_slabs deterministic slab sums for parameter grads
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "gemm_core_f32.h"
+#include "lmufft.h"
+#include "lmufft_internal.h"
+
+namespace lmufft {
+
+// ---------------------------------------------------------------------------
+// u = relu(x . w_u + b_u)                                    src/lmu.py:300
+// one wave per row, 16-byte loads, wave-level shuffle reduction
+// ---------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void k_encode_fwd(const float* __restrict__ x,
+                                                         const float* __restrict__ w_u,
+                                                         const float* __restrict__ b_u,
+                                                         float* __restrict__ u, int rows, int D) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float bias = b_u[0];
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const float* xr = x + (long)row * D;
+    float s = 0.f;
+    if (VEC) {
+      for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + c);
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w_u + c);
+        s += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
+      }
+    } else {
+      for (int c = lane; c < D; c += 64) s += xr[c] * w_u[c];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) u[row] = fmaxf(s + bias, 0.f);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// m[b,t,k] = sum_{tau<=t} u[b,t-tau] H[k,tau]               src/lmu.py:303-312
+// Per batch item a GEMM: A[t][tau] = u[t-tau] (lower-triangular Toeplitz,
+// generated on the fly), B[tau][k] = H[k][tau].  Only the causal part of the
+// K range is visited.  Grid: (k tiles, batch, t tiles) with the deepest
+// (latest) t tiles dispatched first.
+// ---------------------------------------------------------------------------
+using ConvFwdTile = Tile<64, 192, 32, 2, 2, KC, KC>;
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void k_conv_fwd(const float* __restrict__ u,
+                                                       const float* __restrict__ H,
+                                                       float* __restrict__ m, int T, int M, int ldH) {
+  using TL = ConvFwdTile;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n0 = blockIdx.x * TL::BN;
+  const int b = blockIdx.y;
+  const int tb = gridDim.z - 1 - blockIdx.z;
+  const int t0 = tb * TL::BM;
+  const float* ub = u + (long)b * T;
+
+  auto la = [=](int r, int k) -> f32x4 {
+    const int t = t0 + r;
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int s = t - (k + j);
+      v[j] = (t < T && s >= 0) ? ub[s] : 0.f;
+    }
+    return v;
+  };
+  auto lb = [=](int r, int k) -> f32x4 {
+    const int n = n0 + r;
+    if (n >= M) return zero4();
+    return load4<VEC>(H, (long)n * ldH + k, k, T);
+  };
+
+  WavePos<TL> w;
+  f32x16 acc[TL::TM][TL::TN];
+  tile_zero<TL>(acc);
+  const int kend = min(T, t0 + TL::BM);
+  gemm_tile<TL>(smem, acc, la, lb, 0, kend, w);
+
+  float* mb = m + (long)b * T * M;
+  tile_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
+    const int t = t0 + mm, n = n0 + nn;
+    if (t < T && n < M) mb[(long)t * M + n] = v;
+  });
+}
+
+// ---------------------------------------------------------------------------
+// h = relu([m;x] W_h^T + b_h); h_n = h[:, T-1, :]           src/lmu.py:315-318
+// The concatenation is never materialised: the A loader reads columns < M
+// from m and the rest from x.
+// ---------------------------------------------------------------------------
+using ProjTile = Tile<64, 128, 32, 2, 2, KC, KC>;
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void k_proj_fwd(const float* __restrict__ m,
+                                                       const float* __restrict__ x,
+                                                       const float* __restrict__ W,
+                                                       const float* __restrict__ bias,
+                                                       float* __restrict__ h, float* __restrict__ h_n,
+                                                       int rows, int T, int M, int D, int Hd) {
+  using TL = ProjTile;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n0 = blockIdx.x * TL::BN;
+  const int m0 = blockIdx.y * TL::BM;
+  const int K = M + D;
+
+  auto la = [=](int r, int k) -> f32x4 {
+    const long row = m0 + r;
+    if (row >= rows) return zero4();
+    if (VEC) {
+      if (k < M) return *reinterpret_cast<const f32x4*>(m + row * M + k);
+      if (k < K) return *reinterpret_cast<const f32x4*>(x + row * D + (k - M));
+      return zero4();
+    } else {
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kk = k + j;
+        v[j] = kk < M ? m[row * M + kk] : (kk < K ? x[row * D + (kk - M)] : 0.f);
+      }
+      return v;
+    }
+  };
+  auto lb = [=](int r, int k) -> f32x4 {
+    const int n = n0 + r;
+    if (n >= Hd) return zero4();
+    return load4<VEC>(W, (long)n * K + k, k, K);
+  };
+
+  WavePos<TL> w;
+  f32x16 acc[TL::TM][TL::TN];
+  tile_zero<TL>(acc);
+  gemm_tile<TL>(smem, acc, la, lb, 0, K, w);
+
+  tile_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
+    const long row = m0 + mm;
+    const int n = n0 + nn;
+    if (row < rows && n < Hd) {
+      const float y = fmaxf(v + bias[n], 0.f);
+      h[row * Hd + n] = y;
+      const int t = (int)(row % T);
+      if (t == T - 1) h_n[(row / T) * Hd + n] = y;
+    }
+  });
+}
+
+// gz[row][n] = (h > 0) ? gh (+ gh_n on the last frame) : 0, four n at once
+template <bool VEC>
+__device__ __forceinline__ f32x4 load_gz4(const float* __restrict__ h, const float* __restrict__ gh,
+                                          const float* __restrict__ gh_n, long row, int n, int T, int Hd) {
+  const f32x4 hv = load4<VEC>(h, row * Hd + n, n, Hd);
+  f32x4 g = gh ? load4<VEC>(gh, row * Hd + n, n, Hd) : zero4();
+  if (gh_n && (int)(row % T) == T - 1) {
+    const f32x4 gl = load4<VEC>(gh_n, (row / T) * Hd + n, n, Hd);
+    g += gl;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) g[j] = hv[j] > 0.f ? g[j] : 0.f;
+  return g;
+}
+
+// ---------------------------------------------------------------------------
+// [gm ; gx1] = gz W_h     (rows x (M+D), K = Hd)
+// ---------------------------------------------------------------------------
+using DgradTile = Tile<64, 192, 32, 2, 2, KC, NC>;
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void k_dgrad(const float* __restrict__ h,
+                                                    const float* __restrict__ gh,
+                                                    const float* __restrict__ gh_n,
+                                                    const float* __restrict__ W, float* __restrict__ gm,
+                                                    float* __restrict__ gx, int rows, int T, int M, int D,
+                                                    int Hd) {
+  using TL = DgradTile;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n0 = blockIdx.x * TL::BN;
+  const int m0 = blockIdx.y * TL::BM;
+  const int MD = M + D;
+
+  auto la = [=](int r, int k) -> f32x4 {
+    const long row = m0 + r;
+    if (row >= rows) return zero4();
+    return load_gz4<VEC>(h, gh, gh_n, row, k, T, Hd);
+  };
+  // B[k = hidden index][j]: W_h rows are contiguous along j -> NC layout
+  auto lb = [=](int r, int k) -> f32x4 {
+    if (k >= Hd) return zero4();
+    const int j = n0 + r;
+    return load4<VEC>(W, (long)k * MD + j, j, MD);
+  };
+
+  WavePos<TL> w;
+  f32x16 acc[TL::TM][TL::TN];
+  tile_zero<TL>(acc);
+  gemm_tile<TL>(smem, acc, la, lb, 0, Hd, w);
+
+  tile_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
+    const long row = m0 + mm;
+    const int j = n0 + nn;
+    if (row < rows && j < MD) {
+      if (j < M)
+        gm[row * M + j] = v;
+      else if (gx)
+        gx[row * D + (j - M)] = v;
+    }
+  });
+}
+
+// ---------------------------------------------------------------------------
+// gW_h[n][j] = sum_rows gz[row][n] * [m;x][row][j];  gb_h[n] = sum_rows gz[row][n]
+// The row range is split over gridDim.z workgroups; each writes one slab
+// [Hd*(M+D) + Hd] that k_reduce_slabs sums in a fixed order.
+// ---------------------------------------------------------------------------
+using WgradTile = Tile<128, 192, 32, 2, 2, NC, NC>;
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void k_wgrad(const float* __restrict__ h,
+                                                    const float* __restrict__ gh,
+                                                    const float* __restrict__ gh_n,
+                                                    const float* __restrict__ m, const float* __restrict__ x,
+                                                    float* __restrict__ slabs, int rows, int rows_per_split,
+                                                    int T, int M, int D, int Hd) {
+  using TL = WgradTile;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int j0 = blockIdx.x * TL::BN;
+  const int n0 = blockIdx.y * TL::BM;
+  const int MD = M + D;
+  const int kbeg = blockIdx.z * rows_per_split;
+  const int kend = min(rows, kbeg + rows_per_split);
+  const long slab_stride = (long)Hd * MD + Hd;
+  float* slab = slabs + blockIdx.z * slab_stride;
+
+  auto la = [=](int r, int k) -> f32x4 {
+    if (k >= kend) return zero4();
+    return load_gz4<VEC>(h, gh, gh_n, (long)k, n0 + r, T, Hd);
+  };
+  auto lb = [=](int r, int k) -> f32x4 {
+    if (k >= kend) return zero4();
+    const long row = k;
+    const int j = j0 + r;
+    if (VEC) {
+      if (j < M) return *reinterpret_cast<const f32x4*>(m + row * M + j);
+      if (j < MD) return *reinterpret_cast<const f32x4*>(x + row * D + (j - M));
+      return zero4();
+    } else {
+      f32x4 v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int jj = j + q;
+        v[q] = jj < M ? m[row * M + jj] : (jj < MD ? x[row * D + (jj - M)] : 0.f);
+      }
+      return v;
+    }
+  };
+
+  WavePos<TL> w;
+  f32x16 acc[TL::TM][TL::TN];
+  tile_zero<TL>(acc);
+
+  // same loop as gemm_tile, with the bias-gradient column sums taken from the
+  // staged A tile (LDS image [k][n]) by the workgroups of the first j tile
+  float* As = smem;
+  float* Bs = smem + TL::A_FLOATS;
+  f32x4 ra[TL::A_VECS], rb[TL::B_VECS];
+  float colsum = 0.f;
+  const bool do_bias = blockIdx.x == 0 && threadIdx.x < TL::BM;
+  if (kbeg < kend) {
+    tile_fetch<TL::BM, TL::BK, TL::ALAY>(ra, la, kbeg);
+    tile_fetch<TL::BN, TL::BK, TL::BLAY>(rb, lb, kbeg);
+  }
+  for (int k0 = kbeg; k0 < kend; k0 += TL::BK) {
+    tile_store<TL::BM, TL::BK, TL::ALAY>(As, ra);
+    tile_store<TL::BN, TL::BK, TL::BLAY>(Bs, rb);
+    __syncthreads();
+    if (k0 + TL::BK < kend) {
+      tile_fetch<TL::BM, TL::BK, TL::ALAY>(ra, la, k0 + TL::BK);
+      tile_fetch<TL::BN, TL::BK, TL::BLAY>(rb, lb, k0 + TL::BK);
+    }
+    if (do_bias) {
+#pragma unroll 8
+      for (int k = 0; k < TL::BK; ++k) colsum += As[k * TL::BM + threadIdx.x];
+    }
+    tile_compute<TL>(As, Bs, acc, w);
+    __syncthreads();
+  }
+
+  tile_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
+    const int n = n0 + mm, j = j0 + nn;
+    if (n < Hd && j < MD) slab[(long)n * MD + j] = v;
+  });
+  if (do_bias && n0 + (int)threadIdx.x < Hd) slab[(long)Hd * MD + n0 + threadIdx.x] = colsum;
+}
+
+// ---------------------------------------------------------------------------
+// gu[b,s] = sum_{t>=s} sum_k gm[b,t,k] H[k,t-s]
+// Per (batch, t tile): P[i][tau] = sum_k gm[t0+i][k] H[k][tau] on MFMA, then
+// every P element is added to the diagonal s = t0 + i - tau it belongs to
+// (LDS float atomics, conflict-free: one accumulator register is one P row,
+// i.e. 32 distinct diagonals per half-wave).  Each workgroup writes its partial
+// gu for s < t0+BM; k_gu_reduce sums the partials in a fixed order.
+// ---------------------------------------------------------------------------
+using ConvBwdTile = Tile<64, 128, 32, 2, 2, KC, NC>;
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void k_conv_bwd(const float* __restrict__ gm,
+                                                       const float* __restrict__ H,
+                                                       float* __restrict__ gu_part, int T, int M, int ldH) {
+  using TL = ConvBwdTile;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* gu_acc = smem + TL::SMEM_FLOATS;  // [t0 + BM] diagonals
+  const int b = blockIdx.y;
+  const int ntt = gridDim.z;
+  const int tb = ntt - 1 - blockIdx.z;
+  const int t0 = tb * TL::BM;
+  const int send = min(T, t0 + TL::BM);  // diagonals 0 .. send-1
+  const float* gmb = gm + (long)b * T * M;
+
+  for (int s = threadIdx.x; s < send; s += kThreads) gu_acc[s] = 0.f;
+  // (the first barrier inside gemm_tile orders this against the atomics)
+
+  auto la = [=](int r, int k) -> f32x4 {
+    const int t = t0 + r;
+    if (t >= T) return zero4();
+    return load4<VEC>(gmb, (long)t * M + k, k, M);
+  };
+
+  WavePos<TL> w;
+  for (int tau0 = 0; tau0 < send; tau0 += TL::BN) {
+    auto lb = [=](int r, int k) -> f32x4 {
+      if (k >= M) return zero4();
+      const int tau = tau0 + r;
+      return load4<VEC>(H, (long)k * ldH + tau, tau, T);
+    };
+    f32x16 acc[TL::TM][TL::TN];
+    tile_zero<TL>(acc);
+    gemm_tile<TL>(smem, acc, la, lb, 0, M, w);
+    tile_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
+      const int s = t0 + mm - (tau0 + nn);
+      if (s >= 0 && t0 + mm < T) atomicAdd(&gu_acc[s], v);
+    });
+  }
+  __syncthreads();
+  float* out = gu_part + ((long)b * ntt + tb) * T;
+  for (int s = threadIdx.x; s < send; s += kThreads) out[s] = gu_acc[s];
+}
+
+// gu[b,t] = sum over the t tiles tb >= t / tile_t of their partial slab;
+// optional ReLU mask of the encoder: ga = gu * (u > 0)
+__global__ __launch_bounds__(kThreads) void k_gu_reduce(const float* __restrict__ gu_part,
+                                                        const float* __restrict__ u,
+                                                        float* __restrict__ out, int B, int T, int ntt,
+                                                        int tile_t) {
+  const long n = (long)B * T;
+  for (long i = blockIdx.x * (long)kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
+    const int b = (int)(i / T), t = (int)(i % T);
+    float s = 0.f;
+    for (int tb = t / tile_t; tb < ntt; ++tb) s += gu_part[((long)b * ntt + tb) * T + t];
+    if (u) s = u[i] > 0.f ? s : 0.f;
+    out[i] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// gx[row,:] += ga[row] w_u ; partial gw_u = sum_rows ga[row] x[row,:], gb_u
+// One wave per row, rows with ga == 0 (ReLU-dead frames, about half of them)
+// touch neither x nor gx.  Slab per workgroup: [D + 1].
+// ---------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void k_encode_bwd(const float* __restrict__ ga,
+                                                         const float* __restrict__ x,
+                                                         const float* __restrict__ w_u, float* __restrict__ gx,
+                                                         float* __restrict__ part, int rows, int D,
+                                                         int rows_per_block) {
+  __shared__ float red[4][kThreads];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(rows, r0 + rows_per_block);
+  float* slab = part + (long)blockIdx.x * (D + 1);
+
+  for (int c0 = 0; c0 < D; c0 += 256) {
+    const int c = c0 + lane * 4;
+    f32x4 acc = zero4();
+    float gsum = 0.f;
+    const f32x4 wv = load4<VEC>(w_u, c, c, D);
+    for (int row = r0 + wave; row < r1; row += 4) {
+      const float g = ga[row];
+      gsum += g;
+      if (g != 0.f && c < D) {
+        const f32x4 xv = load4<VEC>(x, (long)row * D + c, c, D);
+        acc += g * xv;
+        if (gx) {
+          float* gp = gx + (long)row * D + c;
+          if (VEC) {
+            f32x4 o = *reinterpret_cast<f32x4*>(gp);
+            o += g * wv;
+            *reinterpret_cast<f32x4*>(gp) = o;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (c + j < D) gp[j] += g * wv[j];
+          }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[wave][lane * 4 + j] = acc[j];
+    __syncthreads();
+    const int cc = c0 + threadIdx.x;
+    if (cc < D) slab[cc] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (c0 == 0) {
+      __syncthreads();
+      if (lane == 0) red[wave][0] = gsum;
+      __syncthreads();
+      if (threadIdx.x == 0) slab[D] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+    }
+  }
+}
+
+// out0[i] (i < n0) and out1[i - n0] (n0 <= i < n0+n1) = sum_s in[s*stride + i]
+__global__ __launch_bounds__(kThreads) void k_reduce_slabs(const float* __restrict__ in, int S, long stride,
+                                                           float* __restrict__ out0, long n0,
+                                                           float* __restrict__ out1, long n1) {
+  const long n = n0 + n1;
+  for (long i = blockIdx.x * (long)kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += in[k * stride + i];
+    if (i < n0)
+      out0[i] = s;
+    else
+      out1[i - n0] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
+
+constexpr int kEncRowsPerBlock = 32;
+
+static int wgrad_splits(long rows, int Hd, int MD, int* rows_per_split) {
+  const int tiles = cdiv(Hd, WgradTile::BM) * cdiv(MD, WgradTile::BN);
+  int S = (256 + tiles - 1) / tiles;  // about one workgroup per CU
+  int rps = cdiv(rows, S);
+  rps = cdiv(rps, WgradTile::BK) * WgradTile::BK;
+  S = cdiv(rows, rps);
+  *rows_per_split = rps;
+  return S;
+}
+
+struct BwdPlan {
+  int S, rps, ntt, enc_blocks;
+  size_t off_wslab, off_gupart, off_ga, off_encpart, total;
+};
+
+static BwdPlan plan_backward(const lmufft_shape& s) {
+  BwdPlan p;
+  const long rows = (long)s.B * s.T;
+  const int MD = s.M + s.D;
+  p.S = wgrad_splits(rows, s.Hd, MD, &p.rps);
+  p.ntt = cdiv(s.T, ConvBwdTile::BM);
+  p.enc_blocks = cdiv(rows, kEncRowsPerBlock);
+  size_t off = 0;
+  p.off_wslab = off;
+  off += align256(sizeof(float) * (size_t)p.S * ((size_t)s.Hd * MD + s.Hd));
+  p.off_gupart = off;
+  off += align256(sizeof(float) * (size_t)s.B * p.ntt * s.T);
+  p.off_ga = off;
+  off += align256(sizeof(float) * (size_t)rows);
+  p.off_encpart = off;
+  off += align256(sizeof(float) * (size_t)p.enc_blocks * (s.D + 1));
+  p.total = off;
+  return p;
+}
+
+static int check_shape(const lmufft_shape* s) {
+  if (!s) return set_error("shape is NULL");
+  if (s->B <= 0 || s->T <= 0 || s->D <= 0 || s->M <= 0 || s->Hd <= 0)
+    return set_error("shape: B, T, D, M, Hd must be positive (got B=%d T=%d D=%d M=%d Hd=%d)", s->B, s->T,
+                     s->D, s->M, s->Hd);
+  if (s->T > s->ldH)
+    return set_error("sequence length %d exceeds the impulse response length (seq_len) %d", s->T, s->ldH);
+  if ((long)s->B * s->T >= (1L << 31) / 4) return set_error("B*T too large");
+  return 0;
+}
+
+#define LAUNCH_CHECK(name)                                                            \
+  do {                                                                                \
+    hipError_t e_ = hipGetLastError();                                                \
+    if (e_ != hipSuccess) return set_error("launch of %s failed: %s", name, hipGetErrorString(e_)); \
+  } while (0)
+
+static int conv_forward_toeplitz(const lmufft_shape& s, const float* u, const float* H, float* m,
+                                 hipStream_t st) {
+  using TL = ConvFwdTile;
+  const dim3 grid(cdiv(s.M, TL::BN), s.B, cdiv(s.T, TL::BM));
+  const size_t lds = TL::SMEM_FLOATS * sizeof(float);
+  const bool vec = (s.ldH % 4 == 0) && (s.T % 4 == 0) && aligned16(H);
+  if (vec)
+    hipLaunchKernelGGL(k_conv_fwd<true>, grid, dim3(kThreads), lds, st, u, H, m, s.T, s.M, s.ldH);
+  else
+    hipLaunchKernelGGL(k_conv_fwd<false>, grid, dim3(kThreads), lds, st, u, H, m, s.T, s.M, s.ldH);
+  LAUNCH_CHECK("k_conv_fwd");
+  return 0;
+}
+
+// gu_part: [B][ntt][T] scratch; out = gu (u == NULL) or ga = gu*(u>0)
+static int conv_backward_toeplitz(const lmufft_shape& s, const float* gm, const float* H, const float* u,
+                                  float* gu_part, float* out, hipStream_t st) {
+  using TL = ConvBwdTile;
+  const int ntt = cdiv(s.T, TL::BM);
+  const dim3 grid(1, s.B, ntt);
+  const size_t lds = (TL::SMEM_FLOATS + (size_t)ntt * TL::BM) * sizeof(float);
+  if (lds > 160 * 1024) return set_error("sequence too long for the Toeplitz backward kernel (T=%d)", s.T);
+  const bool vec = (s.ldH % 4 == 0) && (s.T % 4 == 0) && (s.M % 4 == 0) && aligned16(H) && aligned16(gm);
+  if (vec) {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)k_conv_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_conv_bwd<true>, grid, dim3(kThreads), lds, st, gm, H, gu_part, s.T, s.M, s.ldH);
+  } else {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)k_conv_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_conv_bwd<false>, grid, dim3(kThreads), lds, st, gm, H, gu_part, s.T, s.M, s.ldH);
+  }
+  LAUNCH_CHECK("k_conv_bwd");
+  const long n = (long)s.B * s.T;
+  hipLaunchKernelGGL(k_gu_reduce, dim3(min(cdiv(n, kThreads), 2048)), dim3(kThreads), 0, st, gu_part, u, out,
+                     s.B, s.T, ntt, TL::BM);
+  LAUNCH_CHECK("k_gu_reduce");
+  return 0;
+}
+
+}  // namespace lmufft
+
+using namespace lmufft;
+
+extern "C" {
+
+int lmufft_abi_version(void) { return LMUFFT_ABI_VERSION; }
+
+const char* lmufft_last_error(void) { return last_error_buffer(); }
+
+size_t lmufft_forward_workspace_bytes(const lmufft_shape* s, int dtype) {
+  (void)s;
+  (void)dtype;
+  return 256;  // the fp32 forward needs no scratch; never return 0 so callers can always allocate
+}
+
+size_t lmufft_backward_workspace_bytes(const lmufft_shape* s, int dtype) {
+  (void)dtype;
+  if (check_shape(s)) return 0;
+  return plan_backward(*s).total;
+}
+
+size_t lmufft_conv_workspace_bytes(const lmufft_shape* s, int dtype, int conv_algo) {
+  (void)dtype;
+  (void)conv_algo;
+  if (!s || s->B <= 0 || s->T <= 0) return 0;
+  const int ntt = cdiv(s->T, ConvBwdTile::BM);
+  return align256(sizeof(float) * (size_t)s->B * ntt * s->T);
+}
+
+int lmufft_conv_forward_f32(const lmufft_shape* s, const float* u, const float* H, float* m, int conv_algo,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+  (void)workspace;
+  (void)workspace_bytes;
+  if (!s || s->B <= 0 || s->T <= 0 || s->M <= 0) return set_error("conv: bad shape");
+  if (s->T > s->ldH) return set_error("sequence length %d exceeds the impulse response length %d", s->T, s->ldH);
+  if (!u || !H || !m) return set_error("conv: NULL pointer");
+  if (conv_algo != LMUFFT_CONV_AUTO && conv_algo != LMUFFT_CONV_TOEPLITZ)
+    return set_error("conv algorithm %d is not available", conv_algo);
+  return conv_forward_toeplitz(*s, u, H, m, (hipStream_t)stream);
+}
+
+int lmufft_conv_backward_f32(const lmufft_shape* s, const float* gm, const float* H, float* gu, int conv_algo,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+  if (!s || s->B <= 0 || s->T <= 0 || s->M <= 0) return set_error("conv: bad shape");
+  if (s->T > s->ldH) return set_error("sequence length %d exceeds the impulse response length %d", s->T, s->ldH);
+  if (!gm || !H || !gu) return set_error("conv: NULL pointer");
+  if (conv_algo != LMUFFT_CONV_AUTO && conv_algo != LMUFFT_CONV_TOEPLITZ)
+    return set_error("conv algorithm %d is not available", conv_algo);
+  const size_t need = lmufft_conv_workspace_bytes(s, LMUFFT_F32, conv_algo);
+  if (!workspace || workspace_bytes < need)
+    return set_error("conv backward: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+  return conv_backward_toeplitz(*s, gm, H, nullptr, (float*)workspace, gu, (hipStream_t)stream);
+}
+
+int lmufft_forward_f32(const lmufft_shape* s, const float* x, const float* w_u, const float* b_u,
+                       const float* W_h, const float* b_h, const float* H, float* u, float* m, float* h,
+                       float* h_n, int conv_algo, void* workspace, size_t workspace_bytes, void* stream) {
+  (void)workspace;
+  (void)workspace_bytes;
+  if (int rc = check_shape(s)) return rc;
+  if (!x || !w_u || !b_u || !W_h || !b_h || !H || !u || !m || !h || !h_n)
+    return set_error("forward: NULL pointer");
+  if (conv_algo != LMUFFT_CONV_AUTO && conv_algo != LMUFFT_CONV_TOEPLITZ)
+    return set_error("conv algorithm %d is not available", conv_algo);
+  hipStream_t st = (hipStream_t)stream;
+  const long rows = (long)s->B * s->T;
+  const int MD = s->M + s->D;
+
+  {  // eq. 18
+    const bool vec = (s->D % 4 == 0) && aligned16(x) && aligned16(w_u);
+    const dim3 grid(min(cdiv(rows, 4), 4096));
+    if (vec)
+      hipLaunchKernelGGL(k_encode_fwd<true>, grid, dim3(kThreads), 0, st, x, w_u, b_u, u, (int)rows, s->D);
+    else
+      hipLaunchKernelGGL(k_encode_fwd<false>, grid, dim3(kThreads), 0, st, x, w_u, b_u, u, (int)rows, s->D);
+    LAUNCH_CHECK("k_encode_fwd");
+  }
+  if (int rc = conv_forward_toeplitz(*s, u, H, m, st)) return rc;  // eq. 26
+  {  // eq. 20
+    using TL = ProjTile;
+    const bool vec = (s->M % 4 == 0) && (s->D % 4 == 0) && aligned16(m) && aligned16(x) && aligned16(W_h);
+    const dim3 grid(cdiv(s->Hd, TL::BN), cdiv(rows, TL::BM));
+    const size_t lds = TL::SMEM_FLOATS * sizeof(float);
+    if (vec)
+      hipLaunchKernelGGL(k_proj_fwd<true>, grid, dim3(kThreads), lds, st, m, x, W_h, b_h, h, h_n, (int)rows,
+                         s->T, s->M, s->D, s->Hd);
+    else
+      hipLaunchKernelGGL(k_proj_fwd<false>, grid, dim3(kThreads), lds, st, m, x, W_h, b_h, h, h_n, (int)rows,
+                         s->T, s->M, s->D, s->Hd);
+    LAUNCH_CHECK("k_proj_fwd");
+    (void)MD;
+  }
+  return 0;
+}
+
+int lmufft_backward_f32(const lmufft_shape* s, const float* x, const float* w_u, const float* W_h,
+                        const float* H, const float* u, const float* m, const float* h, const float* gh,
+                        const float* gh_n, float* gx, float* gw_u, float* gb_u, float* gW_h, float* gb_h,
+                        float* gm, int conv_algo, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_shape(s)) return rc;
+  if (!x || !w_u || !W_h || !H || !u || !m || !h || !gw_u || !gb_u || !gW_h || !gb_h || !gm)
+    return set_error("backward: NULL pointer");
+  if (conv_algo != LMUFFT_CONV_AUTO && conv_algo != LMUFFT_CONV_TOEPLITZ)
+    return set_error("conv algorithm %d is not available", conv_algo);
+  const BwdPlan p = plan_backward(*s);
+  if (!workspace || workspace_bytes < p.total)
+    return set_error("backward: workspace of %zu bytes needed, %zu given", p.total, workspace_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  float* wslab = (float*)(ws + p.off_wslab);
+  float* gupart = (float*)(ws + p.off_gupart);
+  float* ga = (float*)(ws + p.off_ga);
+  float* encpart = (float*)(ws + p.off_encpart);
+  const long rows = (long)s->B * s->T;
+  const int MD = s->M + s->D;
+  const bool vec_h = (s->Hd % 4 == 0) && aligned16(h) && (!gh || aligned16(gh)) && (!gh_n || aligned16(gh_n));
+
+  {  // [gm ; gx1] = gz W_h
+    using TL = DgradTile;
+    const bool vec = vec_h && (MD % 4 == 0) && aligned16(W_h);
+    const dim3 grid(cdiv(MD, TL::BN), cdiv(rows, TL::BM));
+    const size_t lds = TL::SMEM_FLOATS * sizeof(float);
+    if (vec)
+      hipLaunchKernelGGL(k_dgrad<true>, grid, dim3(kThreads), lds, st, h, gh, gh_n, W_h, gm, gx, (int)rows,
+                         s->T, s->M, s->D, s->Hd);
+    else
+      hipLaunchKernelGGL(k_dgrad<false>, grid, dim3(kThreads), lds, st, h, gh, gh_n, W_h, gm, gx, (int)rows,
+                         s->T, s->M, s->D, s->Hd);
+    LAUNCH_CHECK("k_dgrad");
+  }
+  {  // gW_h, gb_h slabs
+    using TL = WgradTile;
+    const bool vec = vec_h && (s->M % 4 == 0) && (s->D % 4 == 0) && aligned16(m) && aligned16(x);
+    const dim3 grid(cdiv(MD, TL::BN), cdiv(s->Hd, TL::BM), p.S);
+    const size_t lds = TL::SMEM_FLOATS * sizeof(float);
+    if (vec)
+      hipLaunchKernelGGL(k_wgrad<true>, grid, dim3(kThreads), lds, st, h, gh, gh_n, m, x, wslab, (int)rows,
+                         p.rps, s->T, s->M, s->D, s->Hd);
+    else
+      hipLaunchKernelGGL(k_wgrad<false>, grid, dim3(kThreads), lds, st, h, gh, gh_n, m, x, wslab, (int)rows,
+                         p.rps, s->T, s->M, s->D, s->Hd);
+    LAUNCH_CHECK("k_wgrad");
+    const long n0 = (long)s->Hd * MD;
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(min(cdiv(n0 + s->Hd, kThreads), 2048)), dim3(kThreads), 0, st,
+                       wslab, p.S, n0 + s->Hd, gW_h, n0, gb_h, (long)s->Hd);
+    LAUNCH_CHECK("k_reduce_slabs");
+  }
+  // ga = (adjoint conv of gm) * (u > 0)
+  if (int rc = conv_backward_toeplitz(*s, gm, H, u, gupart, ga, st)) return rc;
+  {  // gx += ga w_u ; gw_u, gb_u
+    const bool vec = (s->D % 4 == 0) && aligned16(x) && aligned16(w_u) && (!gx || aligned16(gx));
+    const dim3 grid(p.enc_blocks);
+    if (vec)
+      hipLaunchKernelGGL(k_encode_bwd<true>, grid, dim3(kThreads), 0, st, ga, x, w_u, gx, encpart, (int)rows,
+                         s->D, kEncRowsPerBlock);
+    else
+      hipLaunchKernelGGL(k_encode_bwd<false>, grid, dim3(kThreads), 0, st, ga, x, w_u, gx, encpart, (int)rows,
+                         s->D, kEncRowsPerBlock);
+    LAUNCH_CHECK("k_encode_bwd");
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(min(cdiv(s->D + 1, kThreads), 2048)), dim3(kThreads), 0, st,
+                       encpart, p.enc_blocks, (long)(s->D + 1), gw_u, (long)s->D, gb_u, 1L);
+    LAUNCH_CHECK("k_reduce_slabs");
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,22 @@
+// Helpers shared by the translation units of liblmufft_hip.so (not part of the ABI).
+#pragma once
+#include <stdarg.h>
+#include <stdio.h>
+
+namespace lmufft {
+
+inline char* last_error_buffer() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+
+// Records the message for lmufft_last_error() and returns the error code 1.
+inline int set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(last_error_buffer(), 512, fmt, ap);
+  va_end(ap);
+  return 1;
+}
+
+}  // namespace lmufft

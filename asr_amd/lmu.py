@@ -1,0 +1,107 @@
+"""Drop-in module surface of the reference's `src/lmu.py` for the FFT-LMU path.
+
+`LMUFFT` keeps the reference's constructor signature, attribute / child /
+buffer names and `forward(x) -> (h, h_n)` contract (src/lmu.py:208-320), so a
+caller such as the reference's `LMUEncoder` (src/models/lmu_encoder.py:204-212,
+:266) and its checkpoints (`model_state_dict` keys `A, B, H, fft_H,
+W_u.{weight,bias}, W_h.{weight,bias}`) work unchanged.  The arithmetic runs in
+hand-written gfx950 kernels (asr_amd/csrc) -- there is no eager or CPU path.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch import nn
+
+from .functional import lmufft_layer
+
+__all__ = ["LMUFFT", "LMU", "legendre_state_space", "impulse_response"]
+
+
+def legendre_state_space(memory_size: int, theta: float):
+    """Discretised (zero-order hold, dt = 1) Legendre delay system A [M,M], B [M,1].
+
+    Same construction as the reference (src/lmu.py:248-272): continuous
+    A_c[i,j] = (2i+1)/theta * (-1 if i<j else (-1)^(i-j+1)),
+    B_c[i] = (2i+1)/theta * (-1)^i, discretised by the same third-party routine
+    (scipy.signal.cont2discrete, method "zoh"), then cast to float32.
+    """
+    from scipy.signal import cont2discrete
+
+    q = np.arange(memory_size, dtype=np.float64)
+    scale = ((2.0 * q + 1.0) / float(theta))[:, None]
+    row, col = np.meshgrid(q, q, indexing="ij")
+    a_c = scale * np.where(row < col, -1.0, (-1.0) ** (row - col + 1.0))
+    b_c = scale * ((-1.0) ** q)[:, None]
+    a_d, b_d, _, _, _ = cont2discrete(
+        (a_c, b_c, np.ones((1, memory_size)), np.zeros((1,))), dt=1.0, method="zoh")
+    return torch.from_numpy(a_d).float(), torch.from_numpy(b_d).float()
+
+
+def impulse_response(A: torch.Tensor, B: torch.Tensor, seq_len: int):
+    """H [M, seq_len] with H[:, t] = A^t B and its spectrum rfft(H, 2*seq_len).
+
+    The powers are accumulated in float32 on the CPU in the reference's order
+    (`A_t <- A @ A_t`, src/lmu.py:278-285): an fp64-exact A^t B differs from
+    that by ~8e-6 relative, which would eat into the 1e-4 parity budget.
+    """
+    M = A.shape[0]
+    H = torch.empty((M, seq_len), dtype=torch.float32)
+    a_t = torch.eye(M, dtype=torch.float32)
+    A = A.float().cpu()
+    B = B.float().cpu()
+    for t in range(seq_len):
+        H[:, t : t + 1] = a_t @ B
+        a_t = A @ a_t
+    fft_H = torch.fft.rfft(H, n=2 * seq_len, dim=-1)
+    return H, fft_H
+
+
+class LMUFFT(nn.Module):
+    """Parallel (convolutional) Legendre Memory Unit layer on MI355X.
+
+    Parameters follow the reference (src/lmu.py:225): input_size, hidden_size,
+    memory_size, seq_len, theta.  `forward` accepts any T <= seq_len (the
+    reference requires T == seq_len; where it runs, results are identical).
+
+    `fft_H` is kept as a buffer only so that state_dicts stay interchangeable;
+    the kernels read `H`.  `conv_algo` ("auto" | "toeplitz" | "fft") selects the
+    causal-convolution kernel and is not part of the reference signature.
+    """
+
+    def __init__(self, input_size, hidden_size, memory_size, seq_len, theta, conv_algo="auto"):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.memory_size = memory_size
+        self.seq_len = seq_len
+        self.theta = theta
+        self.conv_algo = conv_algo
+
+        self.W_u = nn.Linear(in_features=input_size, out_features=1)
+        self.f_u = nn.ReLU()
+        self.W_h = nn.Linear(in_features=memory_size + input_size, out_features=hidden_size)
+        self.f_h = nn.ReLU()
+
+        A, B = legendre_state_space(memory_size, theta)
+        self.register_buffer("A", A)  # [memory_size, memory_size]
+        self.register_buffer("B", B)  # [memory_size, 1]
+        H, fft_H = impulse_response(A, B, seq_len)
+        self.register_buffer("H", H)  # [memory_size, seq_len]
+        self.register_buffer("fft_H", fft_H)  # [memory_size, seq_len + 1] complex64
+
+    def forward(self, x):
+        """x [batch, seq_len, input_size] -> (h [batch, seq_len, hidden], h_n [batch, hidden])."""
+        return lmufft_layer(x, self.W_u.weight, self.W_u.bias, self.W_h.weight, self.W_h.bias, self.H,
+                            conv_algo=self.conv_algo)
+
+
+class LMU(nn.Module):
+    """Name kept because the reference encoder imports it (src/models/lmu_encoder.py:9,15).
+
+    The sequential (recurrent) LMU is outside the scope of this library.
+    """
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError(
+            "asr_amd implements the parallel LMUFFT layer only; construct the model with use_fft_lmu=True")

@@ -1,0 +1,113 @@
+/*
+ * lmufft.h -- C ABI of the MI355X (gfx950) implementation of the parallel
+ * Legendre Memory Unit layer ("LMUFFT").
+ *
+ * The library (asr_amd/csrc/liblmufft_hip.so) replaces the arithmetic of the
+ * reference module `LMUFFT` (reference: src/lmu.py:208-320).  The reference is
+ * pure Python and has no FFI of its own for this path; the Python side of this
+ * repository (asr_amd/lmu.py) binds these symbols with ctypes and keeps the
+ * reference module's constructor / forward / state_dict surface.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) owned by the caller; the library
+ *     neither frees nor retains it beyond the call;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *     all work is enqueued on it, nothing synchronises the device;
+ *   - tensors are dense row-major: x[B][T][D], h[B][T][Hd], m[B][T][M],
+ *     u[B][T], W_h[Hd][M+D] (memory columns first, then input columns),
+ *     w_u[D], H[M][ldH] with ldH >= T (the module's seq_len);
+ *   - return value 0 = success; non-zero = error, text via lmufft_last_error();
+ *   - no function allocates device memory: scratch comes in through
+ *     `workspace` (size from lmufft_*_workspace_bytes).
+ */
+#ifndef LMUFFT_H_
+#define LMUFFT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LMUFFT_ABI_VERSION 1
+
+/* element types of the activations (x, h, gh, gx, m) */
+#define LMUFFT_F32 0
+#define LMUFFT_BF16 1
+
+/* causal-convolution algorithms */
+#define LMUFFT_CONV_AUTO 0
+#define LMUFFT_CONV_TOEPLITZ 1 /* blocked Toeplitz contraction on MFMA */
+#define LMUFFT_CONV_FFT 2      /* LDS-resident radix FFT */
+
+int lmufft_abi_version(void);
+
+/* Text of the last error raised on the calling thread ("" if none). */
+const char* lmufft_last_error(void);
+
+/* Shape of one layer call. */
+typedef struct lmufft_shape {
+  int32_t B;   /* batch                                   */
+  int32_t T;   /* frames in this call (<= ldH)            */
+  int32_t D;   /* input_size                              */
+  int32_t M;   /* memory_size                             */
+  int32_t Hd;  /* hidden_size                             */
+  int32_t ldH; /* row stride of H = the module's seq_len  */
+} lmufft_shape;
+
+/* ------------------------------------------------------------------------
+ * Forward of the whole layer.  Replaces LMUFFT.forward, src/lmu.py:290-320:
+ *   u = relu(x . w_u + b_u)                       (src/lmu.py:300)
+ *   m[b,t,k] = sum_{s<=t} H[k,t-s] u[b,s]         (src/lmu.py:303-312)
+ *   h = relu([m;x] W_h^T + b_h), h_n = h[:,T-1,:] (src/lmu.py:315-318)
+ * Outputs u [B][T] and m [B][T][M] are what the backward needs; h [B][T][Hd],
+ * h_n [B][Hd].  All f32.
+ * ---------------------------------------------------------------------- */
+size_t lmufft_forward_workspace_bytes(const lmufft_shape* s, int dtype);
+
+int lmufft_forward_f32(const lmufft_shape* s, const float* x, const float* w_u,
+                       const float* b_u, const float* W_h, const float* b_h,
+                       const float* H, float* u, float* m, float* h, float* h_n,
+                       int conv_algo, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+/* ------------------------------------------------------------------------
+ * Backward of the whole layer (what autograd derives from src/lmu.py:300-318):
+ *   g = gh (+ gh_n on the last frame); gz = g*(h>0);
+ *   gW_h = gz^T [m;x]; gb_h = sum gz; [gm;gx1] = gz W_h;
+ *   gu[b,s] = sum_{t>=s} sum_k H[k,t-s] gm[b,t,k]; ga = gu*(u>0);
+ *   gw_u = sum ga x; gb_u = sum ga; gx = gx1 + ga w_u.
+ * gh and gh_n may each be NULL (treated as zero).  gx may be NULL when the
+ * input needs no gradient.  gm [B][T][M] is caller-provided scratch/output.
+ * ---------------------------------------------------------------------- */
+size_t lmufft_backward_workspace_bytes(const lmufft_shape* s, int dtype);
+
+int lmufft_backward_f32(const lmufft_shape* s, const float* x, const float* w_u,
+                        const float* W_h, const float* H, const float* u,
+                        const float* m, const float* h, const float* gh,
+                        const float* gh_n, float* gx, float* gw_u, float* gb_u,
+                        float* gW_h, float* gb_h, float* gm, int conv_algo,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * The causal convolution on its own (eq. 26, src/lmu.py:303-312) and its
+ * adjoint, exposed for kernel-level parity and roofline measurement.
+ *   forward : u [B][T], H [M][ldH]  ->  m [B][T][M]
+ *   backward: gm [B][T][M]          ->  gu [B][T]
+ * Only B, T, M, ldH of the shape are read.
+ * ---------------------------------------------------------------------- */
+size_t lmufft_conv_workspace_bytes(const lmufft_shape* s, int dtype, int conv_algo);
+
+int lmufft_conv_forward_f32(const lmufft_shape* s, const float* u, const float* H,
+                            float* m, int conv_algo, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
+int lmufft_conv_backward_f32(const lmufft_shape* s, const float* gm, const float* H,
+                             float* gu, int conv_algo, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LMUFFT_H_ */

@@ -1,0 +1,275 @@
+"""GPU parity tests: HIP kernels (through the C ABI) against the CPU oracle and
+against golden vectors produced by the reference.  fp32 bar: rtol 1e-4 (with an
+absolute floor of 1e-5 x the tensor's largest magnitude, because elements that
+cancel to ~0 have no meaningful relative error in fp32)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lmufft_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+ATOL_REL = 1e-5
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.fail("these tests need a GPU (run with -m 'not gpu' on CPU-only machines)")
+    return torch.device("cuda:0")
+
+
+def _close(got, ref, name, rtol=RTOL, atol_rel=ATOL_REL, cond=0.0):
+    """|got-ref| <= rtol*|ref| + atol_rel*max|ref| + 1e-6*cond.
+
+    `cond` is the sum of absolute values of the terms of a long cancelling
+    reduction (gb_u = sum of ga over all frames can be 3000x smaller than
+    sum|ga|): no fp32 summation order, the reference's included, is accurate
+    beyond ~1e-7 of that."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    scale = max(float(np.abs(ref).max()), 1e-30)
+    err = np.abs(got - ref)
+    bound = atol_rel * scale + rtol * np.abs(ref) + 1e-6 * cond
+    bad = err > bound
+    assert not bad.any(), (
+        f"{name}: {bad.sum()} of {bad.size} elements out of tolerance; max err {err.max():.3e} "
+        f"at {np.unravel_index(err.argmax(), err.shape)}, scale {scale:.3e}")
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+
+
+def _load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name + ".npz")))
+
+
+def _rand_H(rng, M, T):
+    # decaying, sign-alternating rows: same flavour as the Legendre impulse response
+    t = np.arange(T)
+    return (rng.standard_normal((M, T)) * np.exp(-t / max(T / 3, 1))[None, :]).astype(np.float32)
+
+
+CONV_SHAPES = [
+    (2, 16, 6, 16),      # tiny, scalar paths
+    (3, 37, 5, 41),      # nothing divisible by 4, T < ldH
+    (2, 100, 128, 100),  # reference smoke shape
+    (2, 200, 192, 200),  # BASELINE config 1 after 2x downsampling
+    (2, 400, 192, 400),  # BASELINE config 1
+    (1, 130, 200, 400),  # M > one 192-wide tile, T < ldH
+]
+
+
+@pytest.mark.parametrize("B,T,M,ldH", CONV_SHAPES)
+def test_conv_forward_matches_oracle(B, T, M, ldH):
+    from asr_amd import causal_conv
+
+    dev = _dev()
+    rng = np.random.default_rng(B * 1000 + T)
+    u = np.maximum(rng.standard_normal((B, T)), 0).astype(np.float32)
+    H = _rand_H(rng, M, ldH)
+    got = causal_conv(_t(u, dev), _t(H, dev), "toeplitz").cpu().numpy()
+    _close(got, orc.causal_conv_direct(u, H[:, :T]), "m")
+
+
+@pytest.mark.parametrize("B,T,M,ldH", CONV_SHAPES)
+def test_conv_backward_matches_oracle(B, T, M, ldH):
+    from asr_amd import causal_conv_adjoint
+
+    dev = _dev()
+    rng = np.random.default_rng(B * 2000 + T)
+    gm = rng.standard_normal((B, T, M)).astype(np.float32)
+    H = _rand_H(rng, M, ldH)
+    got = causal_conv_adjoint(_t(gm, dev), _t(H, dev), "toeplitz").cpu().numpy()
+    _close(got, orc.anticausal_corr_direct(gm, H[:, :T]), "gu")
+
+
+def test_conv_known_answers_full_size(golden_dir):
+    """Size-independent properties at BASELINE's full size (B=64, T=400, M=192)."""
+    from asr_amd import causal_conv, causal_conv_adjoint
+
+    dev = _dev()
+    H = _t(np.load(os.path.join(golden_dir, "buffers_theta1000_M192.npz"))["H400"], dev)
+    B, T, M = 64, 400, 192
+    g = torch.Generator(device="cpu").manual_seed(5)
+    u = torch.relu(torch.randn(B, T, generator=g)).to(dev)
+    v = torch.relu(torch.randn(B, T, generator=g)).to(dev)
+    # impulse -> impulse response
+    imp = torch.zeros(B, T, device=dev)
+    imp[:, 0] = 1.0
+    m_imp = causal_conv(imp, H)
+    assert torch.equal(m_imp[7], H.t().contiguous())
+    # shifted impulse -> shifted response, zeros before
+    imp2 = torch.zeros(1, T, device=dev)
+    imp2[0, 123] = 2.0
+    m2 = causal_conv(imp2, H)[0]
+    assert torch.count_nonzero(m2[:123]) == 0
+    torch.testing.assert_close(m2[123:], 2.0 * H.t()[: T - 123], rtol=0, atol=0)
+    # linearity
+    a = causal_conv(u, H)
+    b = causal_conv(v, H)
+    ab = causal_conv(u + 0.5 * v, H)
+    scale = float(ab.abs().max())
+    assert float((ab - (a + 0.5 * b)).abs().max()) <= 2e-6 * scale
+    # adjoint identity <conv(u), gm> == <u, adj(gm)>
+    gm = torch.randn(B, T, M, generator=g).to(dev)
+    lhs = (a.double() * gm.double()).sum().item()
+    rhs = (u.double() * causal_conv_adjoint(gm, H).double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0)
+    # causality: changing u after frame t0 leaves m before t0 untouched
+    u2 = u.clone()
+    u2[:, 200:] = 0
+    a2 = causal_conv(u2, H)
+    assert torch.equal(a2[:, :200], a[:, :200])
+
+
+GOLDEN_CASES = ["tiny_f64", "tiny_f32", "smoke100_f32", "cfg1a_f32", "cfg1c_f32"]
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_layer_matches_reference_golden(golden_dir, name):
+    """Outputs and gradients of the HIP layer vs the reference's own LMUFFT."""
+    from asr_amd import lmufft_layer
+
+    dev = _dev()
+    g = _load(golden_dir, name)
+    x = _t(g["x"], dev).requires_grad_(True)
+    w_u = _t(g["w_u"], dev).requires_grad_(True)
+    b_u = _t(g["b_u"], dev).requires_grad_(True)
+    W_h = _t(g["W_h"], dev).requires_grad_(True)
+    b_h = _t(g["b_h"], dev).requires_grad_(True)
+    H = _t(g["H"], dev)
+    h, h_n = lmufft_layer(x, w_u, b_u, W_h, b_h, H)
+    _close(h.detach().cpu().numpy(), g["h"], "h")
+    _close(h_n.detach().cpu().numpy(), g["h_n"], "h_n")
+    loss = (h * _t(g["gh"], dev)).sum()
+    if g["gh_n"].size:
+        loss = loss + (h_n * _t(g["gh_n"], dev)).sum()
+    loss.backward()
+    o = orc.lmufft_backward(g["x"], g["w_u"], g["b_u"], g["W_h"], g["b_h"], g["H"], g["gh"],
+                            g["gh_n"] if g["gh_n"].size else None)
+    ga_abs = float(np.abs(o["gu"] * (o["u"] > 0)).sum())
+    _close(x.grad.cpu().numpy(), g["gx"], "gx")
+    _close(w_u.grad.cpu().numpy(), g["gw_u"], "gw_u", cond=ga_abs * float(np.abs(g["x"]).max()))
+    _close(b_u.grad.cpu().numpy(), g["gb_u"], "gb_u", cond=ga_abs)
+    _close(W_h.grad.cpu().numpy(), g["gW_h"], "gW_h")
+    _close(b_h.grad.cpu().numpy(), g["gb_h"], "gb_h")
+
+
+LAYER_SHAPES = [
+    # B, T, D, M, Hd, ldH
+    (2, 16, 12, 6, 10, 16),
+    (3, 37, 13, 5, 9, 41),      # all-odd sizes -> scalar load paths, ragged tiles
+    (1, 1, 8, 4, 8, 4),         # single frame
+    (2, 65, 80, 192, 384, 100),  # one frame past a 64-row tile
+    (5, 129, 384, 192, 384, 200),
+]
+
+
+@pytest.mark.parametrize("B,T,D,M,Hd,ldH", LAYER_SHAPES)
+@pytest.mark.parametrize("which", ["both", "h_only", "hn_only"])
+def test_layer_matches_oracle(B, T, D, M, Hd, ldH, which):
+    from asr_amd import lmufft_layer
+
+    dev = _dev()
+    rng = np.random.default_rng(B * 7 + T * 11 + D)
+    x = rng.standard_normal((B, T, D)).astype(np.float32)
+    w_u = (rng.standard_normal((1, D)) / np.sqrt(D)).astype(np.float32)
+    b_u = np.array([0.05], dtype=np.float32)
+    W_h = (rng.standard_normal((Hd, M + D)) / np.sqrt(M + D)).astype(np.float32)
+    b_h = (0.1 * rng.standard_normal(Hd)).astype(np.float32)
+    H = _rand_H(rng, M, ldH)
+    gh = rng.standard_normal((B, T, Hd)).astype(np.float32) if which != "hn_only" else None
+    gh_n = rng.standard_normal((B, Hd)).astype(np.float32) if which != "h_only" else None
+    ref = orc.lmufft_backward(x, w_u, b_u, W_h, b_h, H[:, :T],
+                              gh if gh is not None else np.zeros((B, T, Hd)), gh_n)
+
+    tx = _t(x, dev).requires_grad_(True)
+    params = [_t(a, dev).requires_grad_(True) for a in (w_u, b_u, W_h, b_h)]
+    h, h_n = lmufft_layer(tx, *params, _t(H, dev))
+    _close(h.detach().cpu().numpy(), ref["h"], "h")
+    _close(h_n.detach().cpu().numpy(), ref["h_n"], "h_n")
+    loss = 0
+    if gh is not None:
+        loss = loss + (h * _t(gh, dev)).sum()
+    if gh_n is not None:
+        loss = loss + (h_n * _t(gh_n, dev)).sum()
+    loss.backward()
+    _close(tx.grad.cpu().numpy(), ref["gx"], "gx")
+    ga_abs = float(np.abs(ref["gu"] * (ref["u"] > 0)).sum())
+    conds = {"gw_u": ga_abs * float(np.abs(x).max()), "gb_u": ga_abs, "gW_h": 0.0, "gb_h": 0.0}
+    for t, k in zip(params, ("gw_u", "gb_u", "gW_h", "gb_h")):
+        _close(t.grad.cpu().numpy(), ref[k], k, cond=conds[k])
+
+
+def test_module_state_dict_roundtrip_and_forward(golden_dir):
+    from asr_amd import LMUFFT
+
+    dev = _dev()
+    g = _load(golden_dir, "cfg1a_f32")
+    layer = LMUFFT(80, 384, 192, 400, 1000)
+    sd = layer.state_dict()
+    sd["W_u.weight"] = torch.from_numpy(g["w_u"])
+    sd["W_u.bias"] = torch.from_numpy(g["b_u"])
+    sd["W_h.weight"] = torch.from_numpy(g["W_h"])
+    sd["W_h.bias"] = torch.from_numpy(g["b_h"])
+    layer.load_state_dict(sd)
+    layer = layer.to(dev)
+    h, h_n = layer(_t(g["x"], dev))
+    # H here is the module's own (built by the constructor, not injected)
+    _close(h.detach().cpu().numpy(), g["h"], "h")
+    assert torch.equal(h_n, h[:, -1, :])
+    # shorter sequences than seq_len are accepted and equal the prefix (causality)
+    h_short, _ = layer(_t(g["x"][:, :150], dev))
+    assert torch.equal(h_short, h[:, :150])
+    # longer ones are rejected
+    with pytest.raises(RuntimeError, match="exceeds"):
+        layer(torch.zeros(1, 401, 80, device=dev))
+
+
+def test_full_size_layer_properties(golden_dir):
+    """BASELINE config 2 layer shape (B=64, T=400, 384/192): oracle on a slice,
+    gradient identity on the whole."""
+    from asr_amd import LMUFFT
+
+    dev = _dev()
+    torch.manual_seed(3)
+    layer = LMUFFT(384, 384, 192, 400, 1000)
+    torch.nn.init.xavier_uniform_(layer.W_u.weight)
+    torch.nn.init.xavier_uniform_(layer.W_h.weight)
+    torch.nn.init.zeros_(layer.W_u.bias)
+    torch.nn.init.zeros_(layer.W_h.bias)
+    layer = layer.to(dev)
+    x = torch.randn(64, 400, 384, device=dev, requires_grad=True)
+    h, h_n = layer(x)
+    gh = torch.randn_like(h)
+    (h * gh).sum().backward()
+    # batch item 17 against the oracle (items are independent)
+    b = 17
+    sd = {k: v.detach().cpu().numpy() for k, v in layer.state_dict().items() if k != "fft_H"}
+    ref = orc.lmufft_backward(x[b : b + 1].detach().cpu().numpy(), sd["W_u.weight"], sd["W_u.bias"],
+                              sd["W_h.weight"], sd["W_h.bias"], sd["H"], gh[b : b + 1].cpu().numpy())
+    _close(h[b : b + 1].detach().cpu().numpy(), ref["h"], "h[17]")
+    _close(x.grad[b : b + 1].cpu().numpy(), ref["gx"], "gx[17]")
+    # directional derivative: <grad_W, dW> == d/de loss(W + e dW) to first order,
+    # evaluated with the kernels themselves at two step sizes (fp32-limited)
+    gW = layer.W_h.weight.grad.double()
+    gbh = layer.W_h.bias.grad.double()
+    # bias gradient equals the sum of masked upstream gradient
+    ref_gb = (gh.double() * (h > 0)).sum(dim=(0, 1))
+    torch.testing.assert_close(gbh, ref_gb, rtol=1e-4, atol=1e-4 * float(ref_gb.abs().max()))
+    # weight gradient against an fp64 torch evaluation from the kernel's own h mask
+    with torch.no_grad():
+        from asr_amd import causal_conv
+
+        u = torch.relu(x.detach() @ layer.W_u.weight.t() + layer.W_u.bias).squeeze(-1)
+        m = causal_conv(u, layer.H)
+        mx = torch.cat([m, x.detach()], dim=-1).double().reshape(-1, 576)
+        gz = (gh.double() * (h > 0)).reshape(-1, 384)
+        ref_gW = gz.t() @ mx
+    torch.testing.assert_close(gW, ref_gW, rtol=1e-4, atol=1e-5 * float(ref_gW.abs().max()))
