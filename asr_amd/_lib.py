@@ -61,6 +61,15 @@ def _load():
     lib.lmufft_conv_forward_f32.argtypes = [sp, vp, vp, vp, ci, vp, sz, vp]
     lib.lmufft_conv_backward_f32.restype = ci
     lib.lmufft_conv_backward_f32.argtypes = [sp, vp, vp, vp, ci, vp, sz, vp]
+    lib.lmufft_profile_enable.restype = ci
+    lib.lmufft_profile_enable.argtypes = [ci]
+    lib.lmufft_profile_reset.restype = None
+    lib.lmufft_profile_reset.argtypes = []
+    lib.lmufft_profile_count.restype = ci
+    lib.lmufft_profile_count.argtypes = []
+    lib.lmufft_profile_get.restype = ci
+    lib.lmufft_profile_get.argtypes = [ci, ctypes.c_char_p, sz, ctypes.POINTER(ctypes.c_double),
+                                       ctypes.POINTER(ctypes.c_int64)]
     got = lib.lmufft_abi_version()
     if got != ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI version {got}, expected {ABI_VERSION}; rebuild it")
@@ -80,7 +89,31 @@ EXPORTS = (
     "lmufft_conv_workspace_bytes",
     "lmufft_conv_forward_f32",
     "lmufft_conv_backward_f32",
+    "lmufft_profile_enable",
+    "lmufft_profile_reset",
+    "lmufft_profile_count",
+    "lmufft_profile_get",
 )
+
+
+def profile_enable(on: bool) -> None:
+    lib.lmufft_profile_enable(1 if on else 0)
+
+
+def profile_reset() -> None:
+    lib.lmufft_profile_reset()
+
+
+def profile_read() -> dict:
+    """{kernel name: (total_ms, launches)} accumulated since the last reset."""
+    out = {}
+    for i in range(lib.lmufft_profile_count()):
+        name = ctypes.create_string_buffer(128)
+        ms = ctypes.c_double(0.0)
+        n = ctypes.c_int64(0)
+        check(lib.lmufft_profile_get(i, name, 128, ctypes.byref(ms), ctypes.byref(n)), "lmufft_profile_get")
+        out[name.value.decode()] = (ms.value, n.value)
+    return out
 
 
 def check(rc: int, what: str) -> None:

@@ -6,16 +6,18 @@
 //   k_encode_fwd   u = relu(x . w_u + b_u)                      HBM-bound
 //   k_conv_fwd     m = Toeplitz(u) * H^T  (causal conv)         MFMA f32
 //   k_proj_fwd     h = relu([m;x] W_h^T + b_h), h_n             MFMA f32
-//   k_dgrad        [gm;gx1] = (g*(h>0)) W_h                     MFMA f32
+//   k_dgrad        gm = gz W_h[:, :M]; gx = gz W_h[:, M:] + ga w_u    MFMA f32
 //   k_wgrad        gW_h, gb_h partial slabs (split over rows)   MFMA f32
 //   k_conv_bwd     gu partial = diag-sums of gm * H             MFMA f32
 //   k_gu_reduce    gu = sum of partial slabs, ga = gu*(u>0)
-//   k_encode_bwd   gx += ga w_u ; gw_u, gb_u partial slabs      HBM-bound
+//   k_encode_bwd   gw_u, gb_u partial slabs                     HBM-bound
 //   k_reduce_slabs deterministic slab sums for parameter grads
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+
+#include <type_traits>
 
 #include "gemm_core_f32.h"
 #include "lmufft.h"
@@ -178,7 +180,11 @@ __device__ __forceinline__ f32x4 load_gz4(const float* __restrict__ h, const flo
 }
 
 // ---------------------------------------------------------------------------
-// [gm ; gx1] = gz W_h     (rows x (M+D), K = Hd)
+// out[row][j - j_begin] = sum_n gz[row][n] W_h[n][j]  (+ ga[row] * w_u[j - j_begin])
+// for the column range [j_begin, j_begin + ncols) of W_h.  Called twice:
+//   columns [0, M)    -> gm  (input of the adjoint convolution)
+//   columns [M, M+D)  -> gx, with the encoder's rank-1 term ga w_u fused into
+//                        the epilogue, so gx is written exactly once.
 // ---------------------------------------------------------------------------
 using DgradTile = Tile<64, 192, 32, 2, 2, KC, NC>;
 
@@ -186,14 +192,14 @@ template <bool VEC>
 __global__ __launch_bounds__(kThreads) void k_dgrad(const float* __restrict__ h,
                                                     const float* __restrict__ gh,
                                                     const float* __restrict__ gh_n,
-                                                    const float* __restrict__ W, float* __restrict__ gm,
-                                                    float* __restrict__ gx, int rows, int T, int M, int D,
-                                                    int Hd) {
+                                                    const float* __restrict__ W, float* __restrict__ out,
+                                                    const float* __restrict__ ga,
+                                                    const float* __restrict__ w_u, int rows, int T, int Hd,
+                                                    int ldw, int j_begin, int ncols) {
   using TL = DgradTile;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n0 = blockIdx.x * TL::BN;
   const int m0 = blockIdx.y * TL::BM;
-  const int MD = M + D;
 
   auto la = [=](int r, int k) -> f32x4 {
     const long row = m0 + r;
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(kThreads) void k_dgrad(const float* __restrict__ h,
   auto lb = [=](int r, int k) -> f32x4 {
     if (k >= Hd) return zero4();
     const int j = n0 + r;
-    return load4<VEC>(W, (long)k * MD + j, j, MD);
+    return load4<VEC>(W, (long)k * ldw + j_begin + j, j, ncols);
   };
 
   WavePos<TL> w;
@@ -215,11 +221,9 @@ __global__ __launch_bounds__(kThreads) void k_dgrad(const float* __restrict__ h,
   tile_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
     const long row = m0 + mm;
     const int j = n0 + nn;
-    if (row < rows && j < MD) {
-      if (j < M)
-        gm[row * M + j] = v;
-      else if (gx)
-        gx[row * D + (j - M)] = v;
+    if (row < rows && j < ncols) {
+      if (ga) v += ga[row] * w_u[j];
+      out[row * ncols + j] = v;
     }
   });
 }
@@ -379,16 +383,14 @@ __global__ __launch_bounds__(kThreads) void k_gu_reduce(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------
-// gx[row,:] += ga[row] w_u ; partial gw_u = sum_rows ga[row] x[row,:], gb_u
-// One wave per row, rows with ga == 0 (ReLU-dead frames, about half of them)
-// touch neither x nor gx.  Slab per workgroup: [D + 1].
+// partial gw_u = sum_rows ga[row] x[row,:], partial gb_u = sum_rows ga[row]
+// One wave per row; rows with ga == 0 (ReLU-dead frames, about half of them)
+// do not touch x.  Slab per workgroup: [D + 1].
 // ---------------------------------------------------------------------------
 template <bool VEC>
 __global__ __launch_bounds__(kThreads) void k_encode_bwd(const float* __restrict__ ga,
-                                                         const float* __restrict__ x,
-                                                         const float* __restrict__ w_u, float* __restrict__ gx,
-                                                         float* __restrict__ part, int rows, int D,
-                                                         int rows_per_block) {
+                                                         const float* __restrict__ x, float* __restrict__ part,
+                                                         int rows, int D, int rows_per_block) {
   __shared__ float red[4][kThreads];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r0 = blockIdx.x * rows_per_block;
@@ -399,26 +401,10 @@ __global__ __launch_bounds__(kThreads) void k_encode_bwd(const float* __restrict
     const int c = c0 + lane * 4;
     f32x4 acc = zero4();
     float gsum = 0.f;
-    const f32x4 wv = load4<VEC>(w_u, c, c, D);
     for (int row = r0 + wave; row < r1; row += 4) {
       const float g = ga[row];
       gsum += g;
-      if (g != 0.f && c < D) {
-        const f32x4 xv = load4<VEC>(x, (long)row * D + c, c, D);
-        acc += g * xv;
-        if (gx) {
-          float* gp = gx + (long)row * D + c;
-          if (VEC) {
-            f32x4 o = *reinterpret_cast<f32x4*>(gp);
-            o += g * wv;
-            *reinterpret_cast<f32x4*>(gp) = o;
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (c + j < D) gp[j] += g * wv[j];
-          }
-        }
-      }
+      if (g != 0.f && c < D) acc += g * load4<VEC>(x, (long)row * D + c, c, D);
     }
     __syncthreads();
 #pragma unroll
@@ -435,18 +421,37 @@ __global__ __launch_bounds__(kThreads) void k_encode_bwd(const float* __restrict
   }
 }
 
-// out0[i] (i < n0) and out1[i - n0] (n0 <= i < n0+n1) = sum_s in[s*stride + i]
+// out0[i] (i < n0) and out1[i - n0] (n0 <= i < n0+n1) = sum_s in[s*stride + i],
+// slabs added in index order (deterministic).  Eight slabs are in flight per
+// thread; with VEC each thread owns four consecutive outputs (stride, n0 % 4 == 0).
+template <bool VEC>
 __global__ __launch_bounds__(kThreads) void k_reduce_slabs(const float* __restrict__ in, int S, long stride,
                                                            float* __restrict__ out0, long n0,
                                                            float* __restrict__ out1, long n1) {
   const long n = n0 + n1;
-  for (long i = blockIdx.x * (long)kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
-    float s = 0.f;
-    for (int k = 0; k < S; ++k) s += in[k * stride + i];
-    if (i < n0)
-      out0[i] = s;
-    else
-      out1[i - n0] = s;
+  constexpr int W = VEC ? 4 : 1;
+  typedef typename std::conditional<VEC, f32x4, float>::type vec_t;
+  for (long i = (blockIdx.x * (long)kThreads + threadIdx.x) * W; i < n; i += (long)gridDim.x * kThreads * W) {
+    vec_t s = vec_t(0.f);
+    int k = 0;
+    for (; k + 8 <= S; k += 8) {
+      vec_t v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const vec_t*>(in + (k + q) * stride + i);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += v[q];
+    }
+    for (; k < S; ++k) s += *reinterpret_cast<const vec_t*>(in + k * stride + i);
+    float o[4];
+    *reinterpret_cast<vec_t*>(o) = s;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const long idx = i + j;
+      if (idx < n0)
+        out0[idx] = o[j];
+      else if (idx < n)
+        out1[idx - n0] = o[j];
+    }
   }
 }
 
@@ -505,11 +510,30 @@ static int check_shape(const lmufft_shape* s) {
   return 0;
 }
 
+#define PROF(name) ProfScope prof_scope_(name, st)
 #define LAUNCH_CHECK(name)                                                            \
   do {                                                                                \
     hipError_t e_ = hipGetLastError();                                                \
     if (e_ != hipSuccess) return set_error("launch of %s failed: %s", name, hipGetErrorString(e_)); \
   } while (0)
+
+static int reduce_slabs(const float* in, int S, long stride, float* out0, long n0, float* out1, long n1,
+                        hipStream_t st) {
+  // vector path: every slab row and both outputs stay 16-byte aligned and n0 + n1 is a multiple of 4
+  const bool vec = (stride % 4 == 0) && (n0 % 4 == 0) && (n1 % 4 == 0) && aligned16(in) && aligned16(out0) &&
+                   aligned16(out1);
+  const long work = vec ? (n0 + n1) / 4 : (n0 + n1);
+  const dim3 grid(min(cdiv(work, kThreads), 4096));
+  {
+    PROF("k_reduce_slabs");
+    if (vec)
+      hipLaunchKernelGGL(k_reduce_slabs<true>, grid, dim3(kThreads), 0, st, in, S, stride, out0, n0, out1, n1);
+    else
+      hipLaunchKernelGGL(k_reduce_slabs<false>, grid, dim3(kThreads), 0, st, in, S, stride, out0, n0, out1, n1);
+  }
+  LAUNCH_CHECK("k_reduce_slabs");
+  return 0;
+}
 
 static int conv_forward_toeplitz(const lmufft_shape& s, const float* u, const float* H, float* m,
                                  hipStream_t st) {
@@ -517,10 +541,13 @@ static int conv_forward_toeplitz(const lmufft_shape& s, const float* u, const fl
   const dim3 grid(cdiv(s.M, TL::BN), s.B, cdiv(s.T, TL::BM));
   const size_t lds = TL::SMEM_FLOATS * sizeof(float);
   const bool vec = (s.ldH % 4 == 0) && (s.T % 4 == 0) && aligned16(H);
+  {
+  PROF("k_conv_fwd");
   if (vec)
     hipLaunchKernelGGL(k_conv_fwd<true>, grid, dim3(kThreads), lds, st, u, H, m, s.T, s.M, s.ldH);
   else
     hipLaunchKernelGGL(k_conv_fwd<false>, grid, dim3(kThreads), lds, st, u, H, m, s.T, s.M, s.ldH);
+  }
   LAUNCH_CHECK("k_conv_fwd");
   return 0;
 }
@@ -534,19 +561,25 @@ static int conv_backward_toeplitz(const lmufft_shape& s, const float* gm, const 
   const size_t lds = (TL::SMEM_FLOATS + (size_t)ntt * TL::BM) * sizeof(float);
   if (lds > 160 * 1024) return set_error("sequence too long for the Toeplitz backward kernel (T=%d)", s.T);
   const bool vec = (s.ldH % 4 == 0) && (s.T % 4 == 0) && (s.M % 4 == 0) && aligned16(H) && aligned16(gm);
-  if (vec) {
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)k_conv_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_conv_bwd<true>, grid, dim3(kThreads), lds, st, gm, H, gu_part, s.T, s.M, s.ldH);
-  } else {
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)k_conv_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_conv_bwd<false>, grid, dim3(kThreads), lds, st, gm, H, gu_part, s.T, s.M, s.ldH);
+  if (lds > 64 * 1024) {
+    const void* fn = vec ? (const void*)k_conv_bwd<true> : (const void*)k_conv_bwd<false>;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return set_error("cannot reserve %zu bytes of LDS for k_conv_bwd", lds);
+  }
+  {
+    PROF("k_conv_bwd");
+    if (vec)
+      hipLaunchKernelGGL(k_conv_bwd<true>, grid, dim3(kThreads), lds, st, gm, H, gu_part, s.T, s.M, s.ldH);
+    else
+      hipLaunchKernelGGL(k_conv_bwd<false>, grid, dim3(kThreads), lds, st, gm, H, gu_part, s.T, s.M, s.ldH);
   }
   LAUNCH_CHECK("k_conv_bwd");
   const long n = (long)s.B * s.T;
+  {
+  PROF("k_gu_reduce");
   hipLaunchKernelGGL(k_gu_reduce, dim3(min(cdiv(n, kThreads), 2048)), dim3(kThreads), 0, st, gu_part, u, out,
                      s.B, s.T, ntt, TL::BM);
+  }
   LAUNCH_CHECK("k_gu_reduce");
   return 0;
 }
@@ -623,10 +656,13 @@ int lmufft_forward_f32(const lmufft_shape* s, const float* x, const float* w_u, 
   {  // eq. 18
     const bool vec = (s->D % 4 == 0) && aligned16(x) && aligned16(w_u);
     const dim3 grid(min(cdiv(rows, 4), 4096));
+    {
+    PROF("k_encode_fwd");
     if (vec)
       hipLaunchKernelGGL(k_encode_fwd<true>, grid, dim3(kThreads), 0, st, x, w_u, b_u, u, (int)rows, s->D);
     else
       hipLaunchKernelGGL(k_encode_fwd<false>, grid, dim3(kThreads), 0, st, x, w_u, b_u, u, (int)rows, s->D);
+    }
     LAUNCH_CHECK("k_encode_fwd");
   }
   if (int rc = conv_forward_toeplitz(*s, u, H, m, st)) return rc;  // eq. 26
@@ -635,12 +671,15 @@ int lmufft_forward_f32(const lmufft_shape* s, const float* x, const float* w_u, 
     const bool vec = (s->M % 4 == 0) && (s->D % 4 == 0) && aligned16(m) && aligned16(x) && aligned16(W_h);
     const dim3 grid(cdiv(s->Hd, TL::BN), cdiv(rows, TL::BM));
     const size_t lds = TL::SMEM_FLOATS * sizeof(float);
+    {
+    PROF("k_proj_fwd");
     if (vec)
       hipLaunchKernelGGL(k_proj_fwd<true>, grid, dim3(kThreads), lds, st, m, x, W_h, b_h, h, h_n, (int)rows,
                          s->T, s->M, s->D, s->Hd);
     else
       hipLaunchKernelGGL(k_proj_fwd<false>, grid, dim3(kThreads), lds, st, m, x, W_h, b_h, h, h_n, (int)rows,
                          s->T, s->M, s->D, s->Hd);
+    }
     LAUNCH_CHECK("k_proj_fwd");
     (void)MD;
   }
@@ -669,51 +708,63 @@ int lmufft_backward_f32(const lmufft_shape* s, const float* x, const float* w_u,
   const int MD = s->M + s->D;
   const bool vec_h = (s->Hd % 4 == 0) && aligned16(h) && (!gh || aligned16(gh)) && (!gh_n || aligned16(gh_n));
 
-  {  // [gm ; gx1] = gz W_h
+  auto dgrad = [&](float* out, int j_begin, int ncols, const float* ga_, const float* wu_) -> int {
     using TL = DgradTile;
-    const bool vec = vec_h && (MD % 4 == 0) && aligned16(W_h);
-    const dim3 grid(cdiv(MD, TL::BN), cdiv(rows, TL::BM));
+    const bool vec = vec_h && (MD % 4 == 0) && (j_begin % 4 == 0) && (ncols % 4 == 0) && aligned16(W_h);
+    const dim3 grid(cdiv(ncols, TL::BN), cdiv(rows, TL::BM));
     const size_t lds = TL::SMEM_FLOATS * sizeof(float);
-    if (vec)
-      hipLaunchKernelGGL(k_dgrad<true>, grid, dim3(kThreads), lds, st, h, gh, gh_n, W_h, gm, gx, (int)rows,
-                         s->T, s->M, s->D, s->Hd);
-    else
-      hipLaunchKernelGGL(k_dgrad<false>, grid, dim3(kThreads), lds, st, h, gh, gh_n, W_h, gm, gx, (int)rows,
-                         s->T, s->M, s->D, s->Hd);
+    {
+      PROF("k_dgrad");
+      if (vec)
+        hipLaunchKernelGGL(k_dgrad<true>, grid, dim3(kThreads), lds, st, h, gh, gh_n, W_h, out, ga_, wu_,
+                           (int)rows, s->T, s->Hd, MD, j_begin, ncols);
+      else
+        hipLaunchKernelGGL(k_dgrad<false>, grid, dim3(kThreads), lds, st, h, gh, gh_n, W_h, out, ga_, wu_,
+                           (int)rows, s->T, s->Hd, MD, j_begin, ncols);
+    }
     LAUNCH_CHECK("k_dgrad");
-  }
+    return 0;
+  };
+
+  // gm = gz W_h[:, :M]
+  if (int rc = dgrad(gm, 0, s->M, nullptr, nullptr)) return rc;
+  // ga = (adjoint conv of gm) * (u > 0)
+  if (int rc = conv_backward_toeplitz(*s, gm, H, u, gupart, ga, st)) return rc;
+  // gx = gz W_h[:, M:] + ga w_u
+  if (gx)
+    if (int rc = dgrad(gx, s->M, s->D, ga, w_u)) return rc;
   {  // gW_h, gb_h slabs
     using TL = WgradTile;
     const bool vec = vec_h && (s->M % 4 == 0) && (s->D % 4 == 0) && aligned16(m) && aligned16(x);
     const dim3 grid(cdiv(MD, TL::BN), cdiv(s->Hd, TL::BM), p.S);
     const size_t lds = TL::SMEM_FLOATS * sizeof(float);
-    if (vec)
-      hipLaunchKernelGGL(k_wgrad<true>, grid, dim3(kThreads), lds, st, h, gh, gh_n, m, x, wslab, (int)rows,
-                         p.rps, s->T, s->M, s->D, s->Hd);
-    else
-      hipLaunchKernelGGL(k_wgrad<false>, grid, dim3(kThreads), lds, st, h, gh, gh_n, m, x, wslab, (int)rows,
-                         p.rps, s->T, s->M, s->D, s->Hd);
+    {
+      PROF("k_wgrad");
+      if (vec)
+        hipLaunchKernelGGL(k_wgrad<true>, grid, dim3(kThreads), lds, st, h, gh, gh_n, m, x, wslab, (int)rows,
+                           p.rps, s->T, s->M, s->D, s->Hd);
+      else
+        hipLaunchKernelGGL(k_wgrad<false>, grid, dim3(kThreads), lds, st, h, gh, gh_n, m, x, wslab, (int)rows,
+                           p.rps, s->T, s->M, s->D, s->Hd);
+    }
     LAUNCH_CHECK("k_wgrad");
     const long n0 = (long)s->Hd * MD;
-    hipLaunchKernelGGL(k_reduce_slabs, dim3(min(cdiv(n0 + s->Hd, kThreads), 2048)), dim3(kThreads), 0, st,
-                       wslab, p.S, n0 + s->Hd, gW_h, n0, gb_h, (long)s->Hd);
-    LAUNCH_CHECK("k_reduce_slabs");
+    if (int rc = reduce_slabs(wslab, p.S, n0 + s->Hd, gW_h, n0, gb_h, (long)s->Hd, st)) return rc;
   }
-  // ga = (adjoint conv of gm) * (u > 0)
-  if (int rc = conv_backward_toeplitz(*s, gm, H, u, gupart, ga, st)) return rc;
-  {  // gx += ga w_u ; gw_u, gb_u
-    const bool vec = (s->D % 4 == 0) && aligned16(x) && aligned16(w_u) && (!gx || aligned16(gx));
+  {  // gw_u, gb_u
+    const bool vec = (s->D % 4 == 0) && aligned16(x);
     const dim3 grid(p.enc_blocks);
-    if (vec)
-      hipLaunchKernelGGL(k_encode_bwd<true>, grid, dim3(kThreads), 0, st, ga, x, w_u, gx, encpart, (int)rows,
-                         s->D, kEncRowsPerBlock);
-    else
-      hipLaunchKernelGGL(k_encode_bwd<false>, grid, dim3(kThreads), 0, st, ga, x, w_u, gx, encpart, (int)rows,
-                         s->D, kEncRowsPerBlock);
+    {
+      PROF("k_encode_bwd");
+      if (vec)
+        hipLaunchKernelGGL(k_encode_bwd<true>, grid, dim3(kThreads), 0, st, ga, x, encpart, (int)rows, s->D,
+                           kEncRowsPerBlock);
+      else
+        hipLaunchKernelGGL(k_encode_bwd<false>, grid, dim3(kThreads), 0, st, ga, x, encpart, (int)rows, s->D,
+                           kEncRowsPerBlock);
+    }
     LAUNCH_CHECK("k_encode_bwd");
-    hipLaunchKernelGGL(k_reduce_slabs, dim3(min(cdiv(s->D + 1, kThreads), 2048)), dim3(kThreads), 0, st,
-                       encpart, p.enc_blocks, (long)(s->D + 1), gw_u, (long)s->D, gb_u, 1L);
-    LAUNCH_CHECK("k_reduce_slabs");
+    if (int rc = reduce_slabs(encpart, p.enc_blocks, (long)(s->D + 1), gw_u, (long)s->D, gb_u, 1L, st)) return rc;
   }
   return 0;
 }

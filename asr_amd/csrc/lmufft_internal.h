@@ -1,5 +1,6 @@
 // Helpers shared by the translation units of liblmufft_hip.so (not part of the ABI).
 #pragma once
+#include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
 
@@ -18,5 +19,20 @@ inline int set_error(const char* fmt, ...) {
   va_end(ap);
   return 1;
 }
+
+// Brackets one kernel launch with HIP events when profiling is enabled
+// (lmufft_profile_enable); a no-op otherwise.
+bool profiling_enabled();
+class ProfScope {
+ public:
+  ProfScope(const char* name, hipStream_t st);
+  ~ProfScope();
+
+ private:
+  bool active_;
+  hipStream_t st_;
+  int id_ = -1;
+  hipEvent_t start_ = nullptr, stop_ = nullptr;
+};
 
 }  // namespace lmufft

@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""Benchmark of the LMUFFT hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = forward + backward through the encoder's stack of three LMUFFT
+layers (hidden 384, memory 192, theta 1000, 400 frames; BASELINE config 2's
+layer shape) on one synthetic batch of 64 utterances per GPU, including the
+data-parallel gradient exchange.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, spec
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # dense matrix peaks, spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
+    ap.add_argument("--frames", type=int, default=400)
+    ap.add_argument("--layers", type=int, default=3)
+    ap.add_argument("--hidden", type=int, default=384)
+    ap.add_argument("--memory", type=int, default=192)
+    ap.add_argument("--theta", type=float, default=1000.0)
+    ap.add_argument("--conv", default="auto", choices=["auto", "toeplitz", "fft"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def kernel_work(name, B, T, D, M, Hd, s=4):
+    """Algorithmic (flops, bytes, bound) of a kernel's launches in ONE layer's forward+backward."""
+    rows = B * T
+    MD = M + D
+    wbytes = Hd * MD * s
+    table = {
+        "k_proj_fwd": (2.0 * rows * MD * Hd, rows * (MD + Hd) * s + wbytes, "mfma"),
+        "k_dgrad": (2.0 * rows * MD * Hd, rows * (2 * Hd + MD) * s + wbytes, "mfma"),
+        "k_wgrad": (2.0 * rows * MD * Hd, rows * (2 * Hd + MD) * s + wbytes, "mfma"),
+        "k_conv_fwd": (1.0 * B * T * (T + 1) * M, rows * (M + 1) * s + M * T * 4, "mfma"),
+        "k_conv_bwd": (1.0 * B * T * (T + 1) * M, rows * (M + 1) * s + M * T * 4, "mfma"),
+        "k_encode_fwd": (2.0 * rows * D, rows * (D + 1) * s, "hbm"),
+        "k_encode_bwd": (4.0 * rows * D, rows * (3 * D + 1) * s, "hbm"),
+    }
+    return table.get(name)
+
+
+def cpu_baseline(args, H, seconds):
+    """The reference's own route (torch.fft + autograd) timed on the host cores."""
+    from oracle.lmufft_torch_port import PortLMUFFT
+
+    threads = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(threads)
+    torch.manual_seed(1234)
+    Hc = H.cpu()
+    layers = [PortLMUFFT(args.hidden, args.hidden, args.memory, Hc) for _ in range(args.layers)]
+    for l in layers:
+        torch.nn.init.xavier_uniform_(l.W_u.weight)
+        torch.nn.init.xavier_uniform_(l.W_h.weight)
+        torch.nn.init.zeros_(l.W_u.bias)
+        torch.nn.init.zeros_(l.W_h.bias)
+    x = torch.randn(args.batch, args.frames, args.hidden, requires_grad=True)
+    gy = torch.randn(args.batch, args.frames, args.hidden)
+
+    def step():
+        y = x
+        for l in layers:
+            y, _ = l(y)
+        y.backward(gy)
+        x.grad = None
+        for l in layers:
+            l.zero_grad(set_to_none=True)
+
+    step()
+    times = []
+    t_end = time.perf_counter() + seconds
+    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 50):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {
+        "value": args.batch * args.frames / med,
+        "unit": "frames/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"same workload (batch {args.batch} x {args.frames} frames x {args.layers} layers, fp32, "
+                  f"torch.fft route + autograd), median of {len(times)} steps, {med * 1e3:.1f} ms/step",
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the LMUFFT layer has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from asr_amd import LMUFFT, _lib
+    from asr_amd.parallel import GradBuckets
+
+    B, T, D, M, Hd = args.batch, args.frames, args.hidden, args.memory, args.hidden
+    torch.manual_seed(1234)  # identical parameters on every rank
+    layers = []
+    for _ in range(args.layers):
+        l = LMUFFT(D, Hd, M, T, args.theta, conv_algo=args.conv)
+        # the reference model re-initialises every nn.Linear like this (src/models/asr_model.py:271-276)
+        torch.nn.init.xavier_uniform_(l.W_u.weight)
+        torch.nn.init.xavier_uniform_(l.W_h.weight)
+        torch.nn.init.zeros_(l.W_u.bias)
+        torch.nn.init.zeros_(l.W_h.bias)
+        layers.append(l.to(dev))
+    buckets = GradBuckets([list(l.parameters()) for l in reversed(layers)])
+    g = torch.Generator(device=dev).manual_seed(1234 + 2 + rank)  # each rank its own utterances
+    x = torch.randn(B, T, D, device=dev, generator=g).requires_grad_(True)
+    gy = torch.randn(B, T, Hd, device=dev, generator=g)
+
+    def step():
+        buckets.zero_grad()
+        x.grad = None
+        y = x
+        for l in layers:
+            y, _ = l(y)
+        y.backward(gy)
+        buckets.finish()
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # second, untimed pass with event brackets around every kernel launch
+    # (every rank runs it -- the steps contain collectives -- but only rank 0 records events)
+    kern = {}
+    if rank == 0:
+        _lib.profile_reset()
+        _lib.profile_enable(True)
+    for _ in range(min(args.steps, 10)):
+        step()
+    torch.cuda.synchronize(dev)
+    if rank == 0:
+        _lib.profile_enable(False)
+        kern = _lib.profile_read()
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        value = world * B * T / (elapsed / args.steps)
+        per_kernel = {k: {"avg_us": v[0] / max(v[1], 1) * 1e3, "launches_per_step": v[1] / min(args.steps, 10),
+                          "total_ms_per_step": v[0] / min(args.steps, 10)} for k, v in kern.items()}
+        dom = max(per_kernel, key=lambda k: per_kernel[k]["total_ms_per_step"]) if per_kernel else None
+        roofline = None
+        if dom and kernel_work(dom, B, T, D, M, Hd):
+            flops, nbytes, bound = kernel_work(dom, B, T, D, M, Hd)
+            per_layer = per_kernel[dom]["launches_per_step"] / args.layers  # launches per layer pass
+            flops, nbytes = flops / per_layer, nbytes / per_layer  # per launch, like the duration
+            dur_s = per_kernel[dom]["avg_us"] * 1e-6
+            if bound == "mfma":
+                achieved, peak, unit = flops / dur_s / 1e12, MFMA_PEAK_TFLOPS["f32"], "TFLOP/s"
+            else:
+                achieved, peak, unit = nbytes / dur_s / 1e9, HBM_PEAK_GBS, "GB/s"
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(dom)
+            roofline = {"kernel": dom, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
+                        "frac": achieved / peak, "traffic": traffic, "avg_us": per_kernel[dom]["avg_us"],
+                        "algorithmic_flops": flops, "algorithmic_bytes": nbytes}
+        # whole-step view against the layer's algorithmic HBM bytes: (3D+3Hd)*4 B per frame and layer
+        layer_bytes = args.layers * B * T * (3 * D + 3 * Hd) * 4
+        t_kern = sum(v["total_ms_per_step"] for v in per_kernel.values()) * 1e-3
+        out = {
+            "metric": "LMU encoder fwd+bwd frames/sec",
+            "value": value,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.layers} stacked LMUFFT layers (input {D}, hidden {Hd}, memory {M}, theta "
+                            f"{args.theta:g}, seq_len {T}) fwd+bwd, batch {B} per GPU, fp32, conv={args.conv}; "
+                            "BASELINE config 2 layer shape",
+                "batch_per_gpu": B, "frames": T, "layers": args.layers, "parallelism": f"dp{world}",
+            },
+            "roofline": roofline,
+            "step_hbm": {"algorithmic_bytes_per_step": layer_bytes,
+                         "achieved_GBs_wall": layer_bytes / (elapsed / args.steps) / 1e9,
+                         "achieved_GBs_kernels": layer_bytes / t_kern / 1e9 if t_kern else None,
+                         "frac_of_peak_wall": layer_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
+            "kernels": per_kernel,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, layers[0].H, args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

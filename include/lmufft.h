@@ -107,6 +107,19 @@ int lmufft_conv_backward_f32(const lmufft_shape* s, const float* gm, const float
                              float* gu, int conv_algo, void* workspace,
                              size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Per-kernel timing with HIP events on the caller's stream (no counterpart in
+ * the reference, which has no profiling hooks).  While enabled, every kernel
+ * launch made by this library is bracketed by two events; the totals are read
+ * back per kernel name.  Off by default; enabling it makes calls allocate
+ * events, so keep it off in production and under graph capture.
+ * ---------------------------------------------------------------------- */
+int lmufft_profile_enable(int on);
+void lmufft_profile_reset(void);
+int lmufft_profile_count(void);
+int lmufft_profile_get(int index, char* name, size_t name_len, double* total_ms,
+                       int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif
