@@ -61,6 +61,14 @@ def _load():
     lib.lmufft_conv_forward_f32.argtypes = [sp, vp, vp, vp, ci, vp, sz, vp]
     lib.lmufft_conv_backward_f32.restype = ci
     lib.lmufft_conv_backward_f32.argtypes = [sp, vp, vp, vp, ci, vp, sz, vp]
+    lib.lmufft_hprep_bytes.restype = sz
+    lib.lmufft_hprep_bytes.argtypes = [sp]
+    lib.lmufft_hprep_bf16.restype = ci
+    lib.lmufft_hprep_bf16.argtypes = [sp, vp, vp, vp]
+    lib.lmufft_forward_bf16.restype = ci
+    lib.lmufft_forward_bf16.argtypes = [sp] + [vp] * 10 + [ci, vp, sz, vp]
+    lib.lmufft_backward_bf16.restype = ci
+    lib.lmufft_backward_bf16.argtypes = [sp] + [vp] * 15 + [ci, vp, sz, vp]
     lib.lmufft_profile_enable.restype = ci
     lib.lmufft_profile_enable.argtypes = [ci]
     lib.lmufft_profile_reset.restype = None
@@ -89,6 +97,10 @@ EXPORTS = (
     "lmufft_conv_workspace_bytes",
     "lmufft_conv_forward_f32",
     "lmufft_conv_backward_f32",
+    "lmufft_hprep_bytes",
+    "lmufft_hprep_bf16",
+    "lmufft_forward_bf16",
+    "lmufft_backward_bf16",
     "lmufft_profile_enable",
     "lmufft_profile_reset",
     "lmufft_profile_count",

@@ -1,0 +1,821 @@
+// bf16 kernels of the LMUFFT layer for gfx950 (MI355X) and their C ABI.
+//
+// Activations (x, m, h, gh, gx, gm) are bf16 in HBM; every sum is accumulated
+// in fp32 (v_mfma_f32_32x32x16_bf16 or fp32 VALU); parameters and their
+// gradients stay fp32 ("master weights"), u and gu stay fp32.  bf16 copies of
+// W_h (both orientations) are made per call, bf16 copies of H once per module
+// (lmufft_hprep_bf16).
+//
+// Reference arithmetic: src/lmu.py:297-320; the reference itself cannot run
+// this path in bf16 on a GPU (torch.fft rejects bf16), so parity is defined
+// against the fp32 reference on bf16-rounded inputs, rtol 2e-2.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm_core_bf16.h"
+#include "lmufft.h"
+#include "lmufft_internal.h"
+
+namespace lmufft {
+
+__device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
+static inline int cdivb(long a, long b) { return (int)((a + b - 1) / b); }
+static inline int up8(int v) { return (v + 7) & ~7; }
+static inline size_t align256b(size_t v) { return (v + 255) & ~size_t(255); }
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---------------------------------------------------------------------------
+// operand preparation
+// ---------------------------------------------------------------------------
+// Wb[n][k] (ld = ldW, zero padded) and WbT[j][n] (ld = ldWT, zero padded) from fp32 W[Hd][MD]
+__global__ __launch_bounds__(kThreads) void k_prep_weights(const float* __restrict__ W, bf16_t* __restrict__ Wb,
+                                                           bf16_t* __restrict__ WbT, int Hd, int MD, int ldW,
+                                                           int ldWT) {
+  const long n1 = Wb ? (long)Hd * ldW : 0;
+  const long n2 = WbT ? (long)MD * ldWT : 0;
+  for (long i = blockIdx.x * (long)kThreads + threadIdx.x; i < n1 + n2; i += (long)gridDim.x * kThreads) {
+    if (i < n1) {
+      const int n = (int)(i / ldW), k = (int)(i % ldW);
+      Wb[i] = (bf16_t)(k < MD ? W[(long)n * MD + k] : 0.f);
+    } else {
+      const long q = i - n1;
+      const int j = (int)(q / ldWT), n = (int)(q % ldWT);
+      WbT[q] = (bf16_t)(n < Hd ? W[(long)n * MD + j] : 0.f);
+    }
+  }
+}
+
+// Hb[k][tau] (ld = ldHb) and HbT[tau][k] (ld = ldHT, ldHb rows) from fp32 H[M][ldH]
+__global__ __launch_bounds__(kThreads) void k_prep_H(const float* __restrict__ H, bf16_t* __restrict__ Hb,
+                                                     bf16_t* __restrict__ HbT, int M, int ldH, int ldHb, int ldHT) {
+  const long n1 = (long)M * ldHb;
+  const long n2 = (long)ldHb * ldHT;
+  for (long i = blockIdx.x * (long)kThreads + threadIdx.x; i < n1 + n2; i += (long)gridDim.x * kThreads) {
+    if (i < n1) {
+      const int k = (int)(i / ldHb), t = (int)(i % ldHb);
+      Hb[i] = (bf16_t)(t < ldH ? H[(long)k * ldH + t] : 0.f);
+    } else {
+      const long q = i - n1;
+      const int t = (int)(q / ldHT), k = (int)(q % ldHT);
+      HbT[q] = (bf16_t)((t < ldH && k < M) ? H[(long)k * ldH + t] : 0.f);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// u = relu(x . w_u + b_u), x bf16, fp32 accumulate             src/lmu.py:300
+// ---------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void k_encode_fwd_bf16(const bf16_t* __restrict__ x,
+                                                              const float* __restrict__ w_u,
+                                                              const float* __restrict__ b_u,
+                                                              float* __restrict__ u, int rows, int D) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float bias = b_u[0];
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const bf16_t* xr = x + (long)row * D;
+    float s = 0.f;
+    if (VEC) {
+      for (int c = lane * 8; c < D; c += 512) {
+        const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xr + c);
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(w_u + c);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(w_u + c + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += (float)xv[j] * w0[j] + (float)xv[4 + j] * w1[j];
+      }
+    } else {
+      for (int c = lane; c < D; c += 64) s += (float)xr[c] * w_u[c];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) u[row] = fmaxf(s + bias, 0.f);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// m[b,t,k] = sum_{tau<=t} u[b,t-tau] H[k,tau]                src/lmu.py:303-312
+// Toeplitz GEMM.  The A operand A[t][tau] = u[t-tau] is never staged as a
+// tile: u (time-reversed, bf16) sits in LDS in 8 copies, copy c shifted by c
+// elements and the copies interleaved at 16-byte granularity, so that every
+// lane's eight consecutive tau are ONE aligned ds_read_b128 and the 16 lanes
+// that the LDS serves together hit 16 different 16-byte slots.
+// ---------------------------------------------------------------------------
+using ConvFwdTileB = TileB<64, 192, 64, 2, 2>;
+
+template <class TL>
+struct ToeplitzOperand {
+  const bf16_t* U8;
+  __device__ __forceinline__ void fetch(int) {}
+  __device__ __forceinline__ void store() {}
+  __device__ __forceinline__ bf16x8 frag(int row, int k0, int kl, int hh) const {
+    const int d = TL::BM - 1 - row;         // distance of this row from the tile's last frame
+    const int c = (8 - (d & 7)) & 7;        // copy whose shift makes the read aligned
+    const int Q = ((d + c) >> 3) + ((k0 + kl) >> 3) + hh;
+    return *reinterpret_cast<const bf16x8*>(&U8[(Q * 8 + c) * 8]);
+  }
+};
+
+__global__ __launch_bounds__(kThreads) void k_conv_fwd_bf16(const float* __restrict__ u,
+                                                            const bf16_t* __restrict__ Hb,
+                                                            bf16_t* __restrict__ m, int T, int M, int ldHb) {
+  using TL = ConvFwdTileB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+  const int n0 = blockIdx.x * TL::BN;
+  const int b = blockIdx.y;
+  const int tb = gridDim.z - 1 - blockIdx.z;
+  const int t0 = tb * TL::BM;
+  const int kend = min(T, t0 + TL::BM);
+  const int kend_pad = cdiv_dev(kend, TL::BK) * TL::BK;
+
+  auto lb = [=](int r, int k) -> bf16x8 {
+    const int n = n0 + r;
+    if (n >= M) return bzero8();
+    return bload8<true>(Hb, (long)n * ldHb + k, k, ldHb);
+  };
+  typedef LdsOperandKC<TL::BN, TL::BK, decltype(lb)> OpB;
+  OpB ob(smem, lb);
+  bf16_t* U8 = smem + OpB::ELEMS;
+
+  // time-reversed u around this tile: position p <-> frame s = (t0 + BM - 1) - p
+  const float* ub = u + (long)b * T;
+  const int smax = t0 + TL::BM - 1;
+  const int nchunks = (kend_pad / 8 + 8) * 8;
+  for (int ch = threadIdx.x; ch < nchunks; ch += kThreads) {
+    const int Q = ch >> 3, c = ch & 7;
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int p = 8 * Q + j - c;
+      const int s = smax - p;
+      v[j] = (bf16_t)((p >= 0 && s >= 0 && s < T) ? ub[s] : 0.f);
+    }
+    *reinterpret_cast<bf16x8*>(&U8[ch * 8]) = v;
+  }
+  // (the first barrier inside gemm_loop_kc orders the fill against the reads)
+
+  ToeplitzOperand<TL> oa{U8};
+  WavePos<TL> w;
+  f32x16 acc[TL::TM][TL::TN];
+  tileb_zero<TL>(acc);
+  gemm_loop_kc<TL>(oa, ob, acc, 0, kend, w);
+
+  bf16_t* mb = m + (long)b * T * M;
+  tileb_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
+    const int t = t0 + mm, n = n0 + nn;
+    if (t < T && n < M) mb[(long)t * M + n] = (bf16_t)v;
+  });
+}
+
+// ---------------------------------------------------------------------------
+// h = relu([m;x] W_h^T + b_h); h_n = h[:, T-1, :]           src/lmu.py:315-318
+// ---------------------------------------------------------------------------
+using ProjTileB = TileB<128, 128, 64, 2, 2>;
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void k_proj_fwd_bf16(const bf16_t* __restrict__ m,
+                                                            const bf16_t* __restrict__ x,
+                                                            const bf16_t* __restrict__ Wb,
+                                                            const float* __restrict__ bias,
+                                                            bf16_t* __restrict__ h, bf16_t* __restrict__ h_n,
+                                                            int rows, int T, int M, int D, int Hd, int ldW) {
+  using TL = ProjTileB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+  const int n0 = blockIdx.x * TL::BN;
+  const int m0 = blockIdx.y * TL::BM;
+  const int K = M + D;
+
+  auto la = [=](int r, int k) -> bf16x8 {
+    const long row = m0 + r;
+    if (row >= rows) return bzero8();
+    if (VEC) {
+      if (k < M) return *reinterpret_cast<const bf16x8*>(m + row * M + k);
+      if (k < K) return *reinterpret_cast<const bf16x8*>(x + row * D + (k - M));
+      return bzero8();
+    } else {
+      bf16x8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int kk = k + j;
+        v[j] = kk < M ? m[row * M + kk] : (kk < K ? x[row * D + (kk - M)] : (bf16_t)0.f);
+      }
+      return v;
+    }
+  };
+  auto lb = [=](int r, int k) -> bf16x8 {
+    const int n = n0 + r;
+    if (n >= Hd) return bzero8();
+    return bload8<true>(Wb, (long)n * ldW + k, k, ldW);
+  };
+  typedef LdsOperandKC<TL::BM, TL::BK, decltype(la)> OpA;
+  typedef LdsOperandKC<TL::BN, TL::BK, decltype(lb)> OpB;
+  OpA oa(smem, la);
+  OpB ob(smem + OpA::ELEMS, lb);
+
+  WavePos<TL> w;
+  f32x16 acc[TL::TM][TL::TN];
+  tileb_zero<TL>(acc);
+  gemm_loop_kc<TL>(oa, ob, acc, 0, K, w);
+
+  tileb_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
+    const long row = m0 + mm;
+    const int n = n0 + nn;
+    if (row < rows && n < Hd) {
+      const bf16_t y = (bf16_t)fmaxf(v + bias[n], 0.f);
+      h[row * Hd + n] = y;
+      if ((int)(row % T) == T - 1) h_n[(row / T) * Hd + n] = y;
+    }
+  });
+}
+
+// gz[row][n..n+7] = (h > 0) ? gh (+ gh_n on the last frame) : 0
+template <bool VEC>
+__device__ __forceinline__ bf16x8 load_gz8(const bf16_t* __restrict__ h, const bf16_t* __restrict__ gh,
+                                           const bf16_t* __restrict__ gh_n, long row, int n, int T, int Hd) {
+  const bf16x8 hv = bload8<VEC>(h, row * Hd + n, n, Hd);
+  bf16x8 g = gh ? bload8<VEC>(gh, row * Hd + n, n, Hd) : bzero8();
+  if (gh_n && (int)(row % T) == T - 1) {
+    const bf16x8 gl = bload8<VEC>(gh_n, (row / T) * Hd + n, n, Hd);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = (bf16_t)((float)g[j] + (float)gl[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) g[j] = (float)hv[j] > 0.f ? g[j] : (bf16_t)0.f;
+  return g;
+}
+
+// ---------------------------------------------------------------------------
+// out[row][j] = sum_n gz[row][n] W_h[n][j_begin + j]  (+ ga[row] w_u[j])
+// called for the memory columns (-> gm) and for the input columns (-> gx)
+// ---------------------------------------------------------------------------
+template <class TL, bool VEC>
+__global__ __launch_bounds__(kThreads) void k_dgrad_bf16(const bf16_t* __restrict__ h,
+                                                         const bf16_t* __restrict__ gh,
+                                                         const bf16_t* __restrict__ gh_n,
+                                                         const bf16_t* __restrict__ WbT, bf16_t* __restrict__ out,
+                                                         const float* __restrict__ ga,
+                                                         const float* __restrict__ w_u, int rows, int T, int Hd,
+                                                         int ldWT, int j_begin, int ncols) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+  const int n0 = blockIdx.x * TL::BN;
+  const int m0 = blockIdx.y * TL::BM;
+
+  auto la = [=](int r, int k) -> bf16x8 {
+    const long row = m0 + r;
+    if (row >= rows) return bzero8();
+    return load_gz8<VEC>(h, gh, gh_n, row, k, T, Hd);
+  };
+  auto lb = [=](int r, int k) -> bf16x8 {
+    const int j = n0 + r;
+    if (j >= ncols) return bzero8();
+    return bload8<true>(WbT, (long)(j_begin + j) * ldWT + k, k, ldWT);
+  };
+  typedef LdsOperandKC<TL::BM, TL::BK, decltype(la)> OpA;
+  typedef LdsOperandKC<TL::BN, TL::BK, decltype(lb)> OpB;
+  OpA oa(smem, la);
+  OpB ob(smem + OpA::ELEMS, lb);
+
+  WavePos<TL> w;
+  f32x16 acc[TL::TM][TL::TN];
+  tileb_zero<TL>(acc);
+  gemm_loop_kc<TL>(oa, ob, acc, 0, Hd, w);
+
+  tileb_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
+    const long row = m0 + mm;
+    const int j = n0 + nn;
+    if (row < rows && j < ncols) {
+      if (ga) v += ga[row] * w_u[j];
+      out[row * ncols + j] = (bf16_t)v;
+    }
+  });
+}
+
+using DgradMTileB = TileB<128, 192, 64, 2, 2>;
+using DgradXTileB = TileB<128, 128, 64, 2, 2>;
+
+// ---------------------------------------------------------------------------
+// gu partial slabs: P[i][tau] = sum_k gm[t0+i][k] H[k][tau], summed along the
+// diagonals s = t0 + i - tau (fp32 LDS atomics), one slab per (batch, t tile)
+// ---------------------------------------------------------------------------
+using ConvBwdTileB = TileB<64, 128, 64, 2, 2>;
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void k_conv_bwd_bf16(const bf16_t* __restrict__ gm,
+                                                            const bf16_t* __restrict__ HbT,
+                                                            float* __restrict__ gu_part, int T, int M, int ldHT,
+                                                            int rowsHT) {
+  using TL = ConvBwdTileB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+  const int b = blockIdx.y;
+  const int ntt = gridDim.z;
+  const int tb = ntt - 1 - blockIdx.z;
+  const int t0 = tb * TL::BM;
+  const int send = min(T, t0 + TL::BM);
+  const bf16_t* gmb = gm + (long)b * T * M;
+
+  auto la = [=](int r, int k) -> bf16x8 {
+    const int t = t0 + r;
+    if (t >= T) return bzero8();
+    return bload8<VEC>(gmb, (long)t * M + k, k, M);
+  };
+  typedef LdsOperandKC<TL::BM, TL::BK, decltype(la)> OpA;
+  constexpr int kBElems = TL::BN * (TL::BK + 8);
+  float* gu_acc = reinterpret_cast<float*>(smem + OpA::ELEMS + kBElems);
+  for (int s = threadIdx.x; s < send; s += kThreads) gu_acc[s] = 0.f;
+
+  WavePos<TL> w;
+  for (int tau0 = 0; tau0 < send; tau0 += TL::BN) {
+    auto lb = [=](int r, int k) -> bf16x8 {
+      const int tau = tau0 + r;
+      if (tau >= rowsHT) return bzero8();
+      return bload8<true>(HbT, (long)tau * ldHT + k, k, ldHT);
+    };
+    typedef LdsOperandKC<TL::BN, TL::BK, decltype(lb)> OpB;
+    static_assert(OpB::ELEMS == kBElems, "LDS carve");
+    OpA oa(smem, la);
+    OpB ob(smem + OpA::ELEMS, lb);
+    f32x16 acc[TL::TM][TL::TN];
+    tileb_zero<TL>(acc);
+    gemm_loop_kc<TL>(oa, ob, acc, 0, M, w);
+    tileb_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
+      const int s = t0 + mm - (tau0 + nn);
+      if (s >= 0 && t0 + mm < T) atomicAdd(&gu_acc[s], v);
+    });
+  }
+  __syncthreads();
+  float* out = gu_part + ((long)b * ntt + tb) * T;
+  for (int s = threadIdx.x; s < send; s += kThreads) out[s] = gu_acc[s];
+}
+
+// ---------------------------------------------------------------------------
+// gW_h[n][j] = sum_rows gz[row][n] [m;x][row][j];  gb_h[n] = sum_rows gz[row][n]
+// k = frame index: both operands are k-strided in HBM -> transposed LDS reads.
+// Row range split over gridDim.z; fp32 slabs [Hd*(M+D) + Hd] summed afterwards.
+// ---------------------------------------------------------------------------
+using WgradTileB = TileB<128, 192, 32, 2, 2>;
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restrict__ h,
+                                                         const bf16_t* __restrict__ gh,
+                                                         const bf16_t* __restrict__ gh_n,
+                                                         const bf16_t* __restrict__ m,
+                                                         const bf16_t* __restrict__ x, float* __restrict__ slabs,
+                                                         int rows, int rows_per_split, int T, int M, int D,
+                                                         int Hd) {
+  using TL = WgradTileB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+  const int j0 = blockIdx.x * TL::BN;
+  const int n0 = blockIdx.y * TL::BM;
+  const int MD = M + D;
+  const int kbeg = blockIdx.z * rows_per_split;
+  const int kend = min(rows, kbeg + rows_per_split);
+  float* slab = slabs + blockIdx.z * ((long)Hd * MD + Hd);
+
+  auto la = [=](int r, int k) -> bf16x8 {
+    if (k >= kend) return bzero8();
+    return load_gz8<VEC>(h, gh, gh_n, (long)k, n0 + r, T, Hd);
+  };
+  auto lb = [=](int r, int k) -> bf16x8 {
+    if (k >= kend) return bzero8();
+    const long row = k;
+    const int j = j0 + r;
+    if (VEC) {
+      if (j < M) return *reinterpret_cast<const bf16x8*>(m + row * M + j);
+      if (j < MD) return *reinterpret_cast<const bf16x8*>(x + row * D + (j - M));
+      return bzero8();
+    } else {
+      bf16x8 v;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int jj = j + q;
+        v[q] = jj < M ? m[row * M + jj] : (jj < MD ? x[row * D + (jj - M)] : (bf16_t)0.f);
+      }
+      return v;
+    }
+  };
+  typedef LdsOperandTR<TL::BM, TL::BK, 32, decltype(la)> OpA;
+  typedef LdsOperandTR<TL::BN, TL::BK, 32, decltype(lb)> OpB;
+  OpA oa(smem, la);
+  OpB ob(smem + OpA::ELEMS, lb);
+
+  // bias gradient: every staged A vector holds 8 hidden units of one frame and
+  // a thread always stages the same 8 units (256 % (BM/8) == 0)
+  const bool do_bias = blockIdx.x == 0;
+  float colsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto add_colsum = [&]() {
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < OpA::NV; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) colsum[j] += (float)oa.regs[i][j];
+    }
+  };
+
+  WavePos<TL> w;
+  f32x16 acc[TL::TM][TL::TN];
+  tileb_zero<TL>(acc);
+  if (kbeg < kend) {
+    oa.fetch(kbeg);
+    ob.fetch(kbeg);
+    add_colsum();
+  }
+  for (int k0 = kbeg; k0 < kend; k0 += TL::BK) {
+    oa.store();
+    ob.store();
+    __syncthreads();
+    if (k0 + TL::BK < kend) {
+      oa.fetch(k0 + TL::BK);
+      ob.fetch(k0 + TL::BK);
+      add_colsum();
+    }
+#pragma unroll
+    for (int kl = 0; kl < TL::BK; kl += 16) {
+      bf16x8 af[TL::TM], bfr[TL::TN];
+#pragma unroll
+      for (int tm = 0; tm < TL::TM; ++tm) af[tm] = oa.frag32(w.wm0 + tm * 32, kl);
+#pragma unroll
+      for (int tn = 0; tn < TL::TN; ++tn) bfr[tn] = ob.frag32(w.wn0 + tn * 32, kl);
+#pragma unroll
+      for (int tm = 0; tm < TL::TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TL::TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bfr[tn], acc[tm][tn], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  tileb_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
+    const int n = n0 + mm, j = j0 + nn;
+    if (n < Hd && j < MD) slab[(long)n * MD + j] = v;
+  });
+
+  if (do_bias) {  // (uniform per workgroup)
+    float* red = reinterpret_cast<float*>(smem);  // [256][8] fp32 = 8 KB, tiles are free after the last barrier
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = colsum[j];
+    __syncthreads();
+    if (threadIdx.x < TL::BM) {
+      const int n8 = threadIdx.x >> 3, j = threadIdx.x & 7;
+      float s = 0.f;
+      for (int q = 0; q < kThreads / (TL::BM / 8); ++q) s += red[(q * (TL::BM / 8) + n8) * 8 + j];
+      if (n0 + (int)threadIdx.x < Hd) slab[(long)Hd * MD + n0 + threadIdx.x] = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// partial gw_u = sum_rows ga[row] x[row,:], partial gb_u = sum_rows ga[row]
+// ---------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void k_encode_bwd_bf16(const float* __restrict__ ga,
+                                                              const bf16_t* __restrict__ x,
+                                                              float* __restrict__ part, int rows, int D,
+                                                              int rows_per_block) {
+  __shared__ float red[4][512];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(rows, r0 + rows_per_block);
+  float* slab = part + (long)blockIdx.x * (D + 1);
+
+  for (int c0 = 0; c0 < D; c0 += 512) {
+    const int c = c0 + lane * 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float gsum = 0.f;
+    for (int row = r0 + wave; row < r1; row += 4) {
+      const float g = ga[row];
+      gsum += g;
+      if (g != 0.f && c < D) {
+        const bf16x8 xv = bload8<VEC>(x, (long)row * D + c, c, D);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += g * (float)xv[j];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[wave][lane * 8 + j] = acc[j];
+    __syncthreads();
+    for (int q = threadIdx.x; q < 512; q += kThreads) {
+      const int cc = c0 + q;
+      if (cc < D) slab[cc] = red[0][q] + red[1][q] + red[2][q] + red[3][q];
+    }
+    if (c0 == 0) {
+      __syncthreads();
+      if (lane == 0) red[wave][0] = gsum;
+      __syncthreads();
+      if (threadIdx.x == 0) slab[D] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+constexpr int kEncRowsPerBlockB = 32;
+
+struct HprepLayout {
+  int ldHb, ldHT;
+  size_t off_Hb, off_HbT, total;
+};
+static HprepLayout hprep_layout(int M, int ldH) {
+  HprepLayout l;
+  l.ldHb = up8(ldH);
+  l.ldHT = up8(M);
+  l.off_Hb = 0;
+  l.off_HbT = align256b(sizeof(bf16_t) * (size_t)M * l.ldHb);
+  l.total = l.off_HbT + align256b(sizeof(bf16_t) * (size_t)l.ldHb * l.ldHT);
+  return l;
+}
+
+struct BwdPlanB {
+  int S, rps, ntt, enc_blocks, ldWT;
+  size_t off_WbT, off_wslab, off_gupart, off_ga, off_encpart, total;
+};
+static BwdPlanB plan_backward_b(const lmufft_shape& s) {
+  BwdPlanB p;
+  const long rows = (long)s.B * s.T;
+  const int MD = s.M + s.D;
+  const int tiles = cdivb(s.Hd, WgradTileB::BM) * cdivb(MD, WgradTileB::BN);
+  int S = (2 * 256 + tiles - 1) / tiles;  // about two workgroups per CU
+  int rps = cdivb(rows, S);
+  rps = cdivb(rps, WgradTileB::BK) * WgradTileB::BK;
+  p.S = cdivb(rows, rps);
+  p.rps = rps;
+  p.ntt = cdivb(s.T, ConvBwdTileB::BM);
+  p.enc_blocks = cdivb(rows, kEncRowsPerBlockB);
+  p.ldWT = up8(s.Hd);
+  size_t off = 0;
+  p.off_WbT = off;
+  off += align256b(sizeof(bf16_t) * (size_t)MD * p.ldWT);
+  p.off_wslab = off;
+  off += align256b(sizeof(float) * (size_t)p.S * ((size_t)s.Hd * MD + s.Hd));
+  p.off_gupart = off;
+  off += align256b(sizeof(float) * (size_t)s.B * p.ntt * s.T);
+  p.off_ga = off;
+  off += align256b(sizeof(float) * (size_t)rows);
+  p.off_encpart = off;
+  off += align256b(sizeof(float) * (size_t)p.enc_blocks * (s.D + 1));
+  p.total = off;
+  return p;
+}
+
+size_t forward_workspace_bf16(const lmufft_shape& s) {
+  return align256b(sizeof(bf16_t) * (size_t)s.Hd * up8(s.M + s.D));
+}
+size_t backward_workspace_bf16(const lmufft_shape& s) { return plan_backward_b(s).total; }
+
+#define PROFB(name) ProfScope prof_scope_(name, st)
+#define LAUNCH_CHECKB(name)                                                                       \
+  do {                                                                                            \
+    hipError_t e_ = hipGetLastError();                                                            \
+    if (e_ != hipSuccess) return set_error("launch of %s failed: %s", name, hipGetErrorString(e_)); \
+  } while (0)
+
+static int check_shape_b(const lmufft_shape* s) {
+  if (!s) return set_error("shape is NULL");
+  if (s->B <= 0 || s->T <= 0 || s->D <= 0 || s->M <= 0 || s->Hd <= 0)
+    return set_error("shape: B, T, D, M, Hd must be positive (got B=%d T=%d D=%d M=%d Hd=%d)", s->B, s->T,
+                     s->D, s->M, s->Hd);
+  if (s->T > s->ldH)
+    return set_error("sequence length %d exceeds the impulse response length (seq_len) %d", s->T, s->ldH);
+  if ((long)s->B * s->T >= (1L << 31) / 4) return set_error("B*T too large");
+  return 0;
+}
+
+}  // namespace lmufft
+
+using namespace lmufft;
+
+extern "C" {
+
+size_t lmufft_hprep_bytes(const lmufft_shape* s) {
+  if (!s || s->M <= 0 || s->ldH <= 0) return 0;
+  return hprep_layout(s->M, s->ldH).total;
+}
+
+int lmufft_hprep_bf16(const lmufft_shape* s, const float* H, void* hprep, void* stream) {
+  if (!s || s->M <= 0 || s->ldH <= 0) return set_error("hprep: bad shape");
+  if (!H || !hprep) return set_error("hprep: NULL pointer");
+  if (!al16(hprep)) return set_error("hprep: buffer must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const HprepLayout l = hprep_layout(s->M, s->ldH);
+  bf16_t* Hb = (bf16_t*)((char*)hprep + l.off_Hb);
+  bf16_t* HbT = (bf16_t*)((char*)hprep + l.off_HbT);
+  const long n = (long)s->M * l.ldHb + (long)l.ldHb * l.ldHT;
+  {
+    PROFB("k_prep_H");
+    hipLaunchKernelGGL(k_prep_H, dim3(min(cdivb(n, kThreads), 2048)), dim3(kThreads), 0, st, H, Hb, HbT, s->M,
+                       s->ldH, l.ldHb, l.ldHT);
+  }
+  LAUNCH_CHECKB("k_prep_H");
+  return 0;
+}
+
+int lmufft_forward_bf16(const lmufft_shape* s, const void* x_, const float* w_u, const float* b_u,
+                        const float* W_h, const float* b_h, const void* hprep, float* u, void* m_, void* h_,
+                        void* h_n_, int conv_algo, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_shape_b(s)) return rc;
+  if (!x_ || !w_u || !b_u || !W_h || !b_h || !hprep || !u || !m_ || !h_ || !h_n_)
+    return set_error("forward: NULL pointer");
+  if (conv_algo != LMUFFT_CONV_AUTO && conv_algo != LMUFFT_CONV_TOEPLITZ)
+    return set_error("conv algorithm %d is not available for bf16", conv_algo);
+  const size_t need = forward_workspace_bf16(*s);
+  if (!workspace || workspace_bytes < need)
+    return set_error("forward: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+  if (!al16(workspace) || !al16(hprep)) return set_error("forward: workspace/hprep must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const bf16_t* x = (const bf16_t*)x_;
+  bf16_t* m = (bf16_t*)m_;
+  bf16_t* h = (bf16_t*)h_;
+  bf16_t* h_n = (bf16_t*)h_n_;
+  const long rows = (long)s->B * s->T;
+  const int MD = s->M + s->D;
+  const int ldW = up8(MD);
+  bf16_t* Wb = (bf16_t*)workspace;
+  const HprepLayout hl = hprep_layout(s->M, s->ldH);
+  const bf16_t* Hb = (const bf16_t*)((const char*)hprep + hl.off_Hb);
+
+  {
+    PROFB("k_prep_weights");
+    hipLaunchKernelGGL(k_prep_weights, dim3(min(cdivb((long)s->Hd * ldW, kThreads), 2048)), dim3(kThreads), 0, st,
+                       W_h, Wb, (bf16_t*)nullptr, s->Hd, MD, ldW, 0);
+  }
+  LAUNCH_CHECKB("k_prep_weights");
+  {
+    const bool vec = (s->D % 8 == 0) && al16(x) && al16(w_u);
+    const dim3 grid(min(cdivb(rows, 4), 4096));
+    PROFB("k_encode_fwd_bf16");
+    if (vec)
+      hipLaunchKernelGGL(k_encode_fwd_bf16<true>, grid, dim3(kThreads), 0, st, x, w_u, b_u, u, (int)rows, s->D);
+    else
+      hipLaunchKernelGGL(k_encode_fwd_bf16<false>, grid, dim3(kThreads), 0, st, x, w_u, b_u, u, (int)rows, s->D);
+  }
+  LAUNCH_CHECKB("k_encode_fwd_bf16");
+  {
+    using TL = ConvFwdTileB;
+    const dim3 grid(cdivb(s->M, TL::BN), s->B, cdivb(s->T, TL::BM));
+    const int kpad = cdivb(s->T, TL::BK) * TL::BK;
+    const size_t lds = sizeof(bf16_t) * ((size_t)TL::BN * (TL::BK + 8) + (size_t)(kpad / 8 + 8) * 64);
+    if (lds > 160 * 1024) return set_error("sequence too long for the Toeplitz forward kernel (T=%d)", s->T);
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)k_conv_fwd_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+      return set_error("cannot reserve %zu bytes of LDS for k_conv_fwd_bf16", lds);
+    {
+      PROFB("k_conv_fwd_bf16");
+      hipLaunchKernelGGL(k_conv_fwd_bf16, grid, dim3(kThreads), lds, st, u, Hb, m, s->T, s->M, hl.ldHb);
+    }
+    LAUNCH_CHECKB("k_conv_fwd_bf16");
+  }
+  {
+    using TL = ProjTileB;
+    const bool vec = (s->M % 8 == 0) && (s->D % 8 == 0) && al16(m) && al16(x);
+    const dim3 grid(cdivb(s->Hd, TL::BN), cdivb(rows, TL::BM));
+    const size_t lds = sizeof(bf16_t) * (size_t)(TL::BM + TL::BN) * (TL::BK + 8);
+    {
+      PROFB("k_proj_fwd_bf16");
+      if (vec)
+        hipLaunchKernelGGL(k_proj_fwd_bf16<true>, grid, dim3(kThreads), lds, st, m, x, Wb, b_h, h, h_n, (int)rows,
+                           s->T, s->M, s->D, s->Hd, ldW);
+      else
+        hipLaunchKernelGGL(k_proj_fwd_bf16<false>, grid, dim3(kThreads), lds, st, m, x, Wb, b_h, h, h_n, (int)rows,
+                           s->T, s->M, s->D, s->Hd, ldW);
+    }
+    LAUNCH_CHECKB("k_proj_fwd_bf16");
+  }
+  return 0;
+}
+
+int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u, const float* W_h,
+                         const void* hprep, const float* u, const void* m_, const void* h_, const void* gh_,
+                         const void* gh_n_, void* gx_, float* gw_u, float* gb_u, float* gW_h, float* gb_h,
+                         void* gm_, int conv_algo, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_shape_b(s)) return rc;
+  if (!x_ || !w_u || !W_h || !hprep || !u || !m_ || !h_ || !gw_u || !gb_u || !gW_h || !gb_h || !gm_)
+    return set_error("backward: NULL pointer");
+  if (conv_algo != LMUFFT_CONV_AUTO && conv_algo != LMUFFT_CONV_TOEPLITZ)
+    return set_error("conv algorithm %d is not available for bf16", conv_algo);
+  const BwdPlanB p = plan_backward_b(*s);
+  if (!workspace || workspace_bytes < p.total)
+    return set_error("backward: workspace of %zu bytes needed, %zu given", p.total, workspace_bytes);
+  if (!al16(workspace) || !al16(hprep)) return set_error("backward: workspace/hprep must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const bf16_t* x = (const bf16_t*)x_;
+  const bf16_t* m = (const bf16_t*)m_;
+  const bf16_t* h = (const bf16_t*)h_;
+  const bf16_t* gh = (const bf16_t*)gh_;
+  const bf16_t* gh_n = (const bf16_t*)gh_n_;
+  bf16_t* gx = (bf16_t*)gx_;
+  bf16_t* gm = (bf16_t*)gm_;
+  char* ws = (char*)workspace;
+  bf16_t* WbT = (bf16_t*)(ws + p.off_WbT);
+  float* wslab = (float*)(ws + p.off_wslab);
+  float* gupart = (float*)(ws + p.off_gupart);
+  float* ga = (float*)(ws + p.off_ga);
+  float* encpart = (float*)(ws + p.off_encpart);
+  const long rows = (long)s->B * s->T;
+  const int MD = s->M + s->D;
+  const HprepLayout hl = hprep_layout(s->M, s->ldH);
+  const bf16_t* HbT = (const bf16_t*)((const char*)hprep + hl.off_HbT);
+  const bool vec_h = (s->Hd % 8 == 0) && al16(h) && (!gh || al16(gh)) && (!gh_n || al16(gh_n));
+
+  {
+    PROFB("k_prep_weights");
+    hipLaunchKernelGGL(k_prep_weights, dim3(min(cdivb((long)MD * p.ldWT, kThreads), 2048)), dim3(kThreads), 0, st,
+                       W_h, (bf16_t*)nullptr, WbT, s->Hd, MD, 0, p.ldWT);
+  }
+  LAUNCH_CHECKB("k_prep_weights");
+
+  {  // gm = gz W_h[:, :M]
+    using TL = DgradMTileB;
+    const dim3 grid(cdivb(s->M, TL::BN), cdivb(rows, TL::BM));
+    const size_t lds = sizeof(bf16_t) * (size_t)(TL::BM + TL::BN) * (TL::BK + 8);
+    {
+      PROFB("k_dgrad_bf16");
+      if (vec_h)
+        hipLaunchKernelGGL((k_dgrad_bf16<TL, true>), grid, dim3(kThreads), lds, st, h, gh, gh_n, WbT, gm,
+                           (const float*)nullptr, (const float*)nullptr, (int)rows, s->T, s->Hd, p.ldWT, 0, s->M);
+      else
+        hipLaunchKernelGGL((k_dgrad_bf16<TL, false>), grid, dim3(kThreads), lds, st, h, gh, gh_n, WbT, gm,
+                           (const float*)nullptr, (const float*)nullptr, (int)rows, s->T, s->Hd, p.ldWT, 0, s->M);
+    }
+    LAUNCH_CHECKB("k_dgrad_bf16");
+  }
+  {  // ga = (adjoint conv of gm) * (u > 0)
+    using TL = ConvBwdTileB;
+    const dim3 grid(1, s->B, p.ntt);
+    const size_t lds = sizeof(bf16_t) * (size_t)(TL::BM + TL::BN) * (TL::BK + 8) + sizeof(float) * (size_t)p.ntt * TL::BM;
+    if (lds > 160 * 1024) return set_error("sequence too long for the Toeplitz backward kernel (T=%d)", s->T);
+    const bool vec = (s->M % 8 == 0) && al16(gm);
+    const void* fn = vec ? (const void*)k_conv_bwd_bf16<true> : (const void*)k_conv_bwd_bf16<false>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return set_error("cannot reserve %zu bytes of LDS for k_conv_bwd_bf16", lds);
+    {
+      PROFB("k_conv_bwd_bf16");
+      if (vec)
+        hipLaunchKernelGGL(k_conv_bwd_bf16<true>, grid, dim3(kThreads), lds, st, gm, HbT, gupart, s->T, s->M,
+                           hl.ldHT, hl.ldHb);
+      else
+        hipLaunchKernelGGL(k_conv_bwd_bf16<false>, grid, dim3(kThreads), lds, st, gm, HbT, gupart, s->T, s->M,
+                           hl.ldHT, hl.ldHb);
+    }
+    LAUNCH_CHECKB("k_conv_bwd_bf16");
+    if (int rc = launch_gu_reduce(gupart, u, ga, s->B, s->T, p.ntt, TL::BM, st)) return rc;
+  }
+  if (gx) {  // gx = gz W_h[:, M:] + ga w_u
+    using TL = DgradXTileB;
+    const dim3 grid(cdivb(s->D, TL::BN), cdivb(rows, TL::BM));
+    const size_t lds = sizeof(bf16_t) * (size_t)(TL::BM + TL::BN) * (TL::BK + 8);
+    {
+      PROFB("k_dgrad_bf16");
+      if (vec_h)
+        hipLaunchKernelGGL((k_dgrad_bf16<TL, true>), grid, dim3(kThreads), lds, st, h, gh, gh_n, WbT, gx,
+                           (const float*)ga, w_u, (int)rows, s->T, s->Hd, p.ldWT, s->M, s->D);
+      else
+        hipLaunchKernelGGL((k_dgrad_bf16<TL, false>), grid, dim3(kThreads), lds, st, h, gh, gh_n, WbT, gx,
+                           (const float*)ga, w_u, (int)rows, s->T, s->Hd, p.ldWT, s->M, s->D);
+    }
+    LAUNCH_CHECKB("k_dgrad_bf16");
+  }
+  {  // gW_h, gb_h
+    using TL = WgradTileB;
+    const bool vec = vec_h && (s->M % 8 == 0) && (s->D % 8 == 0) && al16(m) && al16(x);
+    const dim3 grid(cdivb(MD, TL::BN), cdivb(s->Hd, TL::BM), p.S);
+    const size_t lds = sizeof(bf16_t) * (size_t)TL::BK * ((TL::BM + 32) + (TL::BN + 32));
+    {
+      PROFB("k_wgrad_bf16");
+      if (vec)
+        hipLaunchKernelGGL(k_wgrad_bf16<true>, grid, dim3(kThreads), lds, st, h, gh, gh_n, m, x, wslab, (int)rows,
+                           p.rps, s->T, s->M, s->D, s->Hd);
+      else
+        hipLaunchKernelGGL(k_wgrad_bf16<false>, grid, dim3(kThreads), lds, st, h, gh, gh_n, m, x, wslab, (int)rows,
+                           p.rps, s->T, s->M, s->D, s->Hd);
+    }
+    LAUNCH_CHECKB("k_wgrad_bf16");
+    const long n0 = (long)s->Hd * MD;
+    if (int rc = launch_reduce_slabs(wslab, p.S, n0 + s->Hd, gW_h, n0, gb_h, (long)s->Hd, st)) return rc;
+  }
+  {  // gw_u, gb_u
+    const bool vec = (s->D % 8 == 0) && al16(x);
+    const dim3 grid(p.enc_blocks);
+    {
+      PROFB("k_encode_bwd_bf16");
+      if (vec)
+        hipLaunchKernelGGL(k_encode_bwd_bf16<true>, grid, dim3(kThreads), 0, st, ga, x, encpart, (int)rows, s->D,
+                           kEncRowsPerBlockB);
+      else
+        hipLaunchKernelGGL(k_encode_bwd_bf16<false>, grid, dim3(kThreads), 0, st, ga, x, encpart, (int)rows, s->D,
+                           kEncRowsPerBlockB);
+    }
+    LAUNCH_CHECKB("k_encode_bwd_bf16");
+    if (int rc = launch_reduce_slabs(encpart, p.enc_blocks, (long)(s->D + 1), gw_u, (long)s->D, gb_u, 1L, st))
+      return rc;
+  }
+  return 0;
+}
+
+}  // extern "C"

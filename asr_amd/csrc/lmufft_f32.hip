@@ -517,7 +517,7 @@ static int check_shape(const lmufft_shape* s) {
     if (e_ != hipSuccess) return set_error("launch of %s failed: %s", name, hipGetErrorString(e_)); \
   } while (0)
 
-static int reduce_slabs(const float* in, int S, long stride, float* out0, long n0, float* out1, long n1,
+int launch_reduce_slabs(const float* in, int S, long stride, float* out0, long n0, float* out1, long n1,
                         hipStream_t st) {
   // vector path: every slab row and both outputs stay 16-byte aligned and n0 + n1 is a multiple of 4
   const bool vec = (stride % 4 == 0) && (n0 % 4 == 0) && (n1 % 4 == 0) && aligned16(in) && aligned16(out0) &&
@@ -532,6 +532,18 @@ static int reduce_slabs(const float* in, int S, long stride, float* out0, long n
       hipLaunchKernelGGL(k_reduce_slabs<false>, grid, dim3(kThreads), 0, st, in, S, stride, out0, n0, out1, n1);
   }
   LAUNCH_CHECK("k_reduce_slabs");
+  return 0;
+}
+
+int launch_gu_reduce(const float* gu_part, const float* u, float* out, int B, int T, int ntt, int tile_t,
+                     hipStream_t st) {
+  const long n = (long)B * T;
+  {
+    PROF("k_gu_reduce");
+    hipLaunchKernelGGL(k_gu_reduce, dim3(min(cdiv(n, kThreads), 2048)), dim3(kThreads), 0, st, gu_part, u, out, B,
+                       T, ntt, tile_t);
+  }
+  LAUNCH_CHECK("k_gu_reduce");
   return 0;
 }
 
@@ -574,14 +586,7 @@ static int conv_backward_toeplitz(const lmufft_shape& s, const float* gm, const 
       hipLaunchKernelGGL(k_conv_bwd<false>, grid, dim3(kThreads), lds, st, gm, H, gu_part, s.T, s.M, s.ldH);
   }
   LAUNCH_CHECK("k_conv_bwd");
-  const long n = (long)s.B * s.T;
-  {
-  PROF("k_gu_reduce");
-  hipLaunchKernelGGL(k_gu_reduce, dim3(min(cdiv(n, kThreads), 2048)), dim3(kThreads), 0, st, gu_part, u, out,
-                     s.B, s.T, ntt, TL::BM);
-  }
-  LAUNCH_CHECK("k_gu_reduce");
-  return 0;
+  return launch_gu_reduce(gu_part, u, out, s.B, s.T, ntt, TL::BM, st);
 }
 
 }  // namespace lmufft
@@ -595,14 +600,13 @@ int lmufft_abi_version(void) { return LMUFFT_ABI_VERSION; }
 const char* lmufft_last_error(void) { return last_error_buffer(); }
 
 size_t lmufft_forward_workspace_bytes(const lmufft_shape* s, int dtype) {
-  (void)s;
-  (void)dtype;
+  if (dtype == LMUFFT_BF16) return check_shape(s) ? 0 : forward_workspace_bf16(*s);
   return 256;  // the fp32 forward needs no scratch; never return 0 so callers can always allocate
 }
 
 size_t lmufft_backward_workspace_bytes(const lmufft_shape* s, int dtype) {
-  (void)dtype;
   if (check_shape(s)) return 0;
+  if (dtype == LMUFFT_BF16) return backward_workspace_bf16(*s);
   return plan_backward(*s).total;
 }
 
@@ -749,7 +753,7 @@ int lmufft_backward_f32(const lmufft_shape* s, const float* x, const float* w_u,
     }
     LAUNCH_CHECK("k_wgrad");
     const long n0 = (long)s->Hd * MD;
-    if (int rc = reduce_slabs(wslab, p.S, n0 + s->Hd, gW_h, n0, gb_h, (long)s->Hd, st)) return rc;
+    if (int rc = launch_reduce_slabs(wslab, p.S, n0 + s->Hd, gW_h, n0, gb_h, (long)s->Hd, st)) return rc;
   }
   {  // gw_u, gb_u
     const bool vec = (s->D % 4 == 0) && aligned16(x);
@@ -764,7 +768,7 @@ int lmufft_backward_f32(const lmufft_shape* s, const float* x, const float* w_u,
                            kEncRowsPerBlock);
     }
     LAUNCH_CHECK("k_encode_bwd");
-    if (int rc = reduce_slabs(encpart, p.enc_blocks, (long)(s->D + 1), gw_u, (long)s->D, gb_u, 1L, st)) return rc;
+    if (int rc = launch_reduce_slabs(encpart, p.enc_blocks, (long)(s->D + 1), gw_u, (long)s->D, gb_u, 1L, st)) return rc;
   }
   return 0;
 }

@@ -4,6 +4,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include "lmufft.h"
+
 namespace lmufft {
 
 inline char* last_error_buffer() {
@@ -19,6 +21,15 @@ inline int set_error(const char* fmt, ...) {
   va_end(ap);
   return 1;
 }
+
+// shared launchers (defined in lmufft_f32.hip)
+int launch_reduce_slabs(const float* in, int S, long stride, float* out0, long n0, float* out1, long n1,
+                        hipStream_t st);
+int launch_gu_reduce(const float* gu_part, const float* u, float* out, int B, int T, int ntt, int tile_t,
+                     hipStream_t st);
+// workspace sizes of the bf16 path (defined in lmufft_bf16.hip)
+size_t forward_workspace_bf16(const lmufft_shape& s);
+size_t backward_workspace_bf16(const lmufft_shape& s);
 
 // Brackets one kernel launch with HIP events when profiling is enabled
 // (lmufft_profile_enable); a no-op otherwise.

@@ -11,7 +11,10 @@ import torch
 
 from . import _lib
 
+_DEBUG = None  # set to a dict by kernel-debugging scripts to capture intermediates of the last backward
+
 _ALGOS = {"auto": _lib.CONV_AUTO, "toeplitz": _lib.CONV_TOEPLITZ, "fft": _lib.CONV_FFT}
+_DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
 
 
 def _ptr(t):
@@ -38,16 +41,33 @@ def _shape(B, T, D, M, Hd, ldH) -> _lib.Shape:
     return _lib.Shape(int(B), int(T), int(D), int(M), int(Hd), int(ldH))
 
 
+def prepare_impulse_bf16(H: torch.Tensor) -> torch.Tensor:
+    """bf16 copies of H in both orientations, as the bf16 kernels read them.
+
+    H is a constant buffer of the module, so callers build this once per H and
+    pass it to `lmufft_layer(..., hprep=...)`.
+    """
+    _require_gpu(H, "H")
+    H = H.contiguous().float()
+    M, ldH = H.shape
+    shp = _shape(1, 1, 1, M, 1, ldH)
+    buf = _workspace(_lib.lib.lmufft_hprep_bytes(ctypes.byref(shp)), H.device)
+    with torch.cuda.device(H.device):
+        rc = _lib.lib.lmufft_hprep_bf16(ctypes.byref(shp), _ptr(H), _ptr(buf), _stream(H.device))
+    _lib.check(rc, "lmufft_hprep_bf16")
+    return buf
+
+
 class _LMUFFTFunction(torch.autograd.Function):
     """(x, w_u, b_u, W_h, b_h, H) -> (h, h_n); reference: src/lmu.py:290-320."""
 
     @staticmethod
-    def forward(ctx, x, w_u, b_u, W_h, b_h, H, conv_algo):
-        for name, t in (("x", x), ("W_u.weight", w_u), ("W_u.bias", b_u), ("W_h.weight", W_h),
-                        ("W_h.bias", b_h), ("H", H)):
+    def forward(ctx, x, w_u, b_u, W_h, b_h, H, conv_algo, hprep):
+        _require_gpu(x, "x")
+        if x.dtype not in _DTYPES:
+            raise RuntimeError(f"LMUFFT: x has dtype {x.dtype}; supported: float32, bfloat16")
+        for name, t in (("W_u.weight", w_u), ("W_u.bias", b_u), ("W_h.weight", W_h), ("W_h.bias", b_h), ("H", H)):
             _require_gpu(t, name)
-            if t.dtype != torch.float32:
-                raise RuntimeError(f"LMUFFT: `{name}` has dtype {t.dtype}; this build computes in float32")
             if t.device != x.device:
                 raise RuntimeError(f"LMUFFT: `{name}` is on {t.device}, x on {x.device}")
         if x.dim() != 3:
@@ -64,23 +84,37 @@ class _LMUFFTFunction(torch.autograd.Function):
                 f"LMUFFT: sequence length {T} exceeds the layer's seq_len {ldH} "
                 "(the reference fails likewise when they differ, src/lmu.py:308)"
             )
+        dt = x.dtype
+        ctx.param_dtypes = (w_u.dtype, b_u.dtype, W_h.dtype, b_h.dtype)
+        # parameters and H are consumed in fp32 (master weights); no-ops for fp32 modules
         x = x.contiguous()
-        w_u = w_u.contiguous()
-        W_h = W_h.contiguous()
-        H = H.contiguous()
+        w_u = w_u.contiguous().float()
+        b_u = b_u.contiguous().float()
+        W_h = W_h.contiguous().float()
+        b_h = b_h.contiguous().float()
+        H = H.contiguous().float()
         dev = x.device
         u = torch.empty((B, T), dtype=torch.float32, device=dev)
-        m = torch.empty((B, T, M), dtype=torch.float32, device=dev)
-        h = torch.empty((B, T, Hd), dtype=torch.float32, device=dev)
-        h_n = torch.empty((B, Hd), dtype=torch.float32, device=dev)
+        m = torch.empty((B, T, M), dtype=dt, device=dev)
+        h = torch.empty((B, T, Hd), dtype=dt, device=dev)
+        h_n = torch.empty((B, Hd), dtype=dt, device=dev)
         shp = _shape(B, T, D, M, Hd, ldH)
         with torch.cuda.device(dev):
-            ws = _workspace(_lib.lib.lmufft_forward_workspace_bytes(ctypes.byref(shp), _lib.F32), dev)
-            rc = _lib.lib.lmufft_forward_f32(
-                ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(b_u), _ptr(W_h), _ptr(b_h), _ptr(H),
-                _ptr(u), _ptr(m), _ptr(h), _ptr(h_n), conv_algo, _ptr(ws), ws.numel(), _stream(dev))
-        _lib.check(rc, "lmufft_forward_f32")
-        ctx.save_for_backward(x, w_u, W_h, H, u, m, h)
+            ws = _workspace(_lib.lib.lmufft_forward_workspace_bytes(ctypes.byref(shp), _DTYPES[dt]), dev)
+            if dt == torch.float32:
+                rc = _lib.lib.lmufft_forward_f32(
+                    ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(b_u), _ptr(W_h), _ptr(b_h), _ptr(H),
+                    _ptr(u), _ptr(m), _ptr(h), _ptr(h_n), conv_algo, _ptr(ws), ws.numel(), _stream(dev))
+                what = "lmufft_forward_f32"
+            else:
+                if hprep is None:
+                    hprep = prepare_impulse_bf16(H)
+                rc = _lib.lib.lmufft_forward_bf16(
+                    ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(b_u), _ptr(W_h), _ptr(b_h), _ptr(hprep),
+                    _ptr(u), _ptr(m), _ptr(h), _ptr(h_n), conv_algo, _ptr(ws), ws.numel(), _stream(dev))
+                what = "lmufft_forward_bf16"
+        _lib.check(rc, what)
+        ctx.save_for_backward(x, w_u, W_h, H, u, m, h, hprep)
         ctx.conv_algo = conv_algo
         ctx.shape = (B, T, D, M, Hd, ldH)
         ctx.set_materialize_grads(False)
@@ -88,16 +122,17 @@ class _LMUFFTFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gh, gh_n):
-        x, w_u, W_h, H, u, m, h = ctx.saved_tensors
+        x, w_u, W_h, H, u, m, h, hprep = ctx.saved_tensors
         B, T, D, M, Hd, ldH = ctx.shape
         dev = x.device
+        dt = x.dtype
         need_x = ctx.needs_input_grad[0]
         if gh is None and gh_n is None:
-            return (None,) * 7
+            return (None,) * 8
         if gh is not None:
-            gh = gh.contiguous()
+            gh = gh.to(dt).contiguous()
         if gh_n is not None:
-            gh_n = gh_n.contiguous()
+            gh_n = gh_n.to(dt).contiguous()
         gx = torch.empty_like(x) if need_x else None
         gw_u = torch.empty_like(w_u)
         gb_u = torch.empty((1,), dtype=torch.float32, device=dev)
@@ -106,18 +141,33 @@ class _LMUFFTFunction(torch.autograd.Function):
         gm = torch.empty_like(m)
         shp = _shape(B, T, D, M, Hd, ldH)
         with torch.cuda.device(dev):
-            ws = _workspace(_lib.lib.lmufft_backward_workspace_bytes(ctypes.byref(shp), _lib.F32), dev)
-            rc = _lib.lib.lmufft_backward_f32(
-                ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(W_h), _ptr(H), _ptr(u), _ptr(m), _ptr(h),
-                _ptr(gh), _ptr(gh_n), _ptr(gx), _ptr(gw_u), _ptr(gb_u), _ptr(gW_h), _ptr(gb_h), _ptr(gm),
-                ctx.conv_algo, _ptr(ws), ws.numel(), _stream(dev))
-        _lib.check(rc, "lmufft_backward_f32")
-        return gx, gw_u, gb_u, gW_h, gb_h, None, None
+            ws = _workspace(_lib.lib.lmufft_backward_workspace_bytes(ctypes.byref(shp), _DTYPES[dt]), dev)
+            if dt == torch.float32:
+                rc = _lib.lib.lmufft_backward_f32(
+                    ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(W_h), _ptr(H), _ptr(u), _ptr(m), _ptr(h),
+                    _ptr(gh), _ptr(gh_n), _ptr(gx), _ptr(gw_u), _ptr(gb_u), _ptr(gW_h), _ptr(gb_h), _ptr(gm),
+                    ctx.conv_algo, _ptr(ws), ws.numel(), _stream(dev))
+                what = "lmufft_backward_f32"
+            else:
+                rc = _lib.lib.lmufft_backward_bf16(
+                    ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(W_h), _ptr(hprep), _ptr(u), _ptr(m), _ptr(h),
+                    _ptr(gh), _ptr(gh_n), _ptr(gx), _ptr(gw_u), _ptr(gb_u), _ptr(gW_h), _ptr(gb_h), _ptr(gm),
+                    ctx.conv_algo, _ptr(ws), ws.numel(), _stream(dev))
+                what = "lmufft_backward_bf16"
+        _lib.check(rc, what)
+        if _DEBUG is not None:
+            _DEBUG.update(gm=gm, u=u, m=m)
+        pd = ctx.param_dtypes
+        return gx, gw_u.to(pd[0]), gb_u.to(pd[1]), gW_h.to(pd[2]), gb_h.to(pd[3]), None, None, None
 
 
-def lmufft_layer(x, w_u, b_u, W_h, b_h, H, conv_algo="auto"):
-    """h, h_n = LMUFFT forward with autograd support (HIP kernels only)."""
-    return _LMUFFTFunction.apply(x, w_u, b_u, W_h, b_h, H, _ALGOS[conv_algo])
+def lmufft_layer(x, w_u, b_u, W_h, b_h, H, conv_algo="auto", hprep=None):
+    """h, h_n = LMUFFT forward with autograd support (HIP kernels only).
+
+    x float32 -> exact-fp32 kernels; x bfloat16 -> bf16 kernels with fp32
+    accumulation (`hprep` = prepare_impulse_bf16(H), built on the fly if None).
+    """
+    return _LMUFFTFunction.apply(x, w_u, b_u, W_h, b_h, H, _ALGOS[conv_algo], hprep)
 
 
 def causal_conv(u, H, conv_algo="auto"):

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from .functional import lmufft_layer
+from .functional import lmufft_layer, prepare_impulse_bf16
 
 __all__ = ["LMUFFT", "LMU", "legendre_state_space", "impulse_response"]
 
@@ -88,11 +88,27 @@ class LMUFFT(nn.Module):
         H, fft_H = impulse_response(A, B, seq_len)
         self.register_buffer("H", H)  # [memory_size, seq_len]
         self.register_buffer("fft_H", fft_H)  # [memory_size, seq_len + 1] complex64
+        self._hprep = None  # (key, bf16 copies of H), rebuilt when H changes
+
+    def _impulse_bf16(self):
+        H = self.H
+        key = (H.data_ptr(), H._version, H.device, H.dtype)
+        if self._hprep is None or self._hprep[0] != key:
+            self._hprep = (key, prepare_impulse_bf16(H))
+        return self._hprep[1]
 
     def forward(self, x):
-        """x [batch, seq_len, input_size] -> (h [batch, seq_len, hidden], h_n [batch, hidden])."""
+        """x [batch, seq_len, input_size] -> (h [batch, seq_len, hidden], h_n [batch, hidden]).
+
+        float32 input runs the exact-fp32 kernels.  bfloat16 input, or any input
+        under `torch.autocast("cuda", dtype=torch.bfloat16)`, runs the bf16
+        kernels (fp32 accumulation, fp32 master parameters) and returns bf16.
+        """
+        if torch.is_autocast_enabled() and x.is_cuda and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+            x = x.to(torch.bfloat16)
+        hprep = self._impulse_bf16() if (x.is_cuda and x.dtype == torch.bfloat16) else None
         return lmufft_layer(x, self.W_u.weight, self.W_u.bias, self.W_h.weight, self.W_h.bias, self.H,
-                            conv_algo=self.conv_algo)
+                            conv_algo=self.conv_algo, hprep=hprep)
 
 
 class LMU(nn.Module):

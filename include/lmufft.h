@@ -108,6 +108,33 @@ int lmufft_conv_backward_f32(const lmufft_shape* s, const float* gm, const float
                              size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
+ * bf16 variant: activations x, m, h, h_n, gh, gh_n, gx, gm are bf16 (passed as
+ * void*), every sum is accumulated in fp32; parameters, their gradients, u and
+ * H stay fp32.  The reference has no bf16 GPU path for these lines (torch.fft
+ * rejects bf16); semantics = src/lmu.py:297-320 on bf16-rounded operands.
+ *
+ * `hprep` holds bf16 copies of H in both orientations.  H is a constant
+ * buffer of the module (src/lmu.py:243-245), so it is prepared once:
+ * allocate lmufft_hprep_bytes(s) (M and ldH are read), call lmufft_hprep_bf16,
+ * keep the buffer for every later forward/backward with that H.
+ * ---------------------------------------------------------------------- */
+size_t lmufft_hprep_bytes(const lmufft_shape* s);
+int lmufft_hprep_bf16(const lmufft_shape* s, const float* H, void* hprep, void* stream);
+
+int lmufft_forward_bf16(const lmufft_shape* s, const void* x, const float* w_u,
+                        const float* b_u, const float* W_h, const float* b_h,
+                        const void* hprep, float* u, void* m, void* h, void* h_n,
+                        int conv_algo, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
+int lmufft_backward_bf16(const lmufft_shape* s, const void* x, const float* w_u,
+                         const float* W_h, const void* hprep, const float* u,
+                         const void* m, const void* h, const void* gh,
+                         const void* gh_n, void* gx, float* gw_u, float* gb_u,
+                         float* gW_h, float* gb_h, void* gm, int conv_algo,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
  * Per-kernel timing with HIP events on the caller's stream (no counterpart in
  * the reference, which has no profiling hooks).  While enabled, every kernel
  * launch made by this library is bracketed by two events; the totals are read

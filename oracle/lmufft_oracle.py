@@ -194,8 +194,15 @@ def lmufft_forward(x, w_u, b_u, W_h, b_h, H, dtype=np.float64, conv="direct"):
     return {"u": u, "m": m, "h": h, "h_n": h[:, -1, :].copy()}
 
 
-def lmufft_backward(x, w_u, b_u, W_h, b_h, H, gh, gh_n=None, dtype=np.float64):
+def lmufft_backward(x, w_u, b_u, W_h, b_h, H, gh, gh_n=None, dtype=np.float64, h_mask=None, u_mask=None):
     """Hand-derived backward of the layer.
+
+    `h_mask` / `u_mask` (boolean, optional) replace the activation patterns
+    (z > 0) and (a > 0).  ReLU's derivative jumps at 0, so a reduced-precision
+    forward whose pre-activation differs from the fp64 one by rounding noise
+    takes the other branch for the few elements with |z| below that noise; a
+    backward kernel is then checked against the oracle evaluated with the
+    kernel's OWN forward pattern.
 
     g = gh (+ gh_n on the last frame); gz = g*(z>0); gW_h = gz^T [m;x];
     gb_h = sum gz; [gm; gx1] = gz W_h; gu = adjoint conv of gm;
@@ -210,7 +217,7 @@ def lmufft_backward(x, w_u, b_u, W_h, b_h, H, gh, gh_n=None, dtype=np.float64):
     g = np.array(gh, dtype=dtype, copy=True)
     if gh_n is not None:
         g[:, -1, :] += np.asarray(gh_n, dtype=dtype)
-    gz = g * (f["h"] > 0)
+    gz = g * ((f["h"] > 0) if h_mask is None else np.asarray(h_mask, dtype=bool))
     mx = np.concatenate([f["m"], x], axis=-1)  # [B,T,M+D]
     gW_h = np.einsum("btn,btj->nj", gz, mx)
     gb_h = gz.sum(axis=(0, 1))
@@ -218,7 +225,7 @@ def lmufft_backward(x, w_u, b_u, W_h, b_h, H, gh, gh_n=None, dtype=np.float64):
     gm = gmx[:, :, :M]
     gx = gmx[:, :, M:].copy()
     gu = anticausal_corr_direct(gm, H, dtype=dtype)
-    ga = gu * (f["u"] > 0)
+    ga = gu * ((f["u"] > 0) if u_mask is None else np.asarray(u_mask, dtype=bool))
     gw_u = np.einsum("bt,btd->d", ga, x)[None, :]
     gb_u = np.array([ga.sum()], dtype=dtype)
     gx += ga[:, :, None] * w_u1[None, None, :]
@@ -230,6 +237,8 @@ def lmufft_backward(x, w_u, b_u, W_h, b_h, H, gh, gh_n=None, dtype=np.float64):
         "gb_h": gb_h,
         "gm": gm,
         "gu": gu,
+        "gz": gz,
+        "ga": ga,
         **{k: f[k] for k in ("u", "m", "h", "h_n")},
     }
 

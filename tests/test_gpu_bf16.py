@@ -1,0 +1,207 @@
+"""GPU parity of the bf16 kernels.  The reference cannot run this path in bf16
+on a GPU (torch.fft rejects bf16), so the bar is the one BASELINE states: the
+fp32 reference arithmetic (here: the fp64 oracle) evaluated on the SAME
+bf16-rounded inputs and weights, rtol 2e-2 -- taken relative to |value| plus
+the norm of the terms of the sum that produces the value (see _close), since an
+element that cancels to ~0 has unbounded relative error in any 8-bit-mantissa
+format."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lmufft_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 2e-2
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.fail("these tests need a GPU")
+    return torch.device("cuda:0")
+
+
+def _close(got, ref, name, termnorm=None):
+    """|got - ref| <= 2e-2 * (|ref| + 2 termnorm), and the error as a whole (rms) below 1e-2 of the
+    larger of rms(ref) and rms(termnorm).
+
+    `termnorm` = sqrt(sum of squared terms) of the sum that produces each element.  Every term of a
+    sum carries up to three bf16 roundings of 2^-9 relative each (both operands and, for m and gm, a
+    stored intermediate), so the accumulated noise of a sum is ~0.7e-2 x that norm whatever the
+    (possibly cancelling) value of the sum is; 4e-2 x termnorm is about six standard deviations,
+    which is what a 2e-2 relative bar means for elements that do not cancel.
+    """
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    rms = max(float(np.sqrt(np.mean(ref ** 2))), 1e-30)
+    tn = np.zeros_like(ref) if termnorm is None else np.broadcast_to(np.asarray(termnorm, dtype=np.float64), ref.shape)
+    err = np.abs(got - ref)
+    bound = RTOL * (np.abs(ref) + 2.0 * tn) + 1e-30
+    bad = err > bound
+    rel = float(np.sqrt(np.mean(err ** 2))) / rms
+    assert not bad.any(), (
+        f"{name}: {bad.sum()} of {bad.size} out of tolerance; worst err/bound {np.max(err / bound):.2f}, "
+        f"max err {err.max():.3e}, rms rel err {rel:.3e}, ref rms {rms:.3e}")
+    rms_all = max(rms, float(np.sqrt(np.mean(tn ** 2))))
+    assert float(np.sqrt(np.mean(err ** 2))) < 1e-2 * rms_all, f"{name}: rms relative error {rel:.3e}"
+
+
+def _termnorms(x, w_u, W_h, H, ref):
+    """sqrt(sum of squared terms) for every output of the layer (see _close); rounding noise of
+    intermediate results (gm, gu) is carried along into the sums that consume them."""
+    M = ref["m"].shape[2]
+    T = x.shape[1]
+    Wm, Wx = W_h[:, :M].astype(np.float64), W_h[:, M:].astype(np.float64)
+    m, x, gz, gm = ref["m"], x.astype(np.float64), ref["gz"], ref["gm"]
+    w2 = w_u.astype(np.float64).reshape(-1) ** 2
+    H2 = H[:, :T].astype(np.float64) ** 2
+    tn = {}
+    # m is itself a (cancelling) sum stored in bf16: carry its own term norm along
+    m2 = m ** 2 + orc.causal_conv_direct(ref["u"] ** 2, H2)
+    tn["h"] = np.sqrt(m2 @ (Wm ** 2).T + (x ** 2) @ (Wx ** 2).T)
+    tn["h_n"] = tn["h"][:, -1, :]
+    tn_gm2 = (gz ** 2) @ (Wm ** 2)
+    tn_gu2 = orc.anticausal_corr_direct(gm ** 2 + tn_gm2, H2)
+    ga2 = ref["ga"] ** 2 + tn_gu2 * (ref["u"] > 0)
+    tn["gx"] = np.sqrt((gz ** 2) @ (Wx ** 2) + ga2[:, :, None] * w2[None, None, :])
+    tn["gw_u"] = np.sqrt(np.einsum("bt,btd->d", ga2, x ** 2))[None, :]
+    tn["gb_u"] = np.sqrt(ga2.sum(keepdims=True).reshape(1))
+    mx2 = np.concatenate([m2, x ** 2], axis=-1)
+    tn["gW_h"] = np.sqrt(np.einsum("btn,btj->nj", gz ** 2, mx2))
+    tn["gb_h"] = np.sqrt((gz ** 2).sum(axis=(0, 1)))
+    return tn
+
+
+def _bf(a):
+    return orc.round_bf16(np.asarray(a, dtype=np.float32))
+
+
+def _rand_H(rng, M, T):
+    t = np.arange(T)
+    return (rng.standard_normal((M, T)) * np.exp(-t / max(T / 3, 1))[None, :]).astype(np.float32)
+
+
+SHAPES = [
+    # B, T, D, M, Hd, ldH
+    (2, 16, 12, 6, 10, 16),       # scalar-load paths
+    (3, 37, 13, 5, 9, 41),
+    (1, 1, 8, 8, 8, 8),
+    (2, 100, 80, 128, 256, 100),  # reference smoke shape
+    (2, 65, 80, 192, 384, 100),
+    (3, 200, 384, 192, 384, 200),  # BASELINE config 1c
+    (2, 400, 80, 192, 384, 400),   # BASELINE config 1a
+]
+
+
+@pytest.mark.parametrize("B,T,D,M,Hd,ldH", SHAPES)
+@pytest.mark.parametrize("which", ["both", "h_only"])
+def test_bf16_layer_matches_oracle_on_rounded_inputs(B, T, D, M, Hd, ldH, which):
+    from asr_amd import lmufft_layer
+
+    dev = _dev()
+    rng = np.random.default_rng(B * 7 + T * 11 + D)
+    x = _bf(rng.standard_normal((B, T, D)))
+    w_u = _bf(rng.standard_normal((1, D)) / np.sqrt(D))
+    b_u = _bf(np.array([0.05]))
+    W_h = _bf(rng.standard_normal((Hd, M + D)) / np.sqrt(M + D))
+    b_h = _bf(0.1 * rng.standard_normal(Hd))
+    H = _bf(_rand_H(rng, M, ldH))
+    gh = _bf(rng.standard_normal((B, T, Hd)))
+    gh_n = _bf(rng.standard_normal((B, Hd))) if which == "both" else None
+    t32 = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    tx = t32(x).to(torch.bfloat16).requires_grad_(True)
+    params = [t32(a).requires_grad_(True) for a in (w_u, b_u, W_h, b_h)]
+    h, h_n = lmufft_layer(tx, *params, t32(H))
+    assert h.dtype == torch.bfloat16 and h_n.dtype == torch.bfloat16
+    # the backward is checked against the oracle on the kernel's own ReLU pattern (see the oracle's docstring)
+    fwd = orc.lmufft_forward(x, w_u, b_u, W_h, b_h, H[:, :T])
+    h_mask = h.detach().float().cpu().numpy() > 0
+    flips = int((h_mask != (fwd["h"] > 0)).sum())
+    assert flips <= 0.02 * h_mask.size, f"{flips} of {h_mask.size} activations on the other ReLU branch"
+    ref = orc.lmufft_backward(x, w_u, b_u, W_h, b_h, H[:, :T], gh, gh_n, h_mask=h_mask)
+    tn = _termnorms(x, w_u, W_h, H, ref)
+    _close(h.detach().float().cpu().numpy(), ref["h"], "h", tn["h"])
+    _close(h_n.detach().float().cpu().numpy(), ref["h_n"], "h_n", tn["h_n"])
+    loss = (h.float() * t32(gh)).sum()
+    if gh_n is not None:
+        loss = loss + (h_n.float() * t32(gh_n)).sum()
+    loss.backward()
+    assert tx.grad.dtype == torch.bfloat16
+    _close(tx.grad.float().cpu().numpy(), ref["gx"], "gx", tn["gx"])
+    for t, k in zip(params, ("gw_u", "gb_u", "gW_h", "gb_h")):
+        assert t.grad.dtype == torch.float32
+        _close(t.grad.cpu().numpy(), ref[k], k, tn[k])
+
+
+def test_bf16_module_autocast_and_golden(golden_dir):
+    """Module under autocast(bf16): fp32 input and parameters, bf16 kernels, vs the reference's fp32 golden."""
+    from asr_amd import LMUFFT
+
+    dev = _dev()
+    g = dict(np.load(os.path.join(golden_dir, "cfg1a_f32.npz")))
+    layer = LMUFFT(80, 384, 192, 400, 1000)
+    sd = layer.state_dict()
+    for k, gk in (("W_u.weight", "w_u"), ("W_u.bias", "b_u"), ("W_h.weight", "W_h"), ("W_h.bias", "b_h")):
+        sd[k] = torch.from_numpy(g[gk])
+    layer.load_state_dict(sd)
+    layer = layer.to(dev)
+    x = torch.from_numpy(g["x"]).to(dev).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        h, h_n = layer(x)
+    assert h.dtype == torch.bfloat16
+    # against the fp32 reference output itself: bf16 rounding of x/W/H/m/h all inside 2e-2
+    ref = orc.lmufft_backward(g["x"], g["w_u"], g["b_u"], g["W_h"], g["b_h"], g["H"], g["gh"], None,
+                              h_mask=h.detach().float().cpu().numpy() > 0)
+    tn = _termnorms(g["x"], g["w_u"], g["W_h"], g["H"], ref)
+    _close(h.detach().float().cpu().numpy(), g["h"], "h vs fp32 golden", tn["h"])
+    (h.float() * torch.from_numpy(g["gh"]).to(dev)).sum().backward()
+    assert x.grad.dtype == torch.float32 and layer.W_h.weight.grad.dtype == torch.float32
+    # compare against the golden gradient without its h_n term: recompute with the oracle
+    _close(x.grad.cpu().numpy(), ref["gx"], "gx", tn["gx"])
+    _close(layer.W_h.weight.grad.cpu().numpy(), ref["gW_h"], "gW_h", tn["gW_h"])
+    # a second call reuses the cached bf16 copy of H
+    key = layer._hprep[0]
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        h2, _ = layer(x)
+    assert layer._hprep[0] == key and torch.equal(h2, h)
+
+
+def test_bf16_full_size_properties():
+    """BASELINE config 2 layer shape in bf16: a slice against the oracle, plus exact structural properties."""
+    from asr_amd import LMUFFT
+
+    dev = _dev()
+    torch.manual_seed(3)
+    layer = LMUFFT(384, 384, 192, 400, 1000)
+    torch.nn.init.xavier_uniform_(layer.W_u.weight)
+    torch.nn.init.xavier_uniform_(layer.W_h.weight)
+    torch.nn.init.zeros_(layer.W_u.bias)
+    torch.nn.init.zeros_(layer.W_h.bias)
+    layer = layer.to(dev)
+    x = torch.randn(64, 400, 384, device=dev).to(torch.bfloat16).requires_grad_(True)
+    h, h_n = layer(x)
+    assert torch.equal(h_n, h[:, -1, :])
+    gh = torch.randn(64, 400, 384, device=dev).to(torch.bfloat16)
+    h.backward(gh)
+    b = 41
+    sd = {k: v.detach().cpu().numpy() for k, v in layer.state_dict().items() if k != "fft_H"}
+    ref = orc.lmufft_backward(x[b : b + 1].detach().float().cpu().numpy(), _bf(sd["W_u.weight"]), sd["W_u.bias"],
+                              _bf(sd["W_h.weight"]), sd["W_h.bias"], _bf(sd["H"]),
+                              gh[b : b + 1].float().cpu().numpy(),
+                              h_mask=h[b : b + 1].detach().float().cpu().numpy() > 0)
+    tn = _termnorms(x[b : b + 1].detach().float().cpu().numpy(), sd["W_u.weight"], sd["W_h.weight"], sd["H"], ref)
+    _close(h[b : b + 1].detach().float().cpu().numpy(), ref["h"], "h[41]", tn["h"])
+    _close(x.grad[b : b + 1].float().cpu().numpy(), ref["gx"], "gx[41]", tn["gx"])
+    # batch items are independent: permuting the batch permutes the outputs bit for bit
+    perm = torch.randperm(64, device=dev)
+    h_p, _ = layer(x.detach()[perm])
+    assert torch.equal(h_p, h.detach()[perm])
+    # causality: frames after t0 do not influence frames before it
+    x2 = x.detach().clone()
+    x2[:, 300:] = 0
+    h_c, _ = layer(x2)
+    assert torch.equal(h_c[:, :300], h.detach()[:, :300])
