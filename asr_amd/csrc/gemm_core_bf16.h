@@ -49,19 +49,37 @@ __device__ __forceinline__ bf16x8 bzero8() {
 }
 
 // eight consecutive bf16 of `base` starting at idx; elements whose position
-// pos + j reaches `limit` read as zero.  With VEC the caller guarantees
-// 16-byte alignment and pos % 8 == limit % 8 == 0.
+// pos + j reaches `limit`, and the whole vector when !ok, read as zero.  With
+// VEC the caller guarantees 16-byte alignment and pos % 8 == limit % 8 == 0;
+// a masked vector is loaded from kZeroBytes (select on the address, not on
+// the loaded value: see gemm_core_f32.h).
 template <bool VEC>
-__device__ __forceinline__ bf16x8 bload8(const bf16_t* __restrict__ base, long idx, int pos, int limit) {
+__device__ __forceinline__ bf16x8 bload8(const bf16_t* __restrict__ base, long idx, int pos, int limit,
+                                         bool ok = true) {
   if (VEC) {
-    if (pos < limit) return *reinterpret_cast<const bf16x8*>(base + idx);
-    return bzero8();
+    const bf16_t* p = (ok && pos < limit) ? base + idx : reinterpret_cast<const bf16_t*>(kZeroBytes);
+    return *reinterpret_cast<const bf16x8*>(p);
   } else {
     bf16x8 v;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (pos + j < limit) ? base[idx + j] : (bf16_t)0.f;
+    for (int j = 0; j < 8; ++j) v[j] = (ok && pos + j < limit) ? base[idx + j] : (bf16_t)0.f;
     return v;
   }
+}
+
+// Loader protocol as in gemm_core_f32.h: raw_t fetch(r, k) issues the global
+// loads of one 16-byte staging vector, bf16x8 finish(raw) does the element-wise
+// work and runs only when the tile is written to LDS.
+template <class F>
+struct PlainLoadB {
+  F f;
+  typedef bf16x8 raw_t;
+  __device__ __forceinline__ raw_t fetch(int r, int k) const { return f(r, k); }
+  __device__ __forceinline__ bf16x8 finish(const raw_t& v) const { return v; }
+};
+template <class F>
+__device__ __forceinline__ PlainLoadB<F> plain_load_b(F f) {
+  return PlainLoadB<F>{f};
 }
 
 // ---- k-contiguous operand -------------------------------------------------
@@ -72,21 +90,22 @@ struct LdsOperandKC {
   static_assert((R * BK / 8) % kThreads == 0, "each thread stages a whole number of 16-byte vectors");
   static constexpr int NV = R * BK / 8 / kThreads;
   bf16_t* S;
-  Load& load;
-  bf16x8 regs[NV];
-  __device__ __forceinline__ LdsOperandKC(bf16_t* s, Load& l) : S(s), load(l) {}
+  const Load& load;
+  typename Load::raw_t regs[NV];
+  __device__ __forceinline__ LdsOperandKC(bf16_t* s, const Load& l) : S(s), load(l) {}
+  // load.fetch(r, k): elements k..k+7 of tile row r
   __device__ __forceinline__ void fetch(int k0) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int idx = threadIdx.x + i * kThreads;
-      regs[i] = load(idx / (BK / 8), k0 + (idx % (BK / 8)) * 8);
+      regs[i] = load.fetch(idx / (BK / 8), k0 + (idx % (BK / 8)) * 8);
     }
   }
   __device__ __forceinline__ void store() {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int idx = threadIdx.x + i * kThreads;
-      *reinterpret_cast<bf16x8*>(&S[(idx / (BK / 8)) * LDK + (idx % (BK / 8)) * 8]) = regs[i];
+      *reinterpret_cast<bf16x8*>(&S[(idx / (BK / 8)) * LDK + (idx % (BK / 8)) * 8]) = load.finish(regs[i]);
     }
   }
   // fragment of tile row `row` for the k-step starting at tile-local k = kl (multiple of 16)
@@ -104,23 +123,30 @@ struct LdsOperandTR {
   static_assert((R * BK / 8) % kThreads == 0, "each thread stages a whole number of 16-byte vectors");
   static constexpr int NV = R * BK / 8 / kThreads;
   bf16_t* S;
-  Load& load;
-  bf16x8 regs[NV];
-  __device__ __forceinline__ LdsOperandTR(bf16_t* s, Load& l) : S(s), load(l) {}
-  // load(r, k): eight consecutive output-dimension elements r..r+7 at depth k
+  const Load& load;
+  typename Load::raw_t regs[NV];
+  __device__ __forceinline__ LdsOperandTR(bf16_t* s, const Load& l) : S(s), load(l) {}
+  // load.fetch(r, k): eight consecutive output-dimension elements r..r+7 at depth k
   __device__ __forceinline__ void fetch(int k0) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int idx = threadIdx.x + i * kThreads;
-      regs[i] = load((idx % (R / 8)) * 8, k0 + idx / (R / 8));
+      regs[i] = load.fetch((idx % (R / 8)) * 8, k0 + idx / (R / 8));
     }
   }
-  __device__ __forceinline__ void store() {
+  // seen(v) is called with every finished vector (used for the bias-gradient column sums)
+  template <class Seen>
+  __device__ __forceinline__ void store(Seen&& seen) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int idx = threadIdx.x + i * kThreads;
-      *reinterpret_cast<bf16x8*>(&S[(idx / (R / 8)) * LD + (idx % (R / 8)) * 8]) = regs[i];
+      const bf16x8 v = load.finish(regs[i]);
+      seen(v);
+      *reinterpret_cast<bf16x8*>(&S[(idx / (R / 8)) * LD + (idx % (R / 8)) * 8]) = v;
     }
+  }
+  __device__ __forceinline__ void store() {
+    store([](const bf16x8&) {});
   }
   // fragment for the 32 output rows starting at row0 and the k-step at tile-local kl.
   // In each 16-lane group, lane 4q+p addresses k row q, elements 4p..4p+3, and

@@ -57,49 +57,77 @@ struct Tile {
 
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-// base[idx .. idx+3], elements at or beyond `limit` read as zero.  With VEC the
-// caller guarantees idx % 4 == 0, limit % 4 == 0 and a 16-byte aligned row.
+// 32 bytes of zeros in device memory: masked-out vector loads are redirected
+// here instead of being zeroed after the fact.  A select on a loaded VALUE
+// makes the compiler wait for the load right where it was issued; a select on
+// the ADDRESS lets every staging load of a tile stay in flight behind the MFMAs.
+static __device__ __attribute__((aligned(32))) const unsigned int kZeroBytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+// base[idx .. idx+3]; elements at or beyond `limit` (position pos + j) and the
+// whole vector when !ok read as zero.  With VEC the caller guarantees
+// idx % 4 == 0, limit % 4 == 0 and a 16-byte aligned base.
 template <bool VEC>
-__device__ __forceinline__ f32x4 load4(const float* __restrict__ base, long idx, int pos, int limit) {
+__device__ __forceinline__ f32x4 load4(const float* __restrict__ base, long idx, int pos, int limit,
+                                       bool ok = true) {
   if (VEC) {
-    if (pos < limit) return *reinterpret_cast<const f32x4*>(base + idx);
-    return zero4();
+    const float* p = (ok && pos < limit) ? base + idx : reinterpret_cast<const float*>(kZeroBytes);
+    return *reinterpret_cast<const f32x4*>(p);
   } else {
     f32x4 v;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = (pos + j < limit) ? base[idx + j] : 0.f;
+    for (int j = 0; j < 4; ++j) v[j] = (ok && pos + j < limit) ? base[idx + j] : 0.f;
     return v;
   }
 }
 
+// Operand loaders have two halves so that nothing touches loaded data before
+// the MFMAs of the current tile have been issued:
+//   raw_t fetch(r, k)  -- issues the global loads of one staging vector;
+//   f32x4 finish(raw)  -- element-wise work on the loaded values (masking,
+//                         adds), run only when the tile is written to LDS.
+// KC layout: fetch(r, k) covers elements k..k+3 of tile row r;
+// NC layout: fetch(r, k) covers tile rows r..r+3 at depth k.
+template <class F>
+struct PlainLoad {
+  F f;
+  typedef f32x4 raw_t;
+  __device__ __forceinline__ raw_t fetch(int r, int k) const { return f(r, k); }
+  __device__ __forceinline__ f32x4 finish(const raw_t& v) const { return v; }
+};
+template <class F>
+__device__ __forceinline__ PlainLoad<F> plain_load(F f) {
+  return PlainLoad<F>{f};
+}
+
 template <int R, int BK, int LAY, int NV, class Load>
-__device__ __forceinline__ void tile_fetch(f32x4 (&regs)[NV], Load& load, int k0) {
+__device__ __forceinline__ void tile_fetch(typename Load::raw_t (&regs)[NV], const Load& load, int k0) {
   const int tid = threadIdx.x;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int idx = tid + i * kThreads;
     if (LAY == KC) {
       const int r = idx / (BK / 4), c = idx % (BK / 4);
-      regs[i] = load(r, k0 + c * 4);
+      regs[i] = load.fetch(r, k0 + c * 4);
     } else {
       const int k = idx / (R / 4), r4 = idx % (R / 4);
-      regs[i] = load(r4 * 4, k0 + k);
+      regs[i] = load.fetch(r4 * 4, k0 + k);
     }
   }
 }
 
-template <int R, int BK, int LAY, int NV>
-__device__ __forceinline__ void tile_store(float* S, const f32x4 (&regs)[NV]) {
+template <int R, int BK, int LAY, int NV, class Load>
+__device__ __forceinline__ void tile_store(float* S, const typename Load::raw_t (&regs)[NV], const Load& load) {
   const int tid = threadIdx.x;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int idx = tid + i * kThreads;
+    const f32x4 v = load.finish(regs[i]);
     if (LAY == KC) {
       const int r = idx / (BK / 4), c = idx % (BK / 4);
-      *reinterpret_cast<f32x4*>(&S[r * (BK + 4) + c * 4]) = regs[i];
+      *reinterpret_cast<f32x4*>(&S[r * (BK + 4) + c * 4]) = v;
     } else {
       const int k = idx / (R / 4), r4 = idx % (R / 4);
-      *reinterpret_cast<f32x4*>(&S[k * R + r4 * 4]) = regs[i];
+      *reinterpret_cast<f32x4*>(&S[k * R + r4 * 4]) = v;
     }
   }
 }
@@ -167,18 +195,19 @@ __device__ __forceinline__ void tile_compute(const float* As, const float* Bs,
 // must return zero outside the real operand.  Every thread of the workgroup
 // must call it with the same kbeg/kend (it contains barriers).
 template <class T, class LA, class LB>
-__device__ __forceinline__ void gemm_tile(float* smem, f32x16 (&acc)[T::TM][T::TN], LA& la, LB& lb,
+__device__ __forceinline__ void gemm_tile(float* smem, f32x16 (&acc)[T::TM][T::TN], const LA& la, const LB& lb,
                                           int kbeg, int kend, const WavePos<T>& w) {
   float* As = smem;
   float* Bs = smem + T::A_FLOATS;
-  f32x4 ra[T::A_VECS], rb[T::B_VECS];
+  typename LA::raw_t ra[T::A_VECS];
+  typename LB::raw_t rb[T::B_VECS];
   if (kbeg < kend) {
     tile_fetch<T::BM, T::BK, T::ALAY>(ra, la, kbeg);
     tile_fetch<T::BN, T::BK, T::BLAY>(rb, lb, kbeg);
   }
   for (int k0 = kbeg; k0 < kend; k0 += T::BK) {
-    tile_store<T::BM, T::BK, T::ALAY>(As, ra);
-    tile_store<T::BN, T::BK, T::BLAY>(Bs, rb);
+    tile_store<T::BM, T::BK, T::ALAY>(As, ra, la);
+    tile_store<T::BN, T::BK, T::BLAY>(Bs, rb, lb);
     __syncthreads();
     if (k0 + T::BK < kend) {
       tile_fetch<T::BM, T::BK, T::ALAY>(ra, la, k0 + T::BK);

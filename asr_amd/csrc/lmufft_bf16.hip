@@ -128,11 +128,10 @@ __global__ __launch_bounds__(kThreads) void k_conv_fwd_bf16(const float* __restr
   const int kend = min(T, t0 + TL::BM);
   const int kend_pad = cdiv_dev(kend, TL::BK) * TL::BK;
 
-  auto lb = [=](int r, int k) -> bf16x8 {
+  auto lb = plain_load_b([=](int r, int k) -> bf16x8 {
     const int n = n0 + r;
-    if (n >= M) return bzero8();
-    return bload8<true>(Hb, (long)n * ldHb + k, k, ldHb);
-  };
+    return bload8<true>(Hb, (long)n * ldHb + k, k, ldHb, n < M);
+  });
   typedef LdsOperandKC<TL::BN, TL::BK, decltype(lb)> OpB;
   OpB ob(smem, lb);
   bf16_t* U8 = smem + OpB::ELEMS;
@@ -186,14 +185,14 @@ __global__ __launch_bounds__(kThreads) void k_proj_fwd_bf16(const bf16_t* __rest
   const int m0 = blockIdx.y * TL::BM;
   const int K = M + D;
 
-  auto la = [=](int r, int k) -> bf16x8 {
+  auto la = plain_load_b([=](int r, int k) -> bf16x8 {
     const long row = m0 + r;
-    if (row >= rows) return bzero8();
-    if (VEC) {
-      if (k < M) return *reinterpret_cast<const bf16x8*>(m + row * M + k);
-      if (k < K) return *reinterpret_cast<const bf16x8*>(x + row * D + (k - M));
-      return bzero8();
+    if (VEC) {  // one 16-byte load from whichever panel holds column k
+      const bf16_t* p = k < M ? m + row * M + k : x + row * D + (k - M);
+      p = (row < rows && k < K) ? p : reinterpret_cast<const bf16_t*>(kZeroBytes);
+      return *reinterpret_cast<const bf16x8*>(p);
     } else {
+      if (row >= rows) return bzero8();
       bf16x8 v;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -202,12 +201,11 @@ __global__ __launch_bounds__(kThreads) void k_proj_fwd_bf16(const bf16_t* __rest
       }
       return v;
     }
-  };
-  auto lb = [=](int r, int k) -> bf16x8 {
+  });
+  auto lb = plain_load_b([=](int r, int k) -> bf16x8 {
     const int n = n0 + r;
-    if (n >= Hd) return bzero8();
-    return bload8<true>(Wb, (long)n * ldW + k, k, ldW);
-  };
+    return bload8<true>(Wb, (long)n * ldW + k, k, ldW, n < Hd);
+  });
   typedef LdsOperandKC<TL::BM, TL::BK, decltype(la)> OpA;
   typedef LdsOperandKC<TL::BN, TL::BK, decltype(lb)> OpB;
   OpA oa(smem, la);
@@ -221,29 +219,74 @@ __global__ __launch_bounds__(kThreads) void k_proj_fwd_bf16(const bf16_t* __rest
   tileb_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
     const long row = m0 + mm;
     const int n = n0 + nn;
-    if (row < rows && n < Hd) {
-      const bf16_t y = (bf16_t)fmaxf(v + bias[n], 0.f);
-      h[row * Hd + n] = y;
-      if ((int)(row % T) == T - 1) h_n[(row / T) * Hd + n] = y;
-    }
+    if (row < rows && n < Hd) h[row * Hd + n] = (bf16_t)fmaxf(v + bias[n], 0.f);
   });
+  // h_n: the last frame of every utterance that ends inside this row tile
+  const long tile_end = min((long)rows, (long)m0 + TL::BM);
+  for (long rl = ((long)m0 / T) * T + T - 1; rl < tile_end; rl += T) {
+    const int ml = (int)(rl - m0);
+    tileb_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
+      const int n = n0 + nn;
+      if (mm == ml && n < Hd) h_n[(rl / T) * Hd + n] = (bf16_t)fmaxf(v + bias[n], 0.f);
+    });
+  }
 }
 
-// gz[row][n..n+7] = (h > 0) ? gh (+ gh_n on the last frame) : 0
+// gz[row][n..n+7] = (h > 0) ? gh (+ gh_n on the last frame) : 0.
+// fetch issues the loads of h, gh (and gh_n); the masking runs in finish.
 template <bool VEC>
-__device__ __forceinline__ bf16x8 load_gz8(const bf16_t* __restrict__ h, const bf16_t* __restrict__ gh,
-                                           const bf16_t* __restrict__ gh_n, long row, int n, int T, int Hd) {
-  const bf16x8 hv = bload8<VEC>(h, row * Hd + n, n, Hd);
-  bf16x8 g = gh ? bload8<VEC>(gh, row * Hd + n, n, Hd) : bzero8();
-  if (gh_n && (int)(row % T) == T - 1) {
-    const bf16x8 gl = bload8<VEC>(gh_n, (row / T) * Hd + n, n, Hd);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) g[j] = (bf16_t)((float)g[j] + (float)gl[j]);
+struct GzSourceB {
+  const bf16_t* __restrict__ h;
+  const bf16_t* __restrict__ gh;
+  const bf16_t* __restrict__ gh_n;
+  int T, Hd;
+  struct raw_t {
+    bf16x8 h, g, gl;
+  };
+  __device__ __forceinline__ raw_t fetch_at(long row, int n, bool ok) const {
+    raw_t r;
+    r.h = bload8<VEC>(h, row * Hd + n, n, Hd, ok);
+    r.g = gh ? bload8<VEC>(gh, row * Hd + n, n, Hd, ok) : bzero8();
+    r.gl = bzero8();
+    if (gh_n) {  // (uniform) the last frame also receives the gradient of h_n
+      const unsigned b = (unsigned)row / (unsigned)T;
+      const bool last = (unsigned)row - b * (unsigned)T == (unsigned)(T - 1);
+      r.gl = bload8<VEC>(gh_n, (long)b * Hd + n, n, Hd, ok && last);
+    }
+    return r;
   }
+  __device__ __forceinline__ bf16x8 finish(const raw_t& r) const {
+    bf16x8 g = r.g;
+    if (gh_n) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) g[j] = (float)hv[j] > 0.f ? g[j] : (bf16_t)0.f;
-  return g;
-}
+      for (int j = 0; j < 8; ++j) g[j] = (bf16_t)((float)g[j] + (float)r.gl[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = (float)r.h[j] > 0.f ? g[j] : (bf16_t)0.f;
+    return g;
+  }
+};
+
+// A operand of the data gradient: tile row = frame, k = hidden unit
+template <bool VEC>
+struct GzRowsLoadB {
+  GzSourceB<VEC> src;
+  long m0;
+  int rows;
+  typedef typename GzSourceB<VEC>::raw_t raw_t;
+  __device__ __forceinline__ raw_t fetch(int r, int k) const { return src.fetch_at(m0 + r, k, m0 + r < rows); }
+  __device__ __forceinline__ bf16x8 finish(const raw_t& v) const { return src.finish(v); }
+};
+
+// A operand of the weight gradient: 8 consecutive hidden units at frame k
+template <bool VEC>
+struct GzColsLoadB {
+  GzSourceB<VEC> src;
+  int n0, kend;
+  typedef typename GzSourceB<VEC>::raw_t raw_t;
+  __device__ __forceinline__ raw_t fetch(int r, int k) const { return src.fetch_at((long)k, n0 + r, k < kend); }
+  __device__ __forceinline__ bf16x8 finish(const raw_t& v) const { return src.finish(v); }
+};
 
 // ---------------------------------------------------------------------------
 // out[row][j] = sum_n gz[row][n] W_h[n][j_begin + j]  (+ ga[row] w_u[j])
@@ -262,16 +305,11 @@ __global__ __launch_bounds__(kThreads) void k_dgrad_bf16(const bf16_t* __restric
   const int n0 = blockIdx.x * TL::BN;
   const int m0 = blockIdx.y * TL::BM;
 
-  auto la = [=](int r, int k) -> bf16x8 {
-    const long row = m0 + r;
-    if (row >= rows) return bzero8();
-    return load_gz8<VEC>(h, gh, gh_n, row, k, T, Hd);
-  };
-  auto lb = [=](int r, int k) -> bf16x8 {
+  const GzRowsLoadB<VEC> la{{h, gh, gh_n, T, Hd}, (long)m0, rows};
+  auto lb = plain_load_b([=](int r, int k) -> bf16x8 {
     const int j = n0 + r;
-    if (j >= ncols) return bzero8();
-    return bload8<true>(WbT, (long)(j_begin + j) * ldWT + k, k, ldWT);
-  };
+    return bload8<true>(WbT, (long)(j_begin + j) * ldWT + k, k, ldWT, j < ncols);
+  });
   typedef LdsOperandKC<TL::BM, TL::BK, decltype(la)> OpA;
   typedef LdsOperandKC<TL::BN, TL::BK, decltype(lb)> OpB;
   OpA oa(smem, la);
@@ -316,11 +354,10 @@ __global__ __launch_bounds__(kThreads) void k_conv_bwd_bf16(const bf16_t* __rest
   const int send = min(T, t0 + TL::BM);
   const bf16_t* gmb = gm + (long)b * T * M;
 
-  auto la = [=](int r, int k) -> bf16x8 {
+  auto la = plain_load_b([=](int r, int k) -> bf16x8 {
     const int t = t0 + r;
-    if (t >= T) return bzero8();
-    return bload8<VEC>(gmb, (long)t * M + k, k, M);
-  };
+    return bload8<VEC>(gmb, (long)t * M + k, k, M, t < T);
+  });
   typedef LdsOperandKC<TL::BM, TL::BK, decltype(la)> OpA;
   constexpr int kBElems = TL::BN * (TL::BK + 8);
   float* gu_acc = reinterpret_cast<float*>(smem + OpA::ELEMS + kBElems);
@@ -328,11 +365,10 @@ __global__ __launch_bounds__(kThreads) void k_conv_bwd_bf16(const bf16_t* __rest
 
   WavePos<TL> w;
   for (int tau0 = 0; tau0 < send; tau0 += TL::BN) {
-    auto lb = [=](int r, int k) -> bf16x8 {
+    auto lb = plain_load_b([=](int r, int k) -> bf16x8 {
       const int tau = tau0 + r;
-      if (tau >= rowsHT) return bzero8();
-      return bload8<true>(HbT, (long)tau * ldHT + k, k, ldHT);
-    };
+      return bload8<true>(HbT, (long)tau * ldHT + k, k, ldHT, tau < rowsHT);
+    });
     typedef LdsOperandKC<TL::BN, TL::BK, decltype(lb)> OpB;
     static_assert(OpB::ELEMS == kBElems, "LDS carve");
     OpA oa(smem, la);
@@ -375,19 +411,16 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
   const int kend = min(rows, kbeg + rows_per_split);
   float* slab = slabs + blockIdx.z * ((long)Hd * MD + Hd);
 
-  auto la = [=](int r, int k) -> bf16x8 {
-    if (k >= kend) return bzero8();
-    return load_gz8<VEC>(h, gh, gh_n, (long)k, n0 + r, T, Hd);
-  };
-  auto lb = [=](int r, int k) -> bf16x8 {
-    if (k >= kend) return bzero8();
+  const GzColsLoadB<VEC> la{{h, gh, gh_n, T, Hd}, n0, kend};
+  auto lb = plain_load_b([=](int r, int k) -> bf16x8 {
     const long row = k;
     const int j = j0 + r;
     if (VEC) {
-      if (j < M) return *reinterpret_cast<const bf16x8*>(m + row * M + j);
-      if (j < MD) return *reinterpret_cast<const bf16x8*>(x + row * D + (j - M));
-      return bzero8();
+      const bf16_t* p = j < M ? m + row * M + j : x + row * D + (j - M);
+      p = (k < kend && j < MD) ? p : reinterpret_cast<const bf16_t*>(kZeroBytes);
+      return *reinterpret_cast<const bf16x8*>(p);
     } else {
+      if (k >= kend) return bzero8();
       bf16x8 v;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
@@ -396,7 +429,7 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
       }
       return v;
     }
-  };
+  });
   typedef LdsOperandTR<TL::BM, TL::BK, 32, decltype(la)> OpA;
   typedef LdsOperandTR<TL::BN, TL::BK, 32, decltype(lb)> OpB;
   OpA oa(smem, la);
@@ -406,12 +439,10 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
   // a thread always stages the same 8 units (256 % (BM/8) == 0)
   const bool do_bias = blockIdx.x == 0;
   float colsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  auto add_colsum = [&]() {
+  auto seen = [&](const bf16x8& v) {
     if (do_bias) {
 #pragma unroll
-      for (int i = 0; i < OpA::NV; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) colsum[j] += (float)oa.regs[i][j];
+      for (int j = 0; j < 8; ++j) colsum[j] += (float)v[j];
     }
   };
 
@@ -421,16 +452,14 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
   if (kbeg < kend) {
     oa.fetch(kbeg);
     ob.fetch(kbeg);
-    add_colsum();
   }
   for (int k0 = kbeg; k0 < kend; k0 += TL::BK) {
-    oa.store();
+    oa.store(seen);
     ob.store();
     __syncthreads();
     if (k0 + TL::BK < kend) {
       oa.fetch(k0 + TL::BK);
       ob.fetch(k0 + TL::BK);
-      add_colsum();
     }
 #pragma unroll
     for (int kl = 0; kl < TL::BK; kl += 16) {

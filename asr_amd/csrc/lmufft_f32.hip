@@ -75,21 +75,21 @@ __global__ __launch_bounds__(kThreads) void k_conv_fwd(const float* __restrict__
   const int t0 = tb * TL::BM;
   const float* ub = u + (long)b * T;
 
-  auto la = [=](int r, int k) -> f32x4 {
+  const float* zf = reinterpret_cast<const float*>(kZeroBytes);
+  auto la = plain_load([=](int r, int k) -> f32x4 {
     const int t = t0 + r;
     f32x4 v;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int s = t - (k + j);
-      v[j] = (t < T && s >= 0) ? ub[s] : 0.f;
+      v[j] = *((t < T && s >= 0) ? ub + s : zf);
     }
     return v;
-  };
-  auto lb = [=](int r, int k) -> f32x4 {
+  });
+  auto lb = plain_load([=](int r, int k) -> f32x4 {
     const int n = n0 + r;
-    if (n >= M) return zero4();
-    return load4<VEC>(H, (long)n * ldH + k, k, T);
-  };
+    return load4<VEC>(H, (long)n * ldH + k, k, T, n < M);
+  });
 
   WavePos<TL> w;
   f32x16 acc[TL::TM][TL::TN];
@@ -124,14 +124,14 @@ __global__ __launch_bounds__(kThreads) void k_proj_fwd(const float* __restrict__
   const int m0 = blockIdx.y * TL::BM;
   const int K = M + D;
 
-  auto la = [=](int r, int k) -> f32x4 {
+  auto la = plain_load([=](int r, int k) -> f32x4 {
     const long row = m0 + r;
-    if (row >= rows) return zero4();
-    if (VEC) {
-      if (k < M) return *reinterpret_cast<const f32x4*>(m + row * M + k);
-      if (k < K) return *reinterpret_cast<const f32x4*>(x + row * D + (k - M));
-      return zero4();
+    if (VEC) {  // one 16-byte load from whichever panel holds column k
+      const float* p = k < M ? m + row * M + k : x + row * D + (k - M);
+      p = (row < rows && k < K) ? p : reinterpret_cast<const float*>(kZeroBytes);
+      return *reinterpret_cast<const f32x4*>(p);
     } else {
+      if (row >= rows) return zero4();
       f32x4 v;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -140,12 +140,11 @@ __global__ __launch_bounds__(kThreads) void k_proj_fwd(const float* __restrict__
       }
       return v;
     }
-  };
-  auto lb = [=](int r, int k) -> f32x4 {
+  });
+  auto lb = plain_load([=](int r, int k) -> f32x4 {
     const int n = n0 + r;
-    if (n >= Hd) return zero4();
-    return load4<VEC>(W, (long)n * K + k, k, K);
-  };
+    return load4<VEC>(W, (long)n * K + k, k, K, n < Hd);
+  });
 
   WavePos<TL> w;
   f32x16 acc[TL::TM][TL::TN];
@@ -155,29 +154,70 @@ __global__ __launch_bounds__(kThreads) void k_proj_fwd(const float* __restrict__
   tile_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
     const long row = m0 + mm;
     const int n = n0 + nn;
-    if (row < rows && n < Hd) {
-      const float y = fmaxf(v + bias[n], 0.f);
-      h[row * Hd + n] = y;
-      const int t = (int)(row % T);
-      if (t == T - 1) h_n[(row / T) * Hd + n] = y;
-    }
+    if (row < rows && n < Hd) h[row * Hd + n] = fmaxf(v + bias[n], 0.f);
   });
+  // h_n: the last frame of every utterance that ends inside this row tile
+  const long tile_end = min((long)rows, (long)m0 + TL::BM);
+  for (long rl = ((long)m0 / T) * T + T - 1; rl < tile_end; rl += T) {
+    const int ml = (int)(rl - m0);
+    tile_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
+      const int n = n0 + nn;
+      if (mm == ml && n < Hd) h_n[(rl / T) * Hd + n] = fmaxf(v + bias[n], 0.f);
+    });
+  }
 }
 
-// gz[row][n] = (h > 0) ? gh (+ gh_n on the last frame) : 0, four n at once
+// gz[row][n] = (h > 0) ? gh (+ gh_n on the last frame) : 0, four n at once.
+// fetch issues the loads of h, gh (and gh_n); the masking runs in finish.
 template <bool VEC>
-__device__ __forceinline__ f32x4 load_gz4(const float* __restrict__ h, const float* __restrict__ gh,
-                                          const float* __restrict__ gh_n, long row, int n, int T, int Hd) {
-  const f32x4 hv = load4<VEC>(h, row * Hd + n, n, Hd);
-  f32x4 g = gh ? load4<VEC>(gh, row * Hd + n, n, Hd) : zero4();
-  if (gh_n && (int)(row % T) == T - 1) {
-    const f32x4 gl = load4<VEC>(gh_n, (row / T) * Hd + n, n, Hd);
-    g += gl;
+struct GzSource {
+  const float* __restrict__ h;
+  const float* __restrict__ gh;
+  const float* __restrict__ gh_n;
+  int T, Hd;
+  struct raw_t {
+    f32x4 h, g, gl;
+  };
+  __device__ __forceinline__ raw_t fetch_at(long row, int n, bool ok) const {
+    raw_t r;
+    r.h = load4<VEC>(h, row * Hd + n, n, Hd, ok);
+    r.g = gh ? load4<VEC>(gh, row * Hd + n, n, Hd, ok) : zero4();
+    r.gl = zero4();
+    if (gh_n) {  // (uniform) the last frame also receives the gradient of h_n
+      const unsigned b = (unsigned)row / (unsigned)T;
+      const bool last = (unsigned)row - b * (unsigned)T == (unsigned)(T - 1);
+      r.gl = load4<VEC>(gh_n, (long)b * Hd + n, n, Hd, ok && last);
+    }
+    return r;
   }
+  __device__ __forceinline__ f32x4 finish(const raw_t& r) const {
+    f32x4 g = r.g + r.gl;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) g[j] = hv[j] > 0.f ? g[j] : 0.f;
-  return g;
-}
+    for (int j = 0; j < 4; ++j) g[j] = r.h[j] > 0.f ? g[j] : 0.f;
+    return g;
+  }
+};
+
+// A operand of the data gradient: tile row = frame, k = hidden unit
+template <bool VEC>
+struct GzRowsLoad {
+  GzSource<VEC> src;
+  long m0;
+  int rows;
+  typedef typename GzSource<VEC>::raw_t raw_t;
+  __device__ __forceinline__ raw_t fetch(int r, int k) const { return src.fetch_at(m0 + r, k, m0 + r < rows); }
+  __device__ __forceinline__ f32x4 finish(const raw_t& v) const { return src.finish(v); }
+};
+
+// A operand of the weight gradient: tile row = hidden unit (4 consecutive), k = frame
+template <bool VEC>
+struct GzColsLoad {
+  GzSource<VEC> src;
+  int n0, kend;
+  typedef typename GzSource<VEC>::raw_t raw_t;
+  __device__ __forceinline__ raw_t fetch(int r, int k) const { return src.fetch_at((long)k, n0 + r, k < kend); }
+  __device__ __forceinline__ f32x4 finish(const raw_t& v) const { return src.finish(v); }
+};
 
 // ---------------------------------------------------------------------------
 // out[row][j - j_begin] = sum_n gz[row][n] W_h[n][j]  (+ ga[row] * w_u[j - j_begin])
@@ -201,17 +241,12 @@ __global__ __launch_bounds__(kThreads) void k_dgrad(const float* __restrict__ h,
   const int n0 = blockIdx.x * TL::BN;
   const int m0 = blockIdx.y * TL::BM;
 
-  auto la = [=](int r, int k) -> f32x4 {
-    const long row = m0 + r;
-    if (row >= rows) return zero4();
-    return load_gz4<VEC>(h, gh, gh_n, row, k, T, Hd);
-  };
+  const GzRowsLoad<VEC> la{{h, gh, gh_n, T, Hd}, (long)m0, rows};
   // B[k = hidden index][j]: W_h rows are contiguous along j -> NC layout
-  auto lb = [=](int r, int k) -> f32x4 {
-    if (k >= Hd) return zero4();
+  auto lb = plain_load([=](int r, int k) -> f32x4 {
     const int j = n0 + r;
-    return load4<VEC>(W, (long)k * ldw + j_begin + j, j, ncols);
-  };
+    return load4<VEC>(W, (long)k * ldw + j_begin + j, j, ncols, k < Hd);
+  });
 
   WavePos<TL> w;
   f32x16 acc[TL::TM][TL::TN];
@@ -252,19 +287,16 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(const float* __restrict__ h,
   const long slab_stride = (long)Hd * MD + Hd;
   float* slab = slabs + blockIdx.z * slab_stride;
 
-  auto la = [=](int r, int k) -> f32x4 {
-    if (k >= kend) return zero4();
-    return load_gz4<VEC>(h, gh, gh_n, (long)k, n0 + r, T, Hd);
-  };
-  auto lb = [=](int r, int k) -> f32x4 {
-    if (k >= kend) return zero4();
+  const GzColsLoad<VEC> la{{h, gh, gh_n, T, Hd}, n0, kend};
+  auto lb = plain_load([=](int r, int k) -> f32x4 {
     const long row = k;
     const int j = j0 + r;
     if (VEC) {
-      if (j < M) return *reinterpret_cast<const f32x4*>(m + row * M + j);
-      if (j < MD) return *reinterpret_cast<const f32x4*>(x + row * D + (j - M));
-      return zero4();
+      const float* p = j < M ? m + row * M + j : x + row * D + (j - M);
+      p = (k < kend && j < MD) ? p : reinterpret_cast<const float*>(kZeroBytes);
+      return *reinterpret_cast<const f32x4*>(p);
     } else {
+      if (k >= kend) return zero4();
       f32x4 v;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -273,7 +305,7 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(const float* __restrict__ h,
       }
       return v;
     }
-  };
+  });
 
   WavePos<TL> w;
   f32x16 acc[TL::TM][TL::TN];
@@ -283,7 +315,8 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(const float* __restrict__ h,
   // staged A tile (LDS image [k][n]) by the workgroups of the first j tile
   float* As = smem;
   float* Bs = smem + TL::A_FLOATS;
-  f32x4 ra[TL::A_VECS], rb[TL::B_VECS];
+  typename decltype(la)::raw_t ra[TL::A_VECS];
+  typename decltype(lb)::raw_t rb[TL::B_VECS];
   float colsum = 0.f;
   const bool do_bias = blockIdx.x == 0 && threadIdx.x < TL::BM;
   if (kbeg < kend) {
@@ -291,8 +324,8 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(const float* __restrict__ h,
     tile_fetch<TL::BN, TL::BK, TL::BLAY>(rb, lb, kbeg);
   }
   for (int k0 = kbeg; k0 < kend; k0 += TL::BK) {
-    tile_store<TL::BM, TL::BK, TL::ALAY>(As, ra);
-    tile_store<TL::BN, TL::BK, TL::BLAY>(Bs, rb);
+    tile_store<TL::BM, TL::BK, TL::ALAY>(As, ra, la);
+    tile_store<TL::BN, TL::BK, TL::BLAY>(Bs, rb, lb);
     __syncthreads();
     if (k0 + TL::BK < kend) {
       tile_fetch<TL::BM, TL::BK, TL::ALAY>(ra, la, k0 + TL::BK);
@@ -340,19 +373,17 @@ __global__ __launch_bounds__(kThreads) void k_conv_bwd(const float* __restrict__
   for (int s = threadIdx.x; s < send; s += kThreads) gu_acc[s] = 0.f;
   // (the first barrier inside gemm_tile orders this against the atomics)
 
-  auto la = [=](int r, int k) -> f32x4 {
+  auto la = plain_load([=](int r, int k) -> f32x4 {
     const int t = t0 + r;
-    if (t >= T) return zero4();
-    return load4<VEC>(gmb, (long)t * M + k, k, M);
-  };
+    return load4<VEC>(gmb, (long)t * M + k, k, M, t < T);
+  });
 
   WavePos<TL> w;
   for (int tau0 = 0; tau0 < send; tau0 += TL::BN) {
-    auto lb = [=](int r, int k) -> f32x4 {
-      if (k >= M) return zero4();
+    auto lb = plain_load([=](int r, int k) -> f32x4 {
       const int tau = tau0 + r;
-      return load4<VEC>(H, (long)k * ldH + tau, tau, T);
-    };
+      return load4<VEC>(H, (long)k * ldH + tau, tau, T, k < M);
+    });
     f32x16 acc[TL::TM][TL::TN];
     tile_zero<TL>(acc);
     gemm_tile<TL>(smem, acc, la, lb, 0, M, w);

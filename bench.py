@@ -40,24 +40,31 @@ def parse_args():
     ap.add_argument("--memory", type=int, default=192)
     ap.add_argument("--theta", type=float, default=1000.0)
     ap.add_argument("--conv", default="auto", choices=["auto", "toeplitz", "fft"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"],
+                    help="activation / MFMA operand type (fp32 accumulation either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
 
 def kernel_work(name, B, T, D, M, Hd, s=4):
-    """Algorithmic (flops, bytes, bound) of a kernel's launches in ONE layer's forward+backward."""
+    """Algorithmic (flops, HBM bytes) of a kernel's launches in ONE layer's forward+backward.
+
+    Bytes are what the kernel's contract makes it move at least once: its inputs read once, its
+    outputs written once (s = bytes per activation element; parameters, u, gu, H are fp32)."""
+    name = name.replace("_bf16", "")
     rows = B * T
     MD = M + D
     wbytes = Hd * MD * s
     table = {
-        "k_proj_fwd": (2.0 * rows * MD * Hd, rows * (MD + Hd) * s + wbytes, "mfma"),
-        "k_dgrad": (2.0 * rows * MD * Hd, rows * (2 * Hd + MD) * s + wbytes, "mfma"),
-        "k_wgrad": (2.0 * rows * MD * Hd, rows * (2 * Hd + MD) * s + wbytes, "mfma"),
-        "k_conv_fwd": (1.0 * B * T * (T + 1) * M, rows * (M + 1) * s + M * T * 4, "mfma"),
-        "k_conv_bwd": (1.0 * B * T * (T + 1) * M, rows * (M + 1) * s + M * T * 4, "mfma"),
-        "k_encode_fwd": (2.0 * rows * D, rows * (D + 1) * s, "hbm"),
-        "k_encode_bwd": (4.0 * rows * D, rows * (3 * D + 1) * s, "hbm"),
+        "k_proj_fwd": (2.0 * rows * MD * Hd, rows * (MD + Hd) * s + wbytes),
+        # two launches: (h, gh) -> gm and (h, gh) -> gx
+        "k_dgrad": (2.0 * rows * MD * Hd, rows * (4 * Hd + MD) * s + wbytes),
+        "k_wgrad": (2.0 * rows * MD * Hd, rows * (2 * Hd + MD) * s + Hd * MD * 4),
+        "k_conv_fwd": (1.0 * B * T * (T + 1) * M, rows * M * s + rows * 4 + M * T * s),
+        "k_conv_bwd": (1.0 * B * T * (T + 1) * M, rows * M * s + rows * 4 + M * T * s),
+        "k_encode_fwd": (2.0 * rows * D, rows * D * s + rows * 4),
+        "k_encode_bwd": (2.0 * rows * D, rows * D * s + rows * 4),
     }
     return table.get(name)
 
@@ -137,8 +144,10 @@ def main():
         layers.append(l.to(dev))
     buckets = GradBuckets([list(l.parameters()) for l in reversed(layers)])
     g = torch.Generator(device=dev).manual_seed(1234 + 2 + rank)  # each rank its own utterances
-    x = torch.randn(B, T, D, device=dev, generator=g).requires_grad_(True)
-    gy = torch.randn(B, T, Hd, device=dev, generator=g)
+    tdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    esize = 2 if args.dtype == "bf16" else 4
+    x = torch.randn(B, T, D, device=dev, generator=g).to(tdt).requires_grad_(True)
+    gy = torch.randn(B, T, Hd, device=dev, generator=g).to(tdt)
 
     def step():
         buckets.zero_grad()
@@ -190,13 +199,17 @@ def main():
                           "total_ms_per_step": v[0] / min(args.steps, 10)} for k, v in kern.items()}
         dom = max(per_kernel, key=lambda k: per_kernel[k]["total_ms_per_step"]) if per_kernel else None
         roofline = None
-        if dom and kernel_work(dom, B, T, D, M, Hd):
-            flops, nbytes, bound = kernel_work(dom, B, T, D, M, Hd)
+        if dom and kernel_work(dom, B, T, D, M, Hd, esize):
+            flops, nbytes = kernel_work(dom, B, T, D, M, Hd, esize)
+            # which roof is lower for this kernel's algorithmic work, at the spec peaks
+            t_hbm = nbytes / (HBM_PEAK_GBS * 1e9)
+            t_mfma = flops / (MFMA_PEAK_TFLOPS[args.dtype] * 1e12)
+            bound = "hbm" if t_hbm >= t_mfma else "mfma"
             per_layer = per_kernel[dom]["launches_per_step"] / args.layers  # launches per layer pass
             flops, nbytes = flops / per_layer, nbytes / per_layer  # per launch, like the duration
             dur_s = per_kernel[dom]["avg_us"] * 1e-6
             if bound == "mfma":
-                achieved, peak, unit = flops / dur_s / 1e12, MFMA_PEAK_TFLOPS["f32"], "TFLOP/s"
+                achieved, peak, unit = flops / dur_s / 1e12, MFMA_PEAK_TFLOPS[args.dtype], "TFLOP/s"
             else:
                 achieved, peak, unit = nbytes / dur_s / 1e9, HBM_PEAK_GBS, "GB/s"
             traffic = None
@@ -206,8 +219,8 @@ def main():
             roofline = {"kernel": dom, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
                         "frac": achieved / peak, "traffic": traffic, "avg_us": per_kernel[dom]["avg_us"],
                         "algorithmic_flops": flops, "algorithmic_bytes": nbytes}
-        # whole-step view against the layer's algorithmic HBM bytes: (3D+3Hd)*4 B per frame and layer
-        layer_bytes = args.layers * B * T * (3 * D + 3 * Hd) * 4
+        # whole-step view against the layer's algorithmic HBM bytes: (3D+3Hd)*elsize B per frame and layer
+        layer_bytes = args.layers * B * T * (3 * D + 3 * Hd) * esize
         t_kern = sum(v["total_ms_per_step"] for v in per_kernel.values()) * 1e-3
         out = {
             "metric": "LMU encoder fwd+bwd frames/sec",
@@ -220,11 +233,12 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {
                 "workload": f"{args.layers} stacked LMUFFT layers (input {D}, hidden {Hd}, memory {M}, theta "
-                            f"{args.theta:g}, seq_len {T}) fwd+bwd, batch {B} per GPU, fp32, conv={args.conv}; "
+                            f"{args.theta:g}, seq_len {T}) fwd+bwd, batch {B} per GPU, {args.dtype} activations with fp32 "
+                            f"accumulation and fp32 parameters, conv={args.conv}; "
                             "BASELINE config 2 layer shape",
                 "batch_per_gpu": B, "frames": T, "layers": args.layers, "parallelism": f"dp{world}",
             },
