@@ -65,6 +65,10 @@ def _load():
     lib.lmufft_hprep_bytes.argtypes = [sp]
     lib.lmufft_hprep_bf16.restype = ci
     lib.lmufft_hprep_bf16.argtypes = [sp, vp, vp, vp]
+    lib.lmufft_wprep_bytes.restype = sz
+    lib.lmufft_wprep_bytes.argtypes = [sp]
+    lib.lmufft_wprep_bf16.restype = ci
+    lib.lmufft_wprep_bf16.argtypes = [sp, vp, vp, vp]
     lib.lmufft_forward_bf16.restype = ci
     lib.lmufft_forward_bf16.argtypes = [sp] + [vp] * 10 + [ci, vp, sz, vp]
     lib.lmufft_backward_bf16.restype = ci
@@ -99,6 +103,8 @@ EXPORTS = (
     "lmufft_conv_backward_f32",
     "lmufft_hprep_bytes",
     "lmufft_hprep_bf16",
+    "lmufft_wprep_bytes",
+    "lmufft_wprep_bf16",
     "lmufft_forward_bf16",
     "lmufft_backward_bf16",
     "lmufft_profile_enable",

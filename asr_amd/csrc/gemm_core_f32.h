@@ -61,7 +61,7 @@ __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 // here instead of being zeroed after the fact.  A select on a loaded VALUE
 // makes the compiler wait for the load right where it was issued; a select on
 // the ADDRESS lets every staging load of a tile stay in flight behind the MFMAs.
-static __device__ __attribute__((aligned(32))) const unsigned int kZeroBytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+static __device__ __attribute__((aligned(32))) unsigned int kZeroBytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 // base[idx .. idx+3]; elements at or beyond `limit` (position pos + j) and the
 // whole vector when !ok read as zero.  With VEC the caller guarantees

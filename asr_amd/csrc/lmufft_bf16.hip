@@ -543,7 +543,7 @@ __global__ __launch_bounds__(kThreads) void k_encode_bwd_bf16(const float* __res
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-constexpr int kEncRowsPerBlockB = 32;
+constexpr int kEncRowsPerBlockB = 128;
 
 struct HprepLayout {
   int ldHb, ldHT;
@@ -559,9 +559,24 @@ static HprepLayout hprep_layout(int M, int ldH) {
   return l;
 }
 
+struct WprepLayout {
+  int ldW, ldWT;
+  size_t off_Wb, off_WbT, total;
+};
+static WprepLayout wprep_layout(const lmufft_shape& s) {
+  WprepLayout l;
+  const int MD = s.M + s.D;
+  l.ldW = up8(MD);
+  l.ldWT = up8(s.Hd);
+  l.off_Wb = 0;
+  l.off_WbT = align256b(sizeof(bf16_t) * (size_t)s.Hd * l.ldW);
+  l.total = l.off_WbT + align256b(sizeof(bf16_t) * (size_t)MD * l.ldWT);
+  return l;
+}
+
 struct BwdPlanB {
-  int S, rps, ntt, enc_blocks, ldWT;
-  size_t off_WbT, off_wslab, off_gupart, off_ga, off_encpart, total;
+  int S, rps, ntt, enc_blocks;
+  size_t off_wslab, off_gupart, off_ga, off_encpart, total;
 };
 static BwdPlanB plan_backward_b(const lmufft_shape& s) {
   BwdPlanB p;
@@ -575,10 +590,7 @@ static BwdPlanB plan_backward_b(const lmufft_shape& s) {
   p.rps = rps;
   p.ntt = cdivb(s.T, ConvBwdTileB::BM);
   p.enc_blocks = cdivb(rows, kEncRowsPerBlockB);
-  p.ldWT = up8(s.Hd);
   size_t off = 0;
-  p.off_WbT = off;
-  off += align256b(sizeof(bf16_t) * (size_t)MD * p.ldWT);
   p.off_wslab = off;
   off += align256b(sizeof(float) * (size_t)p.S * ((size_t)s.Hd * MD + s.Hd));
   p.off_gupart = off;
@@ -591,9 +603,7 @@ static BwdPlanB plan_backward_b(const lmufft_shape& s) {
   return p;
 }
 
-size_t forward_workspace_bf16(const lmufft_shape& s) {
-  return align256b(sizeof(bf16_t) * (size_t)s.Hd * up8(s.M + s.D));
-}
+size_t forward_workspace_bf16(const lmufft_shape&) { return 256; }
 size_t backward_workspace_bf16(const lmufft_shape& s) { return plan_backward_b(s).total; }
 
 #define PROFB(name) ProfScope prof_scope_(name, st)
@@ -643,36 +653,52 @@ int lmufft_hprep_bf16(const lmufft_shape* s, const float* H, void* hprep, void* 
   return 0;
 }
 
-int lmufft_forward_bf16(const lmufft_shape* s, const void* x_, const float* w_u, const float* b_u,
-                        const float* W_h, const float* b_h, const void* hprep, float* u, void* m_, void* h_,
-                        void* h_n_, int conv_algo, void* workspace, size_t workspace_bytes, void* stream) {
+size_t lmufft_wprep_bytes(const lmufft_shape* s) {
+  if (check_shape_b(s)) return 0;
+  return wprep_layout(*s).total;
+}
+
+int lmufft_wprep_bf16(const lmufft_shape* s, const float* W_h, void* wprep, void* stream) {
   if (int rc = check_shape_b(s)) return rc;
-  if (!x_ || !w_u || !b_u || !W_h || !b_h || !hprep || !u || !m_ || !h_ || !h_n_)
+  if (!W_h || !wprep) return set_error("wprep: NULL pointer");
+  if (!al16(wprep)) return set_error("wprep: buffer must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const WprepLayout l = wprep_layout(*s);
+  const int MD = s->M + s->D;
+  bf16_t* Wb = (bf16_t*)((char*)wprep + l.off_Wb);
+  bf16_t* WbT = (bf16_t*)((char*)wprep + l.off_WbT);
+  const long n = (long)s->Hd * l.ldW + (long)MD * l.ldWT;
+  {
+    PROFB("k_prep_weights");
+    hipLaunchKernelGGL(k_prep_weights, dim3(min(cdivb(n, kThreads), 2048)), dim3(kThreads), 0, st, W_h, Wb, WbT,
+                       s->Hd, MD, l.ldW, l.ldWT);
+  }
+  LAUNCH_CHECKB("k_prep_weights");
+  return 0;
+}
+
+int lmufft_forward_bf16(const lmufft_shape* s, const void* x_, const float* w_u, const float* b_u,
+                        const void* wprep, const float* b_h, const void* hprep, float* u, void* m_, void* h_,
+                        void* h_n_, int conv_algo, void* workspace, size_t workspace_bytes, void* stream) {
+  (void)workspace;
+  (void)workspace_bytes;
+  if (int rc = check_shape_b(s)) return rc;
+  if (!x_ || !w_u || !b_u || !wprep || !b_h || !hprep || !u || !m_ || !h_ || !h_n_)
     return set_error("forward: NULL pointer");
   if (conv_algo != LMUFFT_CONV_AUTO && conv_algo != LMUFFT_CONV_TOEPLITZ)
     return set_error("conv algorithm %d is not available for bf16", conv_algo);
-  const size_t need = forward_workspace_bf16(*s);
-  if (!workspace || workspace_bytes < need)
-    return set_error("forward: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
-  if (!al16(workspace) || !al16(hprep)) return set_error("forward: workspace/hprep must be 16-byte aligned");
+  if (!al16(wprep) || !al16(hprep)) return set_error("forward: wprep/hprep must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const bf16_t* x = (const bf16_t*)x_;
   bf16_t* m = (bf16_t*)m_;
   bf16_t* h = (bf16_t*)h_;
   bf16_t* h_n = (bf16_t*)h_n_;
   const long rows = (long)s->B * s->T;
-  const int MD = s->M + s->D;
-  const int ldW = up8(MD);
-  bf16_t* Wb = (bf16_t*)workspace;
+  const WprepLayout wl = wprep_layout(*s);
+  const int ldW = wl.ldW;
+  const bf16_t* Wb = (const bf16_t*)((const char*)wprep + wl.off_Wb);
   const HprepLayout hl = hprep_layout(s->M, s->ldH);
   const bf16_t* Hb = (const bf16_t*)((const char*)hprep + hl.off_Hb);
-
-  {
-    PROFB("k_prep_weights");
-    hipLaunchKernelGGL(k_prep_weights, dim3(min(cdivb((long)s->Hd * ldW, kThreads), 2048)), dim3(kThreads), 0, st,
-                       W_h, Wb, (bf16_t*)nullptr, s->Hd, MD, ldW, 0);
-  }
-  LAUNCH_CHECKB("k_prep_weights");
   {
     const bool vec = (s->D % 8 == 0) && al16(x) && al16(w_u);
     const dim3 grid(min(cdivb(rows, 4), 4096));
@@ -718,19 +744,20 @@ int lmufft_forward_bf16(const lmufft_shape* s, const void* x_, const float* w_u,
   return 0;
 }
 
-int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u, const float* W_h,
+int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u, const void* wprep,
                          const void* hprep, const float* u, const void* m_, const void* h_, const void* gh_,
                          const void* gh_n_, void* gx_, float* gw_u, float* gb_u, float* gW_h, float* gb_h,
                          void* gm_, int conv_algo, void* workspace, size_t workspace_bytes, void* stream) {
   if (int rc = check_shape_b(s)) return rc;
-  if (!x_ || !w_u || !W_h || !hprep || !u || !m_ || !h_ || !gw_u || !gb_u || !gW_h || !gb_h || !gm_)
+  if (!x_ || !w_u || !wprep || !hprep || !u || !m_ || !h_ || !gw_u || !gb_u || !gW_h || !gb_h || !gm_)
     return set_error("backward: NULL pointer");
   if (conv_algo != LMUFFT_CONV_AUTO && conv_algo != LMUFFT_CONV_TOEPLITZ)
     return set_error("conv algorithm %d is not available for bf16", conv_algo);
   const BwdPlanB p = plan_backward_b(*s);
   if (!workspace || workspace_bytes < p.total)
     return set_error("backward: workspace of %zu bytes needed, %zu given", p.total, workspace_bytes);
-  if (!al16(workspace) || !al16(hprep)) return set_error("backward: workspace/hprep must be 16-byte aligned");
+  if (!al16(workspace) || !al16(hprep) || !al16(wprep))
+    return set_error("backward: workspace/hprep/wprep must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const bf16_t* x = (const bf16_t*)x_;
   const bf16_t* m = (const bf16_t*)m_;
@@ -740,7 +767,8 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
   bf16_t* gx = (bf16_t*)gx_;
   bf16_t* gm = (bf16_t*)gm_;
   char* ws = (char*)workspace;
-  bf16_t* WbT = (bf16_t*)(ws + p.off_WbT);
+  const WprepLayout wl = wprep_layout(*s);
+  const bf16_t* WbT = (const bf16_t*)((const char*)wprep + wl.off_WbT);
   float* wslab = (float*)(ws + p.off_wslab);
   float* gupart = (float*)(ws + p.off_gupart);
   float* ga = (float*)(ws + p.off_ga);
@@ -751,13 +779,6 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
   const bf16_t* HbT = (const bf16_t*)((const char*)hprep + hl.off_HbT);
   const bool vec_h = (s->Hd % 8 == 0) && al16(h) && (!gh || al16(gh)) && (!gh_n || al16(gh_n));
 
-  {
-    PROFB("k_prep_weights");
-    hipLaunchKernelGGL(k_prep_weights, dim3(min(cdivb((long)MD * p.ldWT, kThreads), 2048)), dim3(kThreads), 0, st,
-                       W_h, (bf16_t*)nullptr, WbT, s->Hd, MD, 0, p.ldWT);
-  }
-  LAUNCH_CHECKB("k_prep_weights");
-
   {  // gm = gz W_h[:, :M]
     using TL = DgradMTileB;
     const dim3 grid(cdivb(s->M, TL::BN), cdivb(rows, TL::BM));
@@ -766,10 +787,10 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
       PROFB("k_dgrad_bf16");
       if (vec_h)
         hipLaunchKernelGGL((k_dgrad_bf16<TL, true>), grid, dim3(kThreads), lds, st, h, gh, gh_n, WbT, gm,
-                           (const float*)nullptr, (const float*)nullptr, (int)rows, s->T, s->Hd, p.ldWT, 0, s->M);
+                           (const float*)nullptr, (const float*)nullptr, (int)rows, s->T, s->Hd, wl.ldWT, 0, s->M);
       else
         hipLaunchKernelGGL((k_dgrad_bf16<TL, false>), grid, dim3(kThreads), lds, st, h, gh, gh_n, WbT, gm,
-                           (const float*)nullptr, (const float*)nullptr, (int)rows, s->T, s->Hd, p.ldWT, 0, s->M);
+                           (const float*)nullptr, (const float*)nullptr, (int)rows, s->T, s->Hd, wl.ldWT, 0, s->M);
     }
     LAUNCH_CHECKB("k_dgrad_bf16");
   }
@@ -803,10 +824,10 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
       PROFB("k_dgrad_bf16");
       if (vec_h)
         hipLaunchKernelGGL((k_dgrad_bf16<TL, true>), grid, dim3(kThreads), lds, st, h, gh, gh_n, WbT, gx,
-                           (const float*)ga, w_u, (int)rows, s->T, s->Hd, p.ldWT, s->M, s->D);
+                           (const float*)ga, w_u, (int)rows, s->T, s->Hd, wl.ldWT, s->M, s->D);
       else
         hipLaunchKernelGGL((k_dgrad_bf16<TL, false>), grid, dim3(kThreads), lds, st, h, gh, gh_n, WbT, gx,
-                           (const float*)ga, w_u, (int)rows, s->T, s->Hd, p.ldWT, s->M, s->D);
+                           (const float*)ga, w_u, (int)rows, s->T, s->Hd, wl.ldWT, s->M, s->D);
     }
     LAUNCH_CHECKB("k_dgrad_bf16");
   }

@@ -486,6 +486,41 @@ __global__ __launch_bounds__(kThreads) void k_reduce_slabs(const float* __restri
   }
 }
 
+// Same sum for FEW outputs and MANY slabs (the encoder's weight gradient:
+// D + 1 outputs, one slab per 32 frames): a workgroup owns 32 outputs, its 8
+// thread rows split the slabs; partial sums are combined through LDS in a
+// fixed order, so the result is deterministic.
+__global__ __launch_bounds__(kThreads) void k_reduce_slabs_tall(const float* __restrict__ in, int S, long stride,
+                                                                float* __restrict__ out0, long n0,
+                                                                float* __restrict__ out1, long n1) {
+  __shared__ float red[8][32];
+  const int col = threadIdx.x & 31, part = threadIdx.x >> 5;
+  const long i = blockIdx.x * 32L + col;
+  const long n = n0 + n1;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int k = part;
+    for (; k + 24 < S; k += 32) {
+      s0 += in[(long)k * stride + i];
+      s1 += in[(long)(k + 8) * stride + i];
+      s2 += in[(long)(k + 16) * stride + i];
+      s3 += in[(long)(k + 24) * stride + i];
+    }
+    for (; k < S; k += 8) s0 += in[(long)k * stride + i];
+  }
+  red[part][col] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (part == 0 && i < n) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += red[q][col];
+    if (i < n0)
+      out0[i] = s;
+    else
+      out1[i - n0] = s;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -493,7 +528,7 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 
-constexpr int kEncRowsPerBlock = 32;
+constexpr int kEncRowsPerBlock = 128;
 
 static int wgrad_splits(long rows, int Hd, int MD, int* rows_per_split) {
   const int tiles = cdiv(Hd, WgradTile::BM) * cdiv(MD, WgradTile::BN);
@@ -550,6 +585,15 @@ static int check_shape(const lmufft_shape* s) {
 
 int launch_reduce_slabs(const float* in, int S, long stride, float* out0, long n0, float* out1, long n1,
                         hipStream_t st) {
+  if (n0 + n1 <= 4096 && S >= 64) {  // few outputs, many slabs
+    {
+      PROF("k_reduce_slabs_tall");
+      hipLaunchKernelGGL(k_reduce_slabs_tall, dim3(cdiv(n0 + n1, 32)), dim3(kThreads), 0, st, in, S, stride, out0,
+                         n0, out1, n1);
+    }
+    LAUNCH_CHECK("k_reduce_slabs_tall");
+    return 0;
+  }
   // vector path: every slab row and both outputs stay 16-byte aligned and n0 + n1 is a multiple of 4
   const bool vec = (stride % 4 == 0) && (n0 % 4 == 0) && (n1 % 4 == 0) && aligned16(in) && aligned16(out0) &&
                    aligned16(out1);

@@ -109,12 +109,16 @@ class _LMUFFTFunction(torch.autograd.Function):
             else:
                 if hprep is None:
                     hprep = prepare_impulse_bf16(H)
+                # bf16 copies of W_h (both orientations), made once and reused by the backward
+                wprep = _workspace(_lib.lib.lmufft_wprep_bytes(ctypes.byref(shp)), dev)
+                _lib.check(_lib.lib.lmufft_wprep_bf16(ctypes.byref(shp), _ptr(W_h), _ptr(wprep), _stream(dev)),
+                           "lmufft_wprep_bf16")
                 rc = _lib.lib.lmufft_forward_bf16(
-                    ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(b_u), _ptr(W_h), _ptr(b_h), _ptr(hprep),
+                    ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(b_u), _ptr(wprep), _ptr(b_h), _ptr(hprep),
                     _ptr(u), _ptr(m), _ptr(h), _ptr(h_n), conv_algo, _ptr(ws), ws.numel(), _stream(dev))
                 what = "lmufft_forward_bf16"
         _lib.check(rc, what)
-        ctx.save_for_backward(x, w_u, W_h, H, u, m, h, hprep)
+        ctx.save_for_backward(x, w_u, W_h, H, u, m, h, hprep, wprep if dt != torch.float32 else None)
         ctx.conv_algo = conv_algo
         ctx.shape = (B, T, D, M, Hd, ldH)
         ctx.set_materialize_grads(False)
@@ -122,7 +126,7 @@ class _LMUFFTFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gh, gh_n):
-        x, w_u, W_h, H, u, m, h, hprep = ctx.saved_tensors
+        x, w_u, W_h, H, u, m, h, hprep, wprep = ctx.saved_tensors
         B, T, D, M, Hd, ldH = ctx.shape
         dev = x.device
         dt = x.dtype
@@ -150,7 +154,7 @@ class _LMUFFTFunction(torch.autograd.Function):
                 what = "lmufft_backward_f32"
             else:
                 rc = _lib.lib.lmufft_backward_bf16(
-                    ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(W_h), _ptr(hprep), _ptr(u), _ptr(m), _ptr(h),
+                    ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(wprep), _ptr(hprep), _ptr(u), _ptr(m), _ptr(h),
                     _ptr(gh), _ptr(gh_n), _ptr(gx), _ptr(gw_u), _ptr(gb_u), _ptr(gW_h), _ptr(gb_h), _ptr(gm),
                     ctx.conv_algo, _ptr(ws), ws.numel(), _stream(dev))
                 what = "lmufft_backward_bf16"

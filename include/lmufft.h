@@ -117,18 +117,25 @@ int lmufft_conv_backward_f32(const lmufft_shape* s, const float* gm, const float
  * buffer of the module (src/lmu.py:243-245), so it is prepared once:
  * allocate lmufft_hprep_bytes(s) (M and ldH are read), call lmufft_hprep_bf16,
  * keep the buffer for every later forward/backward with that H.
+ *
+ * `wprep` holds bf16 copies of W_h in both orientations (the forward reads
+ * W_h[n][k], the data gradient its transpose).  W_h changes every optimiser
+ * step, so it is prepared once per step: lmufft_wprep_bf16 before the
+ * forward, the same buffer handed to the backward.
  * ---------------------------------------------------------------------- */
 size_t lmufft_hprep_bytes(const lmufft_shape* s);
 int lmufft_hprep_bf16(const lmufft_shape* s, const float* H, void* hprep, void* stream);
+size_t lmufft_wprep_bytes(const lmufft_shape* s);
+int lmufft_wprep_bf16(const lmufft_shape* s, const float* W_h, void* wprep, void* stream);
 
 int lmufft_forward_bf16(const lmufft_shape* s, const void* x, const float* w_u,
-                        const float* b_u, const float* W_h, const float* b_h,
+                        const float* b_u, const void* wprep, const float* b_h,
                         const void* hprep, float* u, void* m, void* h, void* h_n,
                         int conv_algo, void* workspace, size_t workspace_bytes,
                         void* stream);
 
 int lmufft_backward_bf16(const lmufft_shape* s, const void* x, const float* w_u,
-                         const float* W_h, const void* hprep, const float* u,
+                         const void* wprep, const void* hprep, const float* u,
                          const void* m, const void* h, const void* gh,
                          const void* gh_n, void* gx, float* gw_u, float* gb_u,
                          float* gW_h, float* gb_h, void* gm, int conv_algo,
