@@ -214,16 +214,7 @@ __device__ __forceinline__ void gemm_loop_kc(OA& a, OB& b, f32x16 (&acc)[T::TM][
 
 template <class T, class F>
 __device__ __forceinline__ void tileb_epilogue(const f32x16 (&acc)[T::TM][T::TN], const WavePos<T>& w, F&& f) {
-#pragma unroll
-  for (int tm = 0; tm < T::TM; ++tm)
-#pragma unroll
-    for (int tn = 0; tn < T::TN; ++tn)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int m = w.wm0 + tm * 32 + (i & 3) + 8 * (i >> 2) + 4 * w.hh;
-        const int n = w.wn0 + tn * 32 + w.r;
-        f(m, n, acc[tm][tn][i]);
-      }
+  tile_epilogue<T>(acc, w, f);
 }
 
 }  // namespace lmufft

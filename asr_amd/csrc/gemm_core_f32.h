@@ -218,11 +218,12 @@ __device__ __forceinline__ void gemm_tile(float* smem, f32x16 (&acc)[T::TM][T::T
   }
 }
 
-// f(m, n, value) for every accumulator element; m, n are tile-local.
-// C/D map of v_mfma_f32_32x32x2_f32: column = lane & 31,
+// f(tm, tn, i, m, n, value) for every accumulator element; m, n are tile-local,
+// (tm, tn, i) identify the MFMA tile and accumulator register.
+// C/D map of the 32x32 MFMAs: column = lane & 31,
 // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 template <class T, class F>
-__device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[T::TM][T::TN], const WavePos<T>& w, F&& f) {
+__device__ __forceinline__ void tile_epilogue_ix(const f32x16 (&acc)[T::TM][T::TN], const WavePos<T>& w, F&& f) {
 #pragma unroll
   for (int tm = 0; tm < T::TM; ++tm)
 #pragma unroll
@@ -231,8 +232,30 @@ __device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[T::TM][T::TN],
       for (int i = 0; i < 16; ++i) {
         const int m = w.wm0 + tm * 32 + (i & 3) + 8 * (i >> 2) + 4 * w.hh;
         const int n = w.wn0 + tn * 32 + w.r;
-        f(m, n, acc[tm][tn][i]);
+        f(tm, tn, i, m, n, acc[tm][tn][i]);
       }
+}
+
+// f(m, n, value) for every accumulator element.
+template <class T, class F>
+__device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[T::TM][T::TN], const WavePos<T>& w, F&& f) {
+  tile_epilogue_ix<T>(acc, w, [&](int, int, int, int m, int n, float v) { f(m, n, v); });
+}
+
+// Per-column / per-row epilogue operands (bias, rank-1 terms) are loaded into
+// registers in one batch BEFORE the epilogue; loading them per accumulator
+// element makes 16*TM*TN dependent global loads, each waited for in turn.
+template <class T, class G>
+__device__ __forceinline__ void preload_cols(float (&c)[T::TN], const WavePos<T>& w, G&& g) {
+#pragma unroll
+  for (int tn = 0; tn < T::TN; ++tn) c[tn] = g(w.wn0 + tn * 32 + w.r);
+}
+template <class T, class G>
+__device__ __forceinline__ void preload_rows(float (&r)[T::TM][16], const WavePos<T>& w, G&& g) {
+#pragma unroll
+  for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[tm][i] = g(w.wm0 + tm * 32 + (i & 3) + 8 * (i >> 2) + 4 * w.hh);
 }
 
 }  // namespace lmufft

@@ -1,0 +1,123 @@
+// bf16 GEMM main loop with direct global->LDS staging (global_load_lds_dwordx4)
+// for gfx950, used by the kernels whose operands are plain k-contiguous rows.
+//
+// Why: with register staging a k-tile costs 8 global loads + 8 ds_write per
+// thread and 32 VGPRs, which caps the kernel at 2 waves per SIMD and leaves the
+// loads' latency exposed.  The LDS-DMA form needs no staging registers and no
+// ds_write; the loads of k-tile i+1 are in flight while tile i is multiplied.
+//
+// LDS image of one operand stage: [R rows][64 bf16] = R x 128 bytes, unpadded
+// (a wave-instruction writes 64 lanes x 16 B = 1 KiB = 8 whole rows, so rows
+// cannot be padded).  Bank conflicts are removed by an XOR swizzle instead:
+// the 16-byte chunk d (0..7) of row r lives at chunk position d ^ ((r >> 1) & 7).
+// The LDS-DMA destination is linear in the lane index, so the swizzle is
+// applied to the per-lane SOURCE address (lane -> row r, position c, loads data
+// chunk c ^ ((r >> 1) & 7)) and again on the fragment read.  For the 16 rows
+// that one ds_read_b128 lane group touches, (r & 1, (r >> 1) & 7) takes 16
+// distinct values: conflict-free.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "gemm_core_bf16.h"
+
+namespace lmufft {
+
+constexpr int kGldsBK = 64;           // bf16 elements per k-tile
+constexpr int kGldsRowBytes = 128;    // = kGldsBK * 2
+
+// Src: const bf16_t* operator()(int r, int k) -> address of the 8 consecutive
+// elements k..k+7 of tile row r, or the zero line when (r, k) is outside the operand.
+template <int R, class Src>
+struct GldsOperand {
+  static_assert(R % 32 == 0, "four waves stage eight rows per instruction");
+  static constexpr int STAGE_BYTES = R * kGldsRowBytes;
+  static constexpr int NI = R / 32;  // wave-instructions per wave and stage
+  unsigned char* base;               // LDS, two stages back to back
+  const Src& src;
+  __device__ __forceinline__ GldsOperand(unsigned char* b, const Src& s) : base(b), src(s) {}
+
+  __device__ __forceinline__ void issue(int stage, int k0) const {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int r0 = wave * (R / 4) + 8 * i;  // wave-uniform
+      const int r = r0 + (lane >> 3);
+      const int d = (lane & 7) ^ ((r >> 1) & 7);
+      const bf16_t* p = src(r, k0 + 8 * d);
+      unsigned char* dst = base + stage * STAGE_BYTES + r0 * kGldsRowBytes;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  }
+  __device__ __forceinline__ bf16x8 frag(int stage, int row, int kl, int hh) const {
+    const int d = (kl >> 3) + hh;
+    const unsigned char* a = base + stage * STAGE_BYTES + row * kGldsRowBytes + ((d ^ ((row >> 1) & 7)) << 4);
+    return *reinterpret_cast<const bf16x8*>(a);
+  }
+};
+
+// acc += A[:, kbeg:kend] B[kbeg:kend, :]; kbeg a multiple of 8.  Two LDS stages.
+// All threads of the workgroup must call it with the same bounds.
+template <class T, class OA, class OB>
+__device__ __forceinline__ void gemm_loop_glds(const OA& a, const OB& b, f32x16 (&acc)[T::TM][T::TN], int kbeg,
+                                               int kend, const WavePos<T>& w) {
+  static_assert(T::BK == kGldsBK, "k-tile of 64");
+  if (kbeg < kend) {
+    a.issue(0, kbeg);
+    b.issue(0, kbeg);
+  }
+  int stage = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += kGldsBK, stage ^= 1) {
+    // this wave's LDS-DMA writes have landed; after the barrier everybody's have,
+    // and everybody has finished reading the other stage
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (k0 + kGldsBK < kend) {
+      a.issue(stage ^ 1, k0 + kGldsBK);
+      b.issue(stage ^ 1, k0 + kGldsBK);
+    }
+#pragma unroll
+    for (int kl = 0; kl < kGldsBK; kl += 16) {
+      bf16x8 af[T::TM], bfr[T::TN];
+#pragma unroll
+      for (int tm = 0; tm < T::TM; ++tm) af[tm] = a.frag(stage, w.wm0 + tm * 32 + w.r, kl, w.hh);
+#pragma unroll
+      for (int tn = 0; tn < T::TN; ++tn) bfr[tn] = b.frag(stage, w.wn0 + tn * 32 + w.r, kl, w.hh);
+#pragma unroll
+      for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < T::TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bfr[tn], acc[tm][tn], 0, 0, 0);
+    }
+  }
+  __syncthreads();  // the stages may be reused (epilogue staging) after this
+}
+
+// Writes the workgroup's accumulator tile as bf16 rows through LDS so that HBM
+// sees 16-byte stores of whole row segments instead of 2-byte column stores.
+//   value(tm, tn, i, m, n, v)  -> float to store for tile-local (m, n)
+//   out[(row0 + m) * ld + col0 + n], rows < row_limit, cols < col_limit,
+//   col_limit % 8 == 0 and 16-byte aligned rows (the caller checks).
+// `lds` needs BM * (BN + 8) * 2 bytes.  Returns with the tile still in LDS
+// (image [BM][BN + 8]) so that callers can copy rows out of it again.
+template <class T, class V>
+__device__ __forceinline__ void store_tile_bf16(const f32x16 (&acc)[T::TM][T::TN], const WavePos<T>& w,
+                                                bf16_t* lds, bf16_t* __restrict__ out, long ld, long row0,
+                                                int col0, long row_limit, int col_limit, V&& value) {
+  constexpr int LDT = T::BN + 8;
+  tile_epilogue_ix<T>(acc, w, [&](int tm, int tn, int i, int m, int n, float v) {
+    lds[m * LDT + n] = (bf16_t)value(tm, tn, i, m, n, v);
+  });
+  __syncthreads();
+  constexpr int CH = T::BN / 8;  // 16-byte chunks per tile row
+  for (int idx = threadIdx.x; idx < T::BM * CH; idx += kThreads) {
+    const int m = idx / CH, c = idx % CH;
+    const long row = row0 + m;
+    const int col = col0 + c * 8;
+    if (row < row_limit && col < col_limit)
+      *reinterpret_cast<bf16x8*>(out + row * ld + col) = *reinterpret_cast<const bf16x8*>(&lds[m * LDT + c * 8]);
+  }
+}
+
+}  // namespace lmufft

@@ -13,6 +13,7 @@
 #include <stdint.h>
 
 #include "gemm_core_bf16.h"
+#include "gemm_glds_bf16.h"
 #include "lmufft.h"
 #include "lmufft_internal.h"
 
@@ -216,96 +217,175 @@ __global__ __launch_bounds__(kThreads) void k_proj_fwd_bf16(const bf16_t* __rest
   tileb_zero<TL>(acc);
   gemm_loop_kc<TL>(oa, ob, acc, 0, K, w);
 
-  tileb_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
+  float bcol[TL::TN];
+  preload_cols<TL>(bcol, w, [&](int nn) { return n0 + nn < Hd ? bias[n0 + nn] : 0.f; });
+  tile_epilogue_ix<TL>(acc, w, [&](int, int tn, int, int mm, int nn, float v) {
     const long row = m0 + mm;
     const int n = n0 + nn;
-    if (row < rows && n < Hd) h[row * Hd + n] = (bf16_t)fmaxf(v + bias[n], 0.f);
+    if (row < rows && n < Hd) h[row * Hd + n] = (bf16_t)fmaxf(v + bcol[tn], 0.f);
   });
   // h_n: the last frame of every utterance that ends inside this row tile
   const long tile_end = min((long)rows, (long)m0 + TL::BM);
   for (long rl = ((long)m0 / T) * T + T - 1; rl < tile_end; rl += T) {
     const int ml = (int)(rl - m0);
-    tileb_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
+    tile_epilogue_ix<TL>(acc, w, [&](int, int tn, int, int mm, int nn, float v) {
       const int n = n0 + nn;
-      if (mm == ml && n < Hd) h_n[(rl / T) * Hd + n] = (bf16_t)fmaxf(v + bias[n], 0.f);
+      if (mm == ml && n < Hd) h_n[(rl / T) * Hd + n] = (bf16_t)fmaxf(v + bcol[tn], 0.f);
     });
   }
 }
 
-// gz[row][n..n+7] = (h > 0) ? gh (+ gh_n on the last frame) : 0.
-// fetch issues the loads of h, gh (and gh_n); the masking runs in finish.
-template <bool VEC>
-struct GzSourceB {
-  const bf16_t* __restrict__ h;
-  const bf16_t* __restrict__ gh;
-  const bf16_t* __restrict__ gh_n;
-  int T, Hd;
-  struct raw_t {
-    bf16x8 h, g, gl;
+// XCD-aware tile order for grids of (n tiles) x (row tiles, rounded up to a
+// multiple of 8): workgroups are dealt to the 8 XCDs round-robin by linear id,
+// so the n tiles that share one row tile (and therefore its A operand) are
+// given ids that are equal modulo 8 -- they run on one XCD and the A rows are
+// fetched from HBM into one L2 only.  A speed choice, never needed for correctness.
+__device__ __forceinline__ void xcd_tile_order(int& ntile, int& mtile) {
+  const int ntn = gridDim.x;
+  const int L = blockIdx.y * ntn + blockIdx.x;
+  const int group = L / (8 * ntn), rem = L % (8 * ntn);
+  mtile = group * 8 + (rem & 7);
+  ntile = rem >> 3;
+}
+
+// Same GEMM with LDS-DMA staging and 16-byte stores; needs M % 8 == D % 8 == Hd % 8 == 0.
+__global__ __launch_bounds__(kThreads) void k_proj_fwd_glds_bf16(const bf16_t* __restrict__ m,
+                                                                 const bf16_t* __restrict__ x,
+                                                                 const bf16_t* __restrict__ Wb,
+                                                                 const float* __restrict__ bias,
+                                                                 bf16_t* __restrict__ h, bf16_t* __restrict__ h_n,
+                                                                 int rows, int T, int M, int D, int Hd, int ldW) {
+  using TL = ProjTileB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  int ntile, mtile;
+  xcd_tile_order(ntile, mtile);
+  const int n0 = ntile * TL::BN;
+  const long m0 = (long)mtile * TL::BM;
+  if (m0 >= rows) return;  // (whole workgroup) padding tile of the XCD-aware order
+  const int K = M + D;
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(kZeroBytes);
+
+  auto sa = [=](int r, int k) -> const bf16_t* {
+    const long row = m0 + r;
+    const bf16_t* p = k < M ? m + row * M + k : x + row * D + (k - M);
+    return (row < rows && k < K) ? p : zero;
   };
-  __device__ __forceinline__ raw_t fetch_at(long row, int n, bool ok) const {
-    raw_t r;
-    r.h = bload8<VEC>(h, row * Hd + n, n, Hd, ok);
-    r.g = gh ? bload8<VEC>(gh, row * Hd + n, n, Hd, ok) : bzero8();
-    r.gl = bzero8();
-    if (gh_n) {  // (uniform) the last frame also receives the gradient of h_n
-      const unsigned b = (unsigned)row / (unsigned)T;
-      const bool last = (unsigned)row - b * (unsigned)T == (unsigned)(T - 1);
-      r.gl = bload8<VEC>(gh_n, (long)b * Hd + n, n, Hd, ok && last);
-    }
-    return r;
-  }
-  __device__ __forceinline__ bf16x8 finish(const raw_t& r) const {
-    bf16x8 g = r.g;
-    if (gh_n) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) g[j] = (bf16_t)((float)g[j] + (float)r.gl[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) g[j] = (float)r.h[j] > 0.f ? g[j] : (bf16_t)0.f;
-    return g;
-  }
-};
+  auto sb = [=](int r, int k) -> const bf16_t* {
+    const int n = n0 + r;
+    return (n < Hd && k < ldW) ? Wb + (long)n * ldW + k : zero;
+  };
+  typedef GldsOperand<TL::BM, decltype(sa)> OpA;
+  typedef GldsOperand<TL::BN, decltype(sb)> OpB;
+  OpA oa(smem_raw, sa);
+  OpB ob(smem_raw + 2 * OpA::STAGE_BYTES, sb);
 
-// A operand of the data gradient: tile row = frame, k = hidden unit
-template <bool VEC>
-struct GzRowsLoadB {
-  GzSourceB<VEC> src;
-  long m0;
-  int rows;
-  typedef typename GzSourceB<VEC>::raw_t raw_t;
-  __device__ __forceinline__ raw_t fetch(int r, int k) const { return src.fetch_at(m0 + r, k, m0 + r < rows); }
-  __device__ __forceinline__ bf16x8 finish(const raw_t& v) const { return src.finish(v); }
-};
+  WavePos<TL> w;
+  f32x16 acc[TL::TM][TL::TN];
+  tileb_zero<TL>(acc);
+  gemm_loop_glds<TL>(oa, ob, acc, 0, K, w);
 
-// A operand of the weight gradient: 8 consecutive hidden units at frame k
+  float bcol[TL::TN];
+  preload_cols<TL>(bcol, w, [&](int nn) { return n0 + nn < Hd ? bias[n0 + nn] : 0.f; });
+  bf16_t* tile = reinterpret_cast<bf16_t*>(smem_raw);
+  store_tile_bf16<TL>(acc, w, tile, h, Hd, m0, n0, rows, Hd,
+                      [&](int, int tn, int, int, int, float v) { return fmaxf(v + bcol[tn], 0.f); });
+  // h_n: the last frame of every utterance that ends inside this row tile (tile still in LDS)
+  const long tile_end = min((long)rows, m0 + TL::BM);
+  constexpr int LDT = TL::BN + 8;
+  for (long rl = (m0 / T) * T + T - 1; rl < tile_end; rl += T) {
+    const int ml = (int)(rl - m0);
+    for (int c = threadIdx.x; c < TL::BN / 8; c += kThreads) {
+      const int col = n0 + c * 8;
+      if (col < Hd)
+        *reinterpret_cast<bf16x8*>(h_n + (rl / T) * Hd + col) = *reinterpret_cast<const bf16x8*>(&tile[ml * LDT + c * 8]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// gz = (h > 0) ? gh (+ gh_n on the last frame) : 0   and   partial gb_h = sum_rows gz
+// One pass over h and gh; the three GEMMs of the backward read gz afterwards.
+// Slab per workgroup: [Hd] fp32.
+// ---------------------------------------------------------------------------
 template <bool VEC>
-struct GzColsLoadB {
-  GzSourceB<VEC> src;
-  int n0, kend;
-  typedef typename GzSourceB<VEC>::raw_t raw_t;
-  __device__ __forceinline__ raw_t fetch(int r, int k) const { return src.fetch_at((long)k, n0 + r, k < kend); }
-  __device__ __forceinline__ bf16x8 finish(const raw_t& v) const { return src.finish(v); }
-};
+__global__ __launch_bounds__(kThreads) void k_relu_bwd_bf16(const bf16_t* __restrict__ h,
+                                                            const bf16_t* __restrict__ gh,
+                                                            const bf16_t* __restrict__ gh_n,
+                                                            bf16_t* __restrict__ gz, float* __restrict__ part,
+                                                            int rows, int T, int Hd, int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [row groups][Hd rounded up to 8]
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(rows, r0 + rows_per_block);
+  float* slab = part + (long)blockIdx.x * Hd;
+  if (VEC) {
+    const int CH = Hd / 8;                 // 16-byte chunks per row
+    const int RP = kThreads / CH;          // rows per pass (threads beyond RP*CH idle)
+    const int c = threadIdx.x % CH, rg = threadIdx.x / CH;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (rg < RP) {
+      for (int row = r0 + rg; row < r1; row += RP) {
+        const long off = (long)row * Hd + c * 8;
+        const bf16x8 hv = *reinterpret_cast<const bf16x8*>(h + off);
+        bf16x8 g = gh ? *reinterpret_cast<const bf16x8*>(gh + off) : bzero8();
+        if (gh_n) {
+          const unsigned b = (unsigned)row / (unsigned)T;
+          if ((unsigned)row - b * (unsigned)T == (unsigned)(T - 1)) {
+            const bf16x8 gl = *reinterpret_cast<const bf16x8*>(gh_n + (long)b * Hd + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] = (bf16_t)((float)g[j] + (float)gl[j]);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          g[j] = (float)hv[j] > 0.f ? g[j] : (bf16_t)0.f;
+          cs[j] += (float)g[j];
+        }
+        *reinterpret_cast<bf16x8*>(gz + off) = g;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[rg * Hd + c * 8 + j] = cs[j];
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < Hd; n += kThreads) {
+      float s = 0.f;
+      for (int q = 0; q < RP; ++q) s += red[q * Hd + n];
+      slab[n] = s;
+    }
+  } else {
+    for (int n = threadIdx.x; n < Hd; n += kThreads) {
+      float s = 0.f;
+      for (int row = r0; row < r1; ++row) {
+        const long off = (long)row * Hd + n;
+        float g = gh ? (float)gh[off] : 0.f;
+        if (gh_n && row % T == T - 1) g += (float)gh_n[(long)(row / T) * Hd + n];
+        const bf16_t gb = (float)h[off] > 0.f ? (bf16_t)g : (bf16_t)0.f;
+        gz[off] = gb;
+        s += (float)gb;
+      }
+      slab[n] = s;
+    }
+  }
+}
 
 // ---------------------------------------------------------------------------
 // out[row][j] = sum_n gz[row][n] W_h[n][j_begin + j]  (+ ga[row] w_u[j])
 // called for the memory columns (-> gm) and for the input columns (-> gx)
 // ---------------------------------------------------------------------------
 template <class TL, bool VEC>
-__global__ __launch_bounds__(kThreads) void k_dgrad_bf16(const bf16_t* __restrict__ h,
-                                                         const bf16_t* __restrict__ gh,
-                                                         const bf16_t* __restrict__ gh_n,
+__global__ __launch_bounds__(kThreads) void k_dgrad_bf16(const bf16_t* __restrict__ gz,
                                                          const bf16_t* __restrict__ WbT, bf16_t* __restrict__ out,
                                                          const float* __restrict__ ga,
-                                                         const float* __restrict__ w_u, int rows, int T, int Hd,
+                                                         const float* __restrict__ w_u, int rows, int Hd,
                                                          int ldWT, int j_begin, int ncols) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
   const int n0 = blockIdx.x * TL::BN;
   const int m0 = blockIdx.y * TL::BM;
 
-  const GzRowsLoadB<VEC> la{{h, gh, gh_n, T, Hd}, (long)m0, rows};
+  auto la = plain_load_b([=](int r, int k) -> bf16x8 {
+    const long row = m0 + r;
+    return bload8<VEC>(gz, row * Hd + k, k, Hd, row < rows);
+  });
   auto lb = plain_load_b([=](int r, int k) -> bf16x8 {
     const int j = n0 + r;
     return bload8<true>(WbT, (long)(j_begin + j) * ldWT + k, k, ldWT, j < ncols);
@@ -320,14 +400,56 @@ __global__ __launch_bounds__(kThreads) void k_dgrad_bf16(const bf16_t* __restric
   tileb_zero<TL>(acc);
   gemm_loop_kc<TL>(oa, ob, acc, 0, Hd, w);
 
-  tileb_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
+  float wcol[TL::TN], grow[TL::TM][16];
+  preload_cols<TL>(wcol, w, [&](int nn) { return (ga && n0 + nn < ncols) ? w_u[n0 + nn] : 0.f; });
+  preload_rows<TL>(grow, w, [&](int mm) { return (ga && m0 + mm < rows) ? ga[m0 + mm] : 0.f; });
+  tile_epilogue_ix<TL>(acc, w, [&](int tm, int tn, int i, int mm, int nn, float v) {
     const long row = m0 + mm;
     const int j = n0 + nn;
-    if (row < rows && j < ncols) {
-      if (ga) v += ga[row] * w_u[j];
-      out[row * ncols + j] = (bf16_t)v;
-    }
+    if (row < rows && j < ncols) out[row * ncols + j] = (bf16_t)(v + grow[tm][i] * wcol[tn]);
   });
+}
+
+// LDS-DMA form; needs Hd % 8 == 0, ncols % 8 == 0 and 16-byte aligned rows
+template <class TL>
+__global__ __launch_bounds__(kThreads) void k_dgrad_glds_bf16(const bf16_t* __restrict__ gz,
+                                                              const bf16_t* __restrict__ WbT,
+                                                              bf16_t* __restrict__ out,
+                                                              const float* __restrict__ ga,
+                                                              const float* __restrict__ w_u, int rows, int Hd,
+                                                              int ldWT, int j_begin, int ncols) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  int ntile, mtile;
+  xcd_tile_order(ntile, mtile);
+  const int n0 = ntile * TL::BN;
+  const long m0 = (long)mtile * TL::BM;
+  if (m0 >= rows) return;  // (whole workgroup) padding tile of the XCD-aware order
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(kZeroBytes);
+
+  auto sa = [=](int r, int k) -> const bf16_t* {
+    const long row = m0 + r;
+    return (row < rows && k < Hd) ? gz + row * Hd + k : zero;
+  };
+  auto sb = [=](int r, int k) -> const bf16_t* {
+    const int j = n0 + r;
+    return (j < ncols && k < ldWT) ? WbT + (long)(j_begin + j) * ldWT + k : zero;
+  };
+  typedef GldsOperand<TL::BM, decltype(sa)> OpA;
+  typedef GldsOperand<TL::BN, decltype(sb)> OpB;
+  OpA oa(smem_raw, sa);
+  OpB ob(smem_raw + 2 * OpA::STAGE_BYTES, sb);
+
+  WavePos<TL> w;
+  f32x16 acc[TL::TM][TL::TN];
+  tileb_zero<TL>(acc);
+  gemm_loop_glds<TL>(oa, ob, acc, 0, Hd, w);
+
+  float wcol[TL::TN], grow[TL::TM][16];
+  preload_cols<TL>(wcol, w, [&](int nn) { return (ga && n0 + nn < ncols) ? w_u[n0 + nn] : 0.f; });
+  preload_rows<TL>(grow, w, [&](int mm) { return (ga && m0 + mm < rows) ? ga[m0 + mm] : 0.f; });
+  bf16_t* tile = reinterpret_cast<bf16_t*>(smem_raw);
+  store_tile_bf16<TL>(acc, w, tile, out, ncols, m0, n0, rows, ncols,
+                      [&](int tm, int tn, int i, int, int, float v) { return v + grow[tm][i] * wcol[tn]; });
 }
 
 using DgradMTileB = TileB<128, 192, 64, 2, 2>;
@@ -387,20 +509,17 @@ __global__ __launch_bounds__(kThreads) void k_conv_bwd_bf16(const bf16_t* __rest
 }
 
 // ---------------------------------------------------------------------------
-// gW_h[n][j] = sum_rows gz[row][n] [m;x][row][j];  gb_h[n] = sum_rows gz[row][n]
+// gW_h[n][j] = sum_rows gz[row][n] [m;x][row][j]
 // k = frame index: both operands are k-strided in HBM -> transposed LDS reads.
-// Row range split over gridDim.z; fp32 slabs [Hd*(M+D) + Hd] summed afterwards.
+// Row range split over gridDim.z; fp32 slabs [Hd*(M+D)] summed afterwards.
 // ---------------------------------------------------------------------------
 using WgradTileB = TileB<128, 192, 32, 2, 2>;
 
 template <bool VEC>
-__global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restrict__ h,
-                                                         const bf16_t* __restrict__ gh,
-                                                         const bf16_t* __restrict__ gh_n,
+__global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restrict__ gz,
                                                          const bf16_t* __restrict__ m,
                                                          const bf16_t* __restrict__ x, float* __restrict__ slabs,
-                                                         int rows, int rows_per_split, int T, int M, int D,
-                                                         int Hd) {
+                                                         int rows, int rows_per_split, int M, int D, int Hd) {
   using TL = WgradTileB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
@@ -409,9 +528,12 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
   const int MD = M + D;
   const int kbeg = blockIdx.z * rows_per_split;
   const int kend = min(rows, kbeg + rows_per_split);
-  float* slab = slabs + blockIdx.z * ((long)Hd * MD + Hd);
+  float* slab = slabs + blockIdx.z * ((long)Hd * MD);
 
-  const GzColsLoadB<VEC> la{{h, gh, gh_n, T, Hd}, n0, kend};
+  auto la = plain_load_b([=](int r, int k) -> bf16x8 {
+    const int n = n0 + r;
+    return bload8<VEC>(gz, (long)k * Hd + n, n, Hd, k < kend);
+  });
   auto lb = plain_load_b([=](int r, int k) -> bf16x8 {
     const long row = k;
     const int j = j0 + r;
@@ -435,17 +557,6 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
   OpA oa(smem, la);
   OpB ob(smem + OpA::ELEMS, lb);
 
-  // bias gradient: every staged A vector holds 8 hidden units of one frame and
-  // a thread always stages the same 8 units (256 % (BM/8) == 0)
-  const bool do_bias = blockIdx.x == 0;
-  float colsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  auto seen = [&](const bf16x8& v) {
-    if (do_bias) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) colsum[j] += (float)v[j];
-    }
-  };
-
   WavePos<TL> w;
   f32x16 acc[TL::TM][TL::TN];
   tileb_zero<TL>(acc);
@@ -454,7 +565,7 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
     ob.fetch(kbeg);
   }
   for (int k0 = kbeg; k0 < kend; k0 += TL::BK) {
-    oa.store(seen);
+    oa.store();
     ob.store();
     __syncthreads();
     if (k0 + TL::BK < kend) {
@@ -481,19 +592,6 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
     const int n = n0 + mm, j = j0 + nn;
     if (n < Hd && j < MD) slab[(long)n * MD + j] = v;
   });
-
-  if (do_bias) {  // (uniform per workgroup)
-    float* red = reinterpret_cast<float*>(smem);  // [256][8] fp32 = 8 KB, tiles are free after the last barrier
-#pragma unroll
-    for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = colsum[j];
-    __syncthreads();
-    if (threadIdx.x < TL::BM) {
-      const int n8 = threadIdx.x >> 3, j = threadIdx.x & 7;
-      float s = 0.f;
-      for (int q = 0; q < kThreads / (TL::BM / 8); ++q) s += red[(q * (TL::BM / 8) + n8) * 8 + j];
-      if (n0 + (int)threadIdx.x < Hd) slab[(long)Hd * MD + n0 + threadIdx.x] = s;
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------
@@ -543,7 +641,7 @@ __global__ __launch_bounds__(kThreads) void k_encode_bwd_bf16(const float* __res
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-constexpr int kEncRowsPerBlockB = 128;
+constexpr int kEncRowsPerBlockB = 64;
 
 struct HprepLayout {
   int ldHb, ldHT;
@@ -574,9 +672,11 @@ static WprepLayout wprep_layout(const lmufft_shape& s) {
   return l;
 }
 
+constexpr int kReluRowsPerBlock = 128;
+
 struct BwdPlanB {
-  int S, rps, ntt, enc_blocks;
-  size_t off_wslab, off_gupart, off_ga, off_encpart, total;
+  int S, rps, ntt, enc_blocks, relu_blocks;
+  size_t off_gz, off_relupart, off_wslab, off_gupart, off_ga, off_encpart, total;
 };
 static BwdPlanB plan_backward_b(const lmufft_shape& s) {
   BwdPlanB p;
@@ -590,9 +690,14 @@ static BwdPlanB plan_backward_b(const lmufft_shape& s) {
   p.rps = rps;
   p.ntt = cdivb(s.T, ConvBwdTileB::BM);
   p.enc_blocks = cdivb(rows, kEncRowsPerBlockB);
+  p.relu_blocks = cdivb(rows, kReluRowsPerBlock);
   size_t off = 0;
+  p.off_gz = off;
+  off += align256b(sizeof(bf16_t) * (size_t)rows * s.Hd);
+  p.off_relupart = off;
+  off += align256b(sizeof(float) * (size_t)p.relu_blocks * s.Hd);
   p.off_wslab = off;
-  off += align256b(sizeof(float) * (size_t)p.S * ((size_t)s.Hd * MD + s.Hd));
+  off += align256b(sizeof(float) * (size_t)p.S * ((size_t)s.Hd * MD));
   p.off_gupart = off;
   off += align256b(sizeof(float) * (size_t)s.B * p.ntt * s.T);
   p.off_ga = off;
@@ -727,17 +832,26 @@ int lmufft_forward_bf16(const lmufft_shape* s, const void* x_, const float* w_u,
   }
   {
     using TL = ProjTileB;
-    const bool vec = (s->M % 8 == 0) && (s->D % 8 == 0) && al16(m) && al16(x);
-    const dim3 grid(cdivb(s->Hd, TL::BN), cdivb(rows, TL::BM));
-    const size_t lds = sizeof(bf16_t) * (size_t)(TL::BM + TL::BN) * (TL::BK + 8);
-    {
+    const bool vec = (s->M % 8 == 0) && (s->D % 8 == 0) && (s->Hd % 8 == 0) && al16(m) && al16(x) && al16(h) &&
+                     al16(h_n);
+    if (vec) {  // LDS-DMA staging, XCD-aware tile order (row tiles rounded up to a multiple of 8)
+      const dim3 grid(cdivb(s->Hd, TL::BN), cdivb(cdivb(rows, TL::BM), 8) * 8);
+      const size_t lds = 2 * (size_t)(TL::BM + TL::BN) * kGldsRowBytes;
+      static_assert(2 * (TL::BM + TL::BN) * kGldsRowBytes >= TL::BM * (TL::BN + 8) * 2, "epilogue tile fits");
+      if (hipFuncSetAttribute((const void*)k_proj_fwd_glds_bf16, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds) != hipSuccess)
+        return set_error("cannot reserve %zu bytes of LDS for k_proj_fwd_glds_bf16", lds);
+      {
+        PROFB("k_proj_fwd_bf16");
+        hipLaunchKernelGGL(k_proj_fwd_glds_bf16, grid, dim3(kThreads), lds, st, m, x, Wb, b_h, h, h_n, (int)rows,
+                           s->T, s->M, s->D, s->Hd, ldW);
+      }
+    } else {
+      const dim3 grid(cdivb(s->Hd, TL::BN), cdivb(rows, TL::BM));
+      const size_t lds = sizeof(bf16_t) * (size_t)(TL::BM + TL::BN) * (TL::BK + 8);
       PROFB("k_proj_fwd_bf16");
-      if (vec)
-        hipLaunchKernelGGL(k_proj_fwd_bf16<true>, grid, dim3(kThreads), lds, st, m, x, Wb, b_h, h, h_n, (int)rows,
-                           s->T, s->M, s->D, s->Hd, ldW);
-      else
-        hipLaunchKernelGGL(k_proj_fwd_bf16<false>, grid, dim3(kThreads), lds, st, m, x, Wb, b_h, h, h_n, (int)rows,
-                           s->T, s->M, s->D, s->Hd, ldW);
+      hipLaunchKernelGGL(k_proj_fwd_bf16<false>, grid, dim3(kThreads), lds, st, m, x, Wb, b_h, h, h_n, (int)rows,
+                         s->T, s->M, s->D, s->Hd, ldW);
     }
     LAUNCH_CHECKB("k_proj_fwd_bf16");
   }
@@ -777,23 +891,55 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
   const int MD = s->M + s->D;
   const HprepLayout hl = hprep_layout(s->M, s->ldH);
   const bf16_t* HbT = (const bf16_t*)((const char*)hprep + hl.off_HbT);
-  const bool vec_h = (s->Hd % 8 == 0) && al16(h) && (!gh || al16(gh)) && (!gh_n || al16(gh_n));
+  bf16_t* gz = (bf16_t*)(ws + p.off_gz);
+  float* relupart = (float*)(ws + p.off_relupart);
+  const bool vec_h = (s->Hd % 8 == 0) && (s->Hd / 8 <= kThreads) && al16(h) && (!gh || al16(gh)) &&
+                     (!gh_n || al16(gh_n));
 
-  {  // gm = gz W_h[:, :M]
-    using TL = DgradMTileB;
-    const dim3 grid(cdivb(s->M, TL::BN), cdivb(rows, TL::BM));
-    const size_t lds = sizeof(bf16_t) * (size_t)(TL::BM + TL::BN) * (TL::BK + 8);
+  {  // gz = relu'(h) * (gh + gh_n), gb_h
+    const dim3 grid(p.relu_blocks);
     {
+      PROFB("k_relu_bwd_bf16");
+      if (vec_h) {
+        const int RP = kThreads / (s->Hd / 8);
+        hipLaunchKernelGGL(k_relu_bwd_bf16<true>, grid, dim3(kThreads), sizeof(float) * (size_t)RP * s->Hd, st, h, gh,
+                           gh_n, gz, relupart, (int)rows, s->T, s->Hd, kReluRowsPerBlock);
+      } else {
+        hipLaunchKernelGGL(k_relu_bwd_bf16<false>, grid, dim3(kThreads), 0, st, h, gh, gh_n, gz, relupart,
+                           (int)rows, s->T, s->Hd, kReluRowsPerBlock);
+      }
+    }
+    LAUNCH_CHECKB("k_relu_bwd_bf16");
+    if (int rc = launch_reduce_slabs(relupart, p.relu_blocks, (long)s->Hd, gb_h, (long)s->Hd, gb_h, 0L, st)) return rc;
+  }
+
+  // out = gz W_h[:, j_begin : j_begin + ncols] (+ ga w_u), LDS-DMA kernel when everything is 16-byte friendly
+  auto dgrad = [&](auto tile_tag, bf16_t* out, int j_begin, int ncols, const float* ga_, const float* wu_) -> int {
+    using TL = decltype(tile_tag);
+    const bool fast = (s->Hd % 8 == 0) && (ncols % 8 == 0) && al16(out);
+    if (fast) {
+      const dim3 grid(cdivb(ncols, TL::BN), cdivb(cdivb(rows, TL::BM), 8) * 8);
+      const size_t lds = 2 * (size_t)(TL::BM + TL::BN) * kGldsRowBytes;
+      static_assert(2 * (TL::BM + TL::BN) * kGldsRowBytes >= TL::BM * (TL::BN + 8) * 2, "epilogue tile fits");
+      if (hipFuncSetAttribute((const void*)k_dgrad_glds_bf16<TL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds) != hipSuccess)
+        return set_error("cannot reserve %zu bytes of LDS for k_dgrad_glds_bf16", lds);
       PROFB("k_dgrad_bf16");
-      if (vec_h)
-        hipLaunchKernelGGL((k_dgrad_bf16<TL, true>), grid, dim3(kThreads), lds, st, h, gh, gh_n, WbT, gm,
-                           (const float*)nullptr, (const float*)nullptr, (int)rows, s->T, s->Hd, wl.ldWT, 0, s->M);
-      else
-        hipLaunchKernelGGL((k_dgrad_bf16<TL, false>), grid, dim3(kThreads), lds, st, h, gh, gh_n, WbT, gm,
-                           (const float*)nullptr, (const float*)nullptr, (int)rows, s->T, s->Hd, wl.ldWT, 0, s->M);
+      hipLaunchKernelGGL(k_dgrad_glds_bf16<TL>, grid, dim3(kThreads), lds, st, (const bf16_t*)gz, WbT, out, ga_, wu_,
+                         (int)rows, s->Hd, wl.ldWT, j_begin, ncols);
+    } else {
+      const dim3 grid(cdivb(ncols, TL::BN), cdivb(rows, TL::BM));
+      const size_t lds = sizeof(bf16_t) * (size_t)(TL::BM + TL::BN) * (TL::BK + 8);
+      PROFB("k_dgrad_bf16");
+      hipLaunchKernelGGL((k_dgrad_bf16<TL, false>), grid, dim3(kThreads), lds, st, (const bf16_t*)gz, WbT, out, ga_,
+                         wu_, (int)rows, s->Hd, wl.ldWT, j_begin, ncols);
     }
     LAUNCH_CHECKB("k_dgrad_bf16");
-  }
+    return 0;
+  };
+
+  // gm = gz W_h[:, :M]
+  if (int rc = dgrad(DgradMTileB{}, gm, 0, s->M, nullptr, nullptr)) return rc;
   {  // ga = (adjoint conv of gm) * (u > 0)
     using TL = ConvBwdTileB;
     const dim3 grid(1, s->B, p.ntt);
@@ -816,38 +962,26 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
     LAUNCH_CHECKB("k_conv_bwd_bf16");
     if (int rc = launch_gu_reduce(gupart, u, ga, s->B, s->T, p.ntt, TL::BM, st)) return rc;
   }
-  if (gx) {  // gx = gz W_h[:, M:] + ga w_u
-    using TL = DgradXTileB;
-    const dim3 grid(cdivb(s->D, TL::BN), cdivb(rows, TL::BM));
-    const size_t lds = sizeof(bf16_t) * (size_t)(TL::BM + TL::BN) * (TL::BK + 8);
-    {
-      PROFB("k_dgrad_bf16");
-      if (vec_h)
-        hipLaunchKernelGGL((k_dgrad_bf16<TL, true>), grid, dim3(kThreads), lds, st, h, gh, gh_n, WbT, gx,
-                           (const float*)ga, w_u, (int)rows, s->T, s->Hd, wl.ldWT, s->M, s->D);
-      else
-        hipLaunchKernelGGL((k_dgrad_bf16<TL, false>), grid, dim3(kThreads), lds, st, h, gh, gh_n, WbT, gx,
-                           (const float*)ga, w_u, (int)rows, s->T, s->Hd, wl.ldWT, s->M, s->D);
-    }
-    LAUNCH_CHECKB("k_dgrad_bf16");
-  }
-  {  // gW_h, gb_h
+  // gx = gz W_h[:, M:] + ga w_u
+  if (gx)
+    if (int rc = dgrad(DgradXTileB{}, gx, s->M, s->D, (const float*)ga, w_u)) return rc;
+  {  // gW_h
     using TL = WgradTileB;
-    const bool vec = vec_h && (s->M % 8 == 0) && (s->D % 8 == 0) && al16(m) && al16(x);
+    const bool vec = (s->Hd % 8 == 0) && (s->M % 8 == 0) && (s->D % 8 == 0) && al16(m) && al16(x);
     const dim3 grid(cdivb(MD, TL::BN), cdivb(s->Hd, TL::BM), p.S);
     const size_t lds = sizeof(bf16_t) * (size_t)TL::BK * ((TL::BM + 32) + (TL::BN + 32));
     {
       PROFB("k_wgrad_bf16");
       if (vec)
-        hipLaunchKernelGGL(k_wgrad_bf16<true>, grid, dim3(kThreads), lds, st, h, gh, gh_n, m, x, wslab, (int)rows,
-                           p.rps, s->T, s->M, s->D, s->Hd);
+        hipLaunchKernelGGL(k_wgrad_bf16<true>, grid, dim3(kThreads), lds, st, (const bf16_t*)gz, m, x, wslab,
+                           (int)rows, p.rps, s->M, s->D, s->Hd);
       else
-        hipLaunchKernelGGL(k_wgrad_bf16<false>, grid, dim3(kThreads), lds, st, h, gh, gh_n, m, x, wslab, (int)rows,
-                           p.rps, s->T, s->M, s->D, s->Hd);
+        hipLaunchKernelGGL(k_wgrad_bf16<false>, grid, dim3(kThreads), lds, st, (const bf16_t*)gz, m, x, wslab,
+                           (int)rows, p.rps, s->M, s->D, s->Hd);
     }
     LAUNCH_CHECKB("k_wgrad_bf16");
     const long n0 = (long)s->Hd * MD;
-    if (int rc = launch_reduce_slabs(wslab, p.S, n0 + s->Hd, gW_h, n0, gb_h, (long)s->Hd, st)) return rc;
+    if (int rc = launch_reduce_slabs(wslab, p.S, n0, gW_h, n0, gW_h, 0L, st)) return rc;
   }
   {  // gw_u, gb_u
     const bool vec = (s->D % 8 == 0) && al16(x);

@@ -151,18 +151,20 @@ __global__ __launch_bounds__(kThreads) void k_proj_fwd(const float* __restrict__
   tile_zero<TL>(acc);
   gemm_tile<TL>(smem, acc, la, lb, 0, K, w);
 
-  tile_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
+  float bcol[TL::TN];
+  preload_cols<TL>(bcol, w, [&](int nn) { return n0 + nn < Hd ? bias[n0 + nn] : 0.f; });
+  tile_epilogue_ix<TL>(acc, w, [&](int, int tn, int, int mm, int nn, float v) {
     const long row = m0 + mm;
     const int n = n0 + nn;
-    if (row < rows && n < Hd) h[row * Hd + n] = fmaxf(v + bias[n], 0.f);
+    if (row < rows && n < Hd) h[row * Hd + n] = fmaxf(v + bcol[tn], 0.f);
   });
   // h_n: the last frame of every utterance that ends inside this row tile
   const long tile_end = min((long)rows, (long)m0 + TL::BM);
   for (long rl = ((long)m0 / T) * T + T - 1; rl < tile_end; rl += T) {
     const int ml = (int)(rl - m0);
-    tile_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
+    tile_epilogue_ix<TL>(acc, w, [&](int, int tn, int, int mm, int nn, float v) {
       const int n = n0 + nn;
-      if (mm == ml && n < Hd) h_n[(rl / T) * Hd + n] = fmaxf(v + bias[n], 0.f);
+      if (mm == ml && n < Hd) h_n[(rl / T) * Hd + n] = fmaxf(v + bcol[tn], 0.f);
     });
   }
 }
@@ -253,13 +255,13 @@ __global__ __launch_bounds__(kThreads) void k_dgrad(const float* __restrict__ h,
   tile_zero<TL>(acc);
   gemm_tile<TL>(smem, acc, la, lb, 0, Hd, w);
 
-  tile_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
+  float wcol[TL::TN], grow[TL::TM][16];
+  preload_cols<TL>(wcol, w, [&](int nn) { return (ga && n0 + nn < ncols) ? w_u[n0 + nn] : 0.f; });
+  preload_rows<TL>(grow, w, [&](int mm) { return (ga && m0 + mm < rows) ? ga[m0 + mm] : 0.f; });
+  tile_epilogue_ix<TL>(acc, w, [&](int tm, int tn, int i, int mm, int nn, float v) {
     const long row = m0 + mm;
     const int j = n0 + nn;
-    if (row < rows && j < ncols) {
-      if (ga) v += ga[row] * w_u[j];
-      out[row * ncols + j] = v;
-    }
+    if (row < rows && j < ncols) out[row * ncols + j] = v + grow[tm][i] * wcol[tn];
   });
 }
 
@@ -528,7 +530,7 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 
-constexpr int kEncRowsPerBlock = 128;
+constexpr int kEncRowsPerBlock = 64;
 
 static int wgrad_splits(long rows, int Hd, int MD, int* rows_per_split) {
   const int tiles = cdiv(Hd, WgradTile::BM) * cdiv(MD, WgradTile::BN);
