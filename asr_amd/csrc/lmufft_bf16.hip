@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "gemm_core_bf16.h"
 #include "gemm_glds_bf16.h"
 #include "lmufft.h"
@@ -509,6 +511,123 @@ __global__ __launch_bounds__(kThreads) void k_conv_bwd_bf16(const bf16_t* __rest
 }
 
 // ---------------------------------------------------------------------------
+// Adjoint convolution, second form (used when M % 8 == 0):
+//   gu[b][s] = sum_{t >= s} sum_k gm[b][t][k] H[k][t - s]
+// as a GEMM whose OUTPUT is gu itself, so no diagonal sums are needed:
+//   rows = batch items   A[b][(t,k)] = gm[b][t][k]   (contiguous in HBM; the
+//                        fragments are loaded straight into registers)
+//   cols = frames s      B[(t,k)][s] = H^T[t - s][k] (a sliding window of H^T
+//                        rows kept in LDS, zero rows where t < s)
+//   K    = (t, k), t restricted to this workgroup's frame range.
+// Grid (P, s tiles of 64, batch tiles of 32): the frames t >= s0 of an s tile
+// are cut into P contiguous ranges; each workgroup writes its 32 x 64 partial
+// tile to slab p, k_sum_slabs_masked adds the P slabs in order.  The four waves
+// take every fourth frame of the range and are summed through LDS in wave order,
+// so the result is deterministic.
+// ---------------------------------------------------------------------------
+constexpr int kCb2St = 64;  // frames s per tile
+constexpr int kCb2Bt = 32;  // batch items per tile
+
+template <int KS>  // k-steps of 16 per frame: KS = ceil(M / 16)
+__global__ __launch_bounds__(kThreads) void k_conv_bwd2_bf16(const bf16_t* __restrict__ gm,
+                                                             const bf16_t* __restrict__ HbT,
+                                                             float* __restrict__ part, int B, int T, int M,
+                                                             int ldHT, int rowsHT, int P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int KP = KS * 16, LDW = KP + 8;
+  const int p = blockIdx.x, s0 = blockIdx.y * kCb2St, b0 = blockIdx.z * kCb2Bt;
+  const int Lp = (T - s0 + P - 1) / P;
+  const int ta = s0 + p * Lp, tb = min(T, ta + Lp);
+  const int nrows = max(tb - ta, 0) + kCb2St - 1;
+  bf16_t* window = reinterpret_cast<bf16_t*>(smem_raw);          // [nrows][LDW], row 0 <-> tau = ta - s0 - 63
+  float* red = reinterpret_cast<float*>(smem_raw + (size_t)(Lp + kCb2St - 1) * LDW * sizeof(bf16_t));  // [4][32][64]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(kZeroBytes);
+
+  const int tau_lo = ta - s0 - (kCb2St - 1);
+  for (int idx = threadIdx.x; idx < nrows * (KP / 8); idx += kThreads) {
+    const int row = idx / (KP / 8), c = idx % (KP / 8);
+    const int tau = tau_lo + row;
+    const bool ok = tau >= 0 && tau < rowsHT && c * 8 < ldHT;
+    *reinterpret_cast<bf16x8*>(&window[row * LDW + c * 8]) =
+        *reinterpret_cast<const bf16x8*>(ok ? HbT + (long)tau * ldHT + c * 8 : zero);
+  }
+  __syncthreads();
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;
+
+  const bool brow_ok = b0 + r < B;
+  const bf16_t* gbase = gm + (long)(b0 + r) * T * M;
+  auto load_frame = [&](bf16x8 (&a)[KS], int t) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = ks * 16 + 8 * hh;
+      a[ks] = *reinterpret_cast<const bf16x8*>((brow_ok && k < M) ? gbase + (long)t * M + k : zero);
+    }
+  };
+  bf16x8 cur[KS], nxt[KS];
+  int t = ta + wave;
+  if (t < tb) load_frame(cur, t);
+  for (; t < tb; t += 4) {
+    const bool more = t + 4 < tb;
+    if (more) load_frame(nxt, t + 4);
+    const int wrow = t - ta + (kCb2St - 1) - r;  // window row of tau = t - s for s = s0 + r
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = ks * 16 + 8 * hh;
+      const bf16x8 b0f = *reinterpret_cast<const bf16x8*>(&window[wrow * LDW + k]);
+      const bf16x8 b1f = *reinterpret_cast<const bf16x8*>(&window[(wrow - 32) * LDW + k]);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[ks], b0f, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[ks], b1f, acc[1], 0, 0, 0);
+    }
+    if (more) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) cur[ks] = nxt[ks];
+    }
+  }
+
+  // wave partials -> LDS -> ordered sum -> slab p
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int bl = (i & 3) + 8 * (i >> 2) + 4 * hh;
+      red[(wave * kCb2Bt + bl) * kCb2St + tn * 32 + r] = acc[tn][i];
+    }
+  __syncthreads();
+  float* slab = part + (long)p * B * T;
+  for (int idx = threadIdx.x; idx < kCb2Bt * kCb2St; idx += kThreads) {
+    const int bl = idx / kCb2St, sl = idx % kCb2St;
+    const float v = ((red[(0 * kCb2Bt + bl) * kCb2St + sl] + red[(1 * kCb2Bt + bl) * kCb2St + sl]) +
+                     red[(2 * kCb2Bt + bl) * kCb2St + sl]) +
+                    red[(3 * kCb2Bt + bl) * kCb2St + sl];
+    if (b0 + bl < B && s0 + sl < T) slab[(long)(b0 + bl) * T + s0 + sl] = v;
+  }
+}
+
+// out[i] = sum_p part[p * n + i], optionally masked by u[i] > 0 (ReLU of the encoder)
+__global__ __launch_bounds__(kThreads) void k_sum_slabs_masked(const float* __restrict__ part,
+                                                               const float* __restrict__ u, float* __restrict__ out,
+                                                               long n, int P) {
+  for (long i = blockIdx.x * (long)kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int p = 0;
+    for (; p + 4 <= P; p += 4) {
+      s0 += part[(long)p * n + i];
+      s1 += part[(long)(p + 1) * n + i];
+      s2 += part[(long)(p + 2) * n + i];
+      s3 += part[(long)(p + 3) * n + i];
+    }
+    for (; p < P; ++p) s0 += part[(long)p * n + i];
+    float s = (s0 + s1) + (s2 + s3);
+    if (u) s = u[i] > 0.f ? s : 0.f;
+    out[i] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // gW_h[n][j] = sum_rows gz[row][n] [m;x][row][j]
 // k = frame index: both operands are k-strided in HBM -> transposed LDS reads.
 // Row range split over gridDim.z; fp32 slabs [Hd*(M+D)] summed afterwards.
@@ -675,7 +794,7 @@ static WprepLayout wprep_layout(const lmufft_shape& s) {
 constexpr int kReluRowsPerBlock = 128;
 
 struct BwdPlanB {
-  int S, rps, ntt, enc_blocks, relu_blocks;
+  int S, rps, ntt, enc_blocks, relu_blocks, cb2_P;
   size_t off_gz, off_relupart, off_wslab, off_gupart, off_ga, off_encpart, total;
 };
 static BwdPlanB plan_backward_b(const lmufft_shape& s) {
@@ -698,8 +817,12 @@ static BwdPlanB plan_backward_b(const lmufft_shape& s) {
   off += align256b(sizeof(float) * (size_t)p.relu_blocks * s.Hd);
   p.off_wslab = off;
   off += align256b(sizeof(float) * (size_t)p.S * ((size_t)s.Hd * MD));
+  {  // second form of the adjoint convolution: P frame ranges per s tile
+    const int tiles = cdivb(s.T, kCb2St) * cdivb(s.B, kCb2Bt);
+    p.cb2_P = std::max(1, std::min(std::min(32, s.T), (768 + tiles - 1) / tiles));
+  }
   p.off_gupart = off;
-  off += align256b(sizeof(float) * (size_t)s.B * p.ntt * s.T);
+  off += align256b(sizeof(float) * std::max((size_t)s.B * p.ntt * s.T, (size_t)p.cb2_P * s.B * s.T));
   p.off_ga = off;
   off += align256b(sizeof(float) * (size_t)rows);
   p.off_encpart = off;
@@ -940,7 +1063,40 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
 
   // gm = gz W_h[:, :M]
   if (int rc = dgrad(DgradMTileB{}, gm, 0, s->M, nullptr, nullptr)) return rc;
-  {  // ga = (adjoint conv of gm) * (u > 0)
+  // ga = (adjoint conv of gm) * (u > 0)
+  const int KS = cdivb(s->M, 16);
+  if (s->M % 8 == 0 && al16(gm) && (KS == 2 || KS == 4 || KS == 8 || KS == 12 || KS == 16)) {
+    const int P = p.cb2_P;
+    const dim3 grid(P, cdivb(s->T, kCb2St), cdivb(s->B, kCb2Bt));
+    const int Lp_max = cdivb(s->T, P);
+    const size_t lds = (size_t)(Lp_max + kCb2St - 1) * (KS * 16 + 8) * sizeof(bf16_t) +
+                       sizeof(float) * 4 * kCb2Bt * kCb2St;
+    if (lds > 160 * 1024) return set_error("adjoint convolution: LDS window of %zu bytes does not fit", lds);
+#define LAUNCH_CB2(KSV)                                                                                       \
+  do {                                                                                                        \
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)k_conv_bwd2_bf16<KSV>,                             \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+      return set_error("cannot reserve %zu bytes of LDS for k_conv_bwd2_bf16", lds);                          \
+    PROFB("k_conv_bwd_bf16");                                                                                 \
+    hipLaunchKernelGGL(k_conv_bwd2_bf16<KSV>, grid, dim3(kThreads), lds, st, (const bf16_t*)gm, HbT, gupart,   \
+                       s->B, s->T, s->M, hl.ldHT, hl.ldHb, P);                                                \
+  } while (0)
+    switch (KS) {
+      case 2: LAUNCH_CB2(2); break;
+      case 4: LAUNCH_CB2(4); break;
+      case 8: LAUNCH_CB2(8); break;
+      case 12: LAUNCH_CB2(12); break;
+      default: LAUNCH_CB2(16); break;
+    }
+#undef LAUNCH_CB2
+    LAUNCH_CHECKB("k_conv_bwd_bf16");
+    {
+      PROFB("k_sum_slabs_masked");
+      hipLaunchKernelGGL(k_sum_slabs_masked, dim3(min(cdivb(rows, kThreads), 2048)), dim3(kThreads), 0, st,
+                         (const float*)gupart, u, ga, rows, P);
+    }
+    LAUNCH_CHECKB("k_sum_slabs_masked");
+  } else {
     using TL = ConvBwdTileB;
     const dim3 grid(1, s->B, p.ntt);
     const size_t lds = sizeof(bf16_t) * (size_t)(TL::BM + TL::BN) * (TL::BK + 8) + sizeof(float) * (size_t)p.ntt * TL::BM;
