@@ -34,7 +34,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 template <int BM_, int BN_, int BK_, int WGM_, int WGN_>
 struct TileB {
   static constexpr int BM = BM_, BN = BN_, BK = BK_, WGM = WGM_, WGN = WGN_;
-  static_assert(WGM_ * WGN_ == 4, "four waves per workgroup");
+  static constexpr int NW = WGM_ * WGN_;  // waves per workgroup
+  static_assert(NW == 4 || NW == 8, "four or eight waves per workgroup");
+  static constexpr int THREADS = 64 * NW;
   static constexpr int WM = BM / WGM, WN = BN / WGN;
   static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile is made of 32x32 MFMA tiles");
   static constexpr int TM = WM / 32, TN = WN / 32;

@@ -25,27 +25,58 @@ namespace lmufft {
 constexpr int kGldsBK = 64;           // bf16 elements per k-tile
 constexpr int kGldsRowBytes = 128;    // = kGldsBK * 2
 
-// Src: const bf16_t* operator()(int r, int k) -> address of the 8 consecutive
-// elements k..k+7 of tile row r, or the zero line when (r, k) is outside the operand.
-template <int R, class Src>
+// One operand staged by LDS-DMA.  Everything that does not change from k-tile
+// to k-tile is computed ONCE per lane: for each of its NI staging
+// instructions the lane keeps a row pointer (two when the row is the
+// concatenation of two tensors, as [m;x]) and its swizzled column offset.
+// Issuing a k-tile then costs one 64-bit add and a select per instruction;
+// recomputing rows, panels and bounds inside the loop took ~150 vector and
+// ~100 scalar instructions per k-tile and was as expensive as the MFMAs.
+//
+// setup(rowfn, split, kmax): rowfn(r, p0, p1) -> bool fills, for tile row r,
+//   p0 such that p0[k] is element k of the row for k < split and
+//   p1 such that p1[k] is element k for split <= k < kmax; returns false for
+//   rows outside the operand.  Elements at k >= kmax read as zero.
+template <int R, int NW, bool TWO_PIECES>
 struct GldsOperand {
-  static_assert(R % 32 == 0, "four waves stage eight rows per instruction");
+  static_assert(R % (8 * NW) == 0, "every wave stages eight whole rows per instruction");
   static constexpr int STAGE_BYTES = R * kGldsRowBytes;
-  static constexpr int NI = R / 32;  // wave-instructions per wave and stage
-  unsigned char* base;               // LDS, two stages back to back
-  const Src& src;
-  __device__ __forceinline__ GldsOperand(unsigned char* b, const Src& s) : base(b), src(s) {}
+  static constexpr int NI = R / (8 * NW);  // wave-instructions per wave and stage
+  unsigned char* base;                     // LDS, two stages back to back
+  const bf16_t* p0[NI];
+  const bf16_t* p1[NI];
+  unsigned okmask;
+  int koff, split, kmax, wave_off;
+  const bf16_t* zero;
 
-  __device__ __forceinline__ void issue(int stage, int k0) const {
+  template <class RowFn>
+  __device__ __forceinline__ GldsOperand(unsigned char* lds, RowFn&& rowfn, int split_, int kmax_)
+      : base(lds), okmask(0), split(split_), kmax(kmax_) {
+    zero = reinterpret_cast<const bf16_t*>(kZeroBytes);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
+    wave_off = wave * (R / NW) * kGldsRowBytes;
+    koff = 0;  // the swizzled column offset differs per instruction (bit 3 of r enters the swizzle)
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int r0 = wave * (R / 4) + 8 * i;  // wave-uniform
-      const int r = r0 + (lane >> 3);
+      const int r = wave * (R / NW) + 8 * i + (lane >> 3);
+      const bf16_t *q0 = zero, *q1 = zero;
+      const bool ok = rowfn(r, q0, q1);
       const int d = (lane & 7) ^ ((r >> 1) & 7);
-      const bf16_t* p = src(r, k0 + 8 * d);
-      unsigned char* dst = base + stage * STAGE_BYTES + r0 * kGldsRowBytes;
+      p0[i] = q0 + 8 * d;
+      p1[i] = q1 + 8 * d;
+      okmask |= (ok ? 1u : 0u) << i;
+      koff |= (8 * d) << (6 * i);  // 6 bits per instruction (values 0..56)
+    }
+  }
+
+  __device__ __forceinline__ void issue(int stage, int k0) const {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int k = k0 + ((koff >> (6 * i)) & 63);
+      const bf16_t* p = (TWO_PIECES && k >= split) ? p1[i] : p0[i];
+      p = (((okmask >> i) & 1u) && k < kmax) ? p + k0 : zero;
+      unsigned char* dst = base + stage * STAGE_BYTES + wave_off + 8 * i * kGldsRowBytes;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
                                        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
@@ -111,7 +142,7 @@ __device__ __forceinline__ void store_tile_bf16(const f32x16 (&acc)[T::TM][T::TN
   });
   __syncthreads();
   constexpr int CH = T::BN / 8;  // 16-byte chunks per tile row
-  for (int idx = threadIdx.x; idx < T::BM * CH; idx += kThreads) {
+  for (int idx = threadIdx.x; idx < T::BM * CH; idx += T::THREADS) {
     const int m = idx / CH, c = idx % CH;
     const long row = row0 + m;
     const int col = col0 + c * 8;

@@ -237,49 +237,42 @@ __global__ __launch_bounds__(kThreads) void k_proj_fwd_bf16(const bf16_t* __rest
   }
 }
 
-// XCD-aware tile order for grids of (n tiles) x (row tiles, rounded up to a
-// multiple of 8): workgroups are dealt to the 8 XCDs round-robin by linear id,
-// so the n tiles that share one row tile (and therefore its A operand) are
-// given ids that are equal modulo 8 -- they run on one XCD and the A rows are
-// fetched from HBM into one L2 only.  A speed choice, never needed for correctness.
-__device__ __forceinline__ void xcd_tile_order(int& ntile, int& mtile) {
-  const int ntn = gridDim.x;
-  const int L = blockIdx.y * ntn + blockIdx.x;
-  const int group = L / (8 * ntn), rem = L % (8 * ntn);
-  mtile = group * 8 + (rem & 7);
-  ntile = rem >> 3;
-}
-
 // Same GEMM with LDS-DMA staging and 16-byte stores; needs M % 8 == D % 8 == Hd % 8 == 0.
-__global__ __launch_bounds__(kThreads) void k_proj_fwd_glds_bf16(const bf16_t* __restrict__ m,
-                                                                 const bf16_t* __restrict__ x,
-                                                                 const bf16_t* __restrict__ Wb,
-                                                                 const float* __restrict__ bias,
-                                                                 bf16_t* __restrict__ h, bf16_t* __restrict__ h_n,
-                                                                 int rows, int T, int M, int D, int Hd, int ldW) {
-  using TL = ProjTileB;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  int ntile, mtile;
-  xcd_tile_order(ntile, mtile);
-  const int n0 = ntile * TL::BN;
-  const long m0 = (long)mtile * TL::BM;
-  if (m0 >= rows) return;  // (whole workgroup) padding tile of the XCD-aware order
-  const int K = M + D;
-  const bf16_t* zero = reinterpret_cast<const bf16_t*>(kZeroBytes);
+// Tile 128 rows x 384 columns on eight waves: with hidden_size <= 384 every row
+// of [m;x] -- the operand that comes from HBM -- passes through a CU's load path
+// exactly once, and W_h (L2-resident) once per 128 rows.
+using ProjGldsTile = TileB<128, 384, 64, 2, 4>;
 
-  auto sa = [=](int r, int k) -> const bf16_t* {
-    const long row = m0 + r;
-    const bf16_t* p = k < M ? m + row * M + k : x + row * D + (k - M);
-    return (row < rows && k < K) ? p : zero;
-  };
-  auto sb = [=](int r, int k) -> const bf16_t* {
-    const int n = n0 + r;
-    return (n < Hd && k < ldW) ? Wb + (long)n * ldW + k : zero;
-  };
-  typedef GldsOperand<TL::BM, decltype(sa)> OpA;
-  typedef GldsOperand<TL::BN, decltype(sb)> OpB;
-  OpA oa(smem_raw, sa);
-  OpB ob(smem_raw + 2 * OpA::STAGE_BYTES, sb);
+__global__ __launch_bounds__(ProjGldsTile::THREADS) void k_proj_fwd_glds_bf16(
+    const bf16_t* __restrict__ m, const bf16_t* __restrict__ x, const bf16_t* __restrict__ Wb,
+    const float* __restrict__ bias, bf16_t* __restrict__ h, bf16_t* __restrict__ h_n, int rows, int T, int M, int D,
+    int Hd, int ldW) {
+  using TL = ProjGldsTile;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int n0 = blockIdx.x * TL::BN;
+  const long m0 = (long)blockIdx.y * TL::BM;
+  const int K = M + D;
+
+  // A rows are [m[row] ; x[row]]: element k lives at m + row*M + k (k < M) or x + row*D + (k - M)
+  GldsOperand<TL::BM, TL::NW, true> oa(
+      smem_raw,
+      [&](int r, const bf16_t*& q0, const bf16_t*& q1) {
+        const long row = m0 + r;
+        if (row >= rows) return false;
+        q0 = m + row * M;
+        q1 = x + row * D - M;
+        return true;
+      },
+      M, K);
+  GldsOperand<TL::BN, TL::NW, false> ob(
+      smem_raw + 2 * GldsOperand<TL::BM, TL::NW, true>::STAGE_BYTES,
+      [&](int r, const bf16_t*& q0, const bf16_t*&) {
+        const int n = n0 + r;
+        if (n >= Hd) return false;
+        q0 = Wb + (long)n * ldW;
+        return true;
+      },
+      ldW, ldW);
 
   WavePos<TL> w;
   f32x16 acc[TL::TM][TL::TN];
@@ -296,7 +289,7 @@ __global__ __launch_bounds__(kThreads) void k_proj_fwd_glds_bf16(const bf16_t* _
   constexpr int LDT = TL::BN + 8;
   for (long rl = (m0 / T) * T + T - 1; rl < tile_end; rl += T) {
     const int ml = (int)(rl - m0);
-    for (int c = threadIdx.x; c < TL::BN / 8; c += kThreads) {
+    for (int c = threadIdx.x; c < TL::BN / 8; c += TL::THREADS) {
       const int col = n0 + c * 8;
       if (col < Hd)
         *reinterpret_cast<bf16x8*>(h_n + (rl / T) * Hd + col) = *reinterpret_cast<const bf16x8*>(&tile[ml * LDT + c * 8]);
@@ -414,32 +407,34 @@ __global__ __launch_bounds__(kThreads) void k_dgrad_bf16(const bf16_t* __restric
 
 // LDS-DMA form; needs Hd % 8 == 0, ncols % 8 == 0 and 16-byte aligned rows
 template <class TL>
-__global__ __launch_bounds__(kThreads) void k_dgrad_glds_bf16(const bf16_t* __restrict__ gz,
-                                                              const bf16_t* __restrict__ WbT,
-                                                              bf16_t* __restrict__ out,
-                                                              const float* __restrict__ ga,
-                                                              const float* __restrict__ w_u, int rows, int Hd,
-                                                              int ldWT, int j_begin, int ncols) {
+__global__ __launch_bounds__(TL::THREADS) void k_dgrad_glds_bf16(const bf16_t* __restrict__ gz,
+                                                                 const bf16_t* __restrict__ WbT,
+                                                                 bf16_t* __restrict__ out,
+                                                                 const float* __restrict__ ga,
+                                                                 const float* __restrict__ w_u, int rows, int Hd,
+                                                                 int ldWT, int j_begin, int ncols) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  int ntile, mtile;
-  xcd_tile_order(ntile, mtile);
-  const int n0 = ntile * TL::BN;
-  const long m0 = (long)mtile * TL::BM;
-  if (m0 >= rows) return;  // (whole workgroup) padding tile of the XCD-aware order
-  const bf16_t* zero = reinterpret_cast<const bf16_t*>(kZeroBytes);
+  const int n0 = blockIdx.x * TL::BN;
+  const long m0 = (long)blockIdx.y * TL::BM;
 
-  auto sa = [=](int r, int k) -> const bf16_t* {
-    const long row = m0 + r;
-    return (row < rows && k < Hd) ? gz + row * Hd + k : zero;
-  };
-  auto sb = [=](int r, int k) -> const bf16_t* {
-    const int j = n0 + r;
-    return (j < ncols && k < ldWT) ? WbT + (long)(j_begin + j) * ldWT + k : zero;
-  };
-  typedef GldsOperand<TL::BM, decltype(sa)> OpA;
-  typedef GldsOperand<TL::BN, decltype(sb)> OpB;
-  OpA oa(smem_raw, sa);
-  OpB ob(smem_raw + 2 * OpA::STAGE_BYTES, sb);
+  GldsOperand<TL::BM, TL::NW, false> oa(
+      smem_raw,
+      [&](int r, const bf16_t*& q0, const bf16_t*&) {
+        const long row = m0 + r;
+        if (row >= rows) return false;
+        q0 = gz + row * Hd;
+        return true;
+      },
+      Hd, Hd);
+  GldsOperand<TL::BN, TL::NW, false> ob(
+      smem_raw + 2 * GldsOperand<TL::BM, TL::NW, false>::STAGE_BYTES,
+      [&](int r, const bf16_t*& q0, const bf16_t*&) {
+        const int j = n0 + r;
+        if (j >= ncols) return false;
+        q0 = WbT + (long)(j_begin + j) * ldWT;
+        return true;
+      },
+      ldWT, ldWT);
 
   WavePos<TL> w;
   f32x16 acc[TL::TM][TL::TN];
@@ -454,8 +449,9 @@ __global__ __launch_bounds__(kThreads) void k_dgrad_glds_bf16(const bf16_t* __re
                       [&](int tm, int tn, int i, int, int, float v) { return v + grow[tm][i] * wcol[tn]; });
 }
 
-using DgradMTileB = TileB<128, 192, 64, 2, 2>;
-using DgradXTileB = TileB<128, 128, 64, 2, 2>;
+using DgradMTileB = TileB<128, 192, 64, 2, 2>;   // memory columns (M = 192): one column tile
+using DgradXTileB = TileB<128, 128, 64, 2, 2>;   // register-staged fallback for the input columns
+using DgradXGldsTile = TileB<128, 384, 64, 2, 4>;  // input columns, LDS-DMA form, eight waves
 
 // ---------------------------------------------------------------------------
 // gu partial slabs: P[i][tau] = sum_k gm[t0+i][k] H[k][tau], summed along the
@@ -957,16 +953,17 @@ int lmufft_forward_bf16(const lmufft_shape* s, const void* x_, const float* w_u,
     using TL = ProjTileB;
     const bool vec = (s->M % 8 == 0) && (s->D % 8 == 0) && (s->Hd % 8 == 0) && al16(m) && al16(x) && al16(h) &&
                      al16(h_n);
-    if (vec) {  // LDS-DMA staging, XCD-aware tile order (row tiles rounded up to a multiple of 8)
-      const dim3 grid(cdivb(s->Hd, TL::BN), cdivb(cdivb(rows, TL::BM), 8) * 8);
-      const size_t lds = 2 * (size_t)(TL::BM + TL::BN) * kGldsRowBytes;
-      static_assert(2 * (TL::BM + TL::BN) * kGldsRowBytes >= TL::BM * (TL::BN + 8) * 2, "epilogue tile fits");
+    if (vec) {  // LDS-DMA staging
+      using TG = ProjGldsTile;
+      const dim3 grid(cdivb(s->Hd, TG::BN), cdivb(rows, TG::BM));
+      const size_t lds = 2 * (size_t)(TG::BM + TG::BN) * kGldsRowBytes;
+      static_assert(2 * (TG::BM + TG::BN) * kGldsRowBytes >= TG::BM * (TG::BN + 8) * 2, "epilogue tile fits");
       if (hipFuncSetAttribute((const void*)k_proj_fwd_glds_bf16, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds) != hipSuccess)
         return set_error("cannot reserve %zu bytes of LDS for k_proj_fwd_glds_bf16", lds);
       {
         PROFB("k_proj_fwd_bf16");
-        hipLaunchKernelGGL(k_proj_fwd_glds_bf16, grid, dim3(kThreads), lds, st, m, x, Wb, b_h, h, h_n, (int)rows,
+        hipLaunchKernelGGL(k_proj_fwd_glds_bf16, grid, dim3(TG::THREADS), lds, st, m, x, Wb, b_h, h, h_n, (int)rows,
                            s->T, s->M, s->D, s->Hd, ldW);
       }
     } else {
@@ -1037,24 +1034,26 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
   }
 
   // out = gz W_h[:, j_begin : j_begin + ncols] (+ ga w_u), LDS-DMA kernel when everything is 16-byte friendly
-  auto dgrad = [&](auto tile_tag, bf16_t* out, int j_begin, int ncols, const float* ga_, const float* wu_) -> int {
-    using TL = decltype(tile_tag);
+  auto dgrad = [&](auto glds_tag, auto fallback_tag, bf16_t* out, int j_begin, int ncols, const float* ga_,
+                   const float* wu_) -> int {
+    using TG = decltype(glds_tag);
+    using TF = decltype(fallback_tag);
     const bool fast = (s->Hd % 8 == 0) && (ncols % 8 == 0) && al16(out);
     if (fast) {
-      const dim3 grid(cdivb(ncols, TL::BN), cdivb(cdivb(rows, TL::BM), 8) * 8);
-      const size_t lds = 2 * (size_t)(TL::BM + TL::BN) * kGldsRowBytes;
-      static_assert(2 * (TL::BM + TL::BN) * kGldsRowBytes >= TL::BM * (TL::BN + 8) * 2, "epilogue tile fits");
-      if (hipFuncSetAttribute((const void*)k_dgrad_glds_bf16<TL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      const dim3 grid(cdivb(ncols, TG::BN), cdivb(rows, TG::BM));
+      const size_t lds = 2 * (size_t)(TG::BM + TG::BN) * kGldsRowBytes;
+      static_assert(2 * (TG::BM + TG::BN) * kGldsRowBytes >= TG::BM * (TG::BN + 8) * 2, "epilogue tile fits");
+      if (hipFuncSetAttribute((const void*)k_dgrad_glds_bf16<TG>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds) != hipSuccess)
         return set_error("cannot reserve %zu bytes of LDS for k_dgrad_glds_bf16", lds);
       PROFB("k_dgrad_bf16");
-      hipLaunchKernelGGL(k_dgrad_glds_bf16<TL>, grid, dim3(kThreads), lds, st, (const bf16_t*)gz, WbT, out, ga_, wu_,
-                         (int)rows, s->Hd, wl.ldWT, j_begin, ncols);
+      hipLaunchKernelGGL(k_dgrad_glds_bf16<TG>, grid, dim3(TG::THREADS), lds, st, (const bf16_t*)gz, WbT, out, ga_,
+                         wu_, (int)rows, s->Hd, wl.ldWT, j_begin, ncols);
     } else {
-      const dim3 grid(cdivb(ncols, TL::BN), cdivb(rows, TL::BM));
-      const size_t lds = sizeof(bf16_t) * (size_t)(TL::BM + TL::BN) * (TL::BK + 8);
+      const dim3 grid(cdivb(ncols, TF::BN), cdivb(rows, TF::BM));
+      const size_t lds = sizeof(bf16_t) * (size_t)(TF::BM + TF::BN) * (TF::BK + 8);
       PROFB("k_dgrad_bf16");
-      hipLaunchKernelGGL((k_dgrad_bf16<TL, false>), grid, dim3(kThreads), lds, st, (const bf16_t*)gz, WbT, out, ga_,
+      hipLaunchKernelGGL((k_dgrad_bf16<TF, false>), grid, dim3(kThreads), lds, st, (const bf16_t*)gz, WbT, out, ga_,
                          wu_, (int)rows, s->Hd, wl.ldWT, j_begin, ncols);
     }
     LAUNCH_CHECKB("k_dgrad_bf16");
@@ -1062,7 +1061,7 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
   };
 
   // gm = gz W_h[:, :M]
-  if (int rc = dgrad(DgradMTileB{}, gm, 0, s->M, nullptr, nullptr)) return rc;
+  if (int rc = dgrad(DgradMTileB{}, DgradMTileB{}, gm, 0, s->M, nullptr, nullptr)) return rc;
   // ga = (adjoint conv of gm) * (u > 0)
   const int KS = cdivb(s->M, 16);
   if (s->M % 8 == 0 && al16(gm) && (KS == 2 || KS == 4 || KS == 8 || KS == 12 || KS == 16)) {
@@ -1120,7 +1119,7 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
   }
   // gx = gz W_h[:, M:] + ga w_u
   if (gx)
-    if (int rc = dgrad(DgradXTileB{}, gx, s->M, s->D, (const float*)ga, w_u)) return rc;
+    if (int rc = dgrad(DgradXGldsTile{}, DgradXTileB{}, gx, s->M, s->D, (const float*)ga, w_u)) return rc;
   {  // gW_h
     using TL = WgradTileB;
     const bool vec = (s->Hd % 8 == 0) && (s->M % 8 == 0) && (s->D % 8 == 0) && al16(m) && al16(x);
