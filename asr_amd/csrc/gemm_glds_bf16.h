@@ -22,7 +22,7 @@
 
 namespace lmufft {
 
-constexpr int kGldsBK = 64;           // bf16 elements per k-tile
+constexpr int kGldsBK = 64;           // bf16 elements per k-tile of the two-stage loop
 constexpr int kGldsRowBytes = 128;    // = kGldsBK * 2
 
 // One operand staged by LDS-DMA.  Everything that does not change from k-tile
@@ -37,11 +37,21 @@ constexpr int kGldsRowBytes = 128;    // = kGldsBK * 2
 //   p0 such that p0[k] is element k of the row for k < split and
 //   p1 such that p1[k] is element k for split <= k < kmax; returns false for
 //   rows outside the operand.  Elements at k >= kmax read as zero.
-template <int R, int NW, bool TWO_PIECES>
+//
+// BK = 64 (128-byte LDS rows, 8 rows per wave-instruction, swizzle (r >> 1) & 7) or
+// BK = 32 ( 64-byte LDS rows, 16 rows per wave-instruction, swizzle (r >> 2) & 3):
+// in both cases the 16 rows of a ds_read_b128 lane group fall on 16 distinct
+// 16-byte slots of the 256-byte bank row.
+template <int R, int NW, bool TWO_PIECES, int BK = 64>
 struct GldsOperand {
-  static_assert(R % (8 * NW) == 0, "every wave stages eight whole rows per instruction");
-  static constexpr int STAGE_BYTES = R * kGldsRowBytes;
-  static constexpr int NI = R / (8 * NW);  // wave-instructions per wave and stage
+  static_assert(BK == 64 || BK == 32, "k-tile of 64 or 32");
+  static constexpr int ROWB = BK * 2;        // bytes per LDS row
+  static constexpr int RPI = 1024 / ROWB;    // rows per wave-instruction
+  static constexpr int CPR = ROWB / 16;      // 16-byte chunks per row
+  static_assert(R % (RPI * NW) == 0, "every wave stages whole rows");
+  static constexpr int STAGE_BYTES = R * ROWB;
+  static constexpr int NI = R / (RPI * NW);  // wave-instructions per wave and stage
+  __device__ static __forceinline__ int swz(int r) { return BK == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
   unsigned char* base;                     // LDS, two stages back to back
   const bf16_t* p0[NI];
   const bf16_t* p1[NI];
@@ -55,14 +65,14 @@ struct GldsOperand {
     zero = reinterpret_cast<const bf16_t*>(kZeroBytes);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    wave_off = wave * (R / NW) * kGldsRowBytes;
+    wave_off = wave * (R / NW) * ROWB;
     koff = 0;  // the swizzled column offset differs per instruction (bit 3 of r enters the swizzle)
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int r = wave * (R / NW) + 8 * i + (lane >> 3);
+      const int r = wave * (R / NW) + RPI * i + lane / CPR;
       const bf16_t *q0 = zero, *q1 = zero;
       const bool ok = rowfn(r, q0, q1);
-      const int d = (lane & 7) ^ ((r >> 1) & 7);
+      const int d = (lane % CPR) ^ swz(r);
       p0[i] = q0 + 8 * d;
       p1[i] = q1 + 8 * d;
       okmask |= (ok ? 1u : 0u) << i;
@@ -76,14 +86,14 @@ struct GldsOperand {
       const int k = k0 + ((koff >> (6 * i)) & 63);
       const bf16_t* p = (TWO_PIECES && k >= split) ? p1[i] : p0[i];
       p = (((okmask >> i) & 1u) && k < kmax) ? p + k0 : zero;
-      unsigned char* dst = base + stage * STAGE_BYTES + wave_off + 8 * i * kGldsRowBytes;
+      unsigned char* dst = base + stage * STAGE_BYTES + wave_off + i * 1024;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
                                        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
   }
   __device__ __forceinline__ bf16x8 frag(int stage, int row, int kl, int hh) const {
     const int d = (kl >> 3) + hh;
-    const unsigned char* a = base + stage * STAGE_BYTES + row * kGldsRowBytes + ((d ^ ((row >> 1) & 7)) << 4);
+    const unsigned char* a = base + stage * STAGE_BYTES + row * ROWB + ((d ^ swz(row)) << 4);
     return *reinterpret_cast<const bf16x8*>(a);
   }
 };
@@ -122,6 +132,54 @@ __device__ __forceinline__ void gemm_loop_glds(const OA& a, const OB& b, f32x16 
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bfr[tn], acc[tm][tn], 0, 0, 0);
     }
   }
+  __syncthreads();  // the stages may be reused (epilogue staging) after this
+}
+
+// Deeper form: NS LDS stages of BK = 32, NS - 1 k-tiles in flight at all times.
+// The two-stage loop drains the load queue at every k-tile (vmcnt(0) before the
+// barrier), so a CU has one tile in flight only while it multiplies the
+// previous one; here the wait is COUNTED -- all but the newest NS - 2 tiles --
+// and the barrier is a raw s_barrier, so loads stay in flight across it.
+// Every iteration issues the same number of LDS-DMA instructions (tiles beyond
+// kend are fetched from the zero line), which is what makes the count valid.
+// All LDS of the kernel must live in the one dynamic array the stages are carved from.
+template <class T, int NS, class OA, class OB>
+__device__ __forceinline__ void gemm_loop_glds_deep(const OA& a, const OB& b, f32x16 (&acc)[T::TM][T::TN],
+                                                    int kbeg, int kend, const WavePos<T>& w, int dbg = 0) {
+  static_assert(T::BK == 32, "k-tile of 32");
+  constexpr int G = OA::NI + OB::NI;          // LDS-DMA instructions per wave and k-tile
+  constexpr int KEEP = G * (NS - 2);          // may stay outstanding when a tile is consumed
+  static_assert(KEEP <= 63, "vmcnt is a 6-bit counter");
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) {
+    a.issue(s, kbeg + s * T::BK);
+    b.issue(s, kbeg + s * T::BK);
+  }
+  int stage = 0, pf = NS - 1;
+  for (int k0 = kbeg; k0 < kend; k0 += T::BK) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
+    __builtin_amdgcn_s_barrier();
+    a.issue(pf, k0 + (NS - 1) * T::BK);
+    b.issue(pf, k0 + (NS - 1) * T::BK);
+    if (!(dbg & 1)) {
+#pragma unroll
+    for (int kl = 0; kl < T::BK; kl += 16) {
+      bf16x8 af[T::TM], bfr[T::TN];
+#pragma unroll
+      for (int tm = 0; tm < T::TM; ++tm) af[tm] = a.frag(stage, w.wm0 + tm * 32 + w.r, kl, w.hh);
+#pragma unroll
+      for (int tn = 0; tn < T::TN; ++tn) bfr[tn] = b.frag(stage, w.wn0 + tn * 32 + w.r, kl, w.hh);
+#pragma unroll
+      for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < T::TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bfr[tn], acc[tm][tn], 0, 0, 0);
+    }
+    }
+    stage = stage + 1 == NS ? 0 : stage + 1;
+    pf = pf + 1 == NS ? 0 : pf + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing zero-line tiles
   __syncthreads();  // the stages may be reused (epilogue staging) after this
 }
 

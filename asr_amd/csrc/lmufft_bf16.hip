@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "gemm_core_bf16.h"
@@ -241,12 +243,13 @@ __global__ __launch_bounds__(kThreads) void k_proj_fwd_bf16(const bf16_t* __rest
 // Tile 128 rows x 384 columns on eight waves: with hidden_size <= 384 every row
 // of [m;x] -- the operand that comes from HBM -- passes through a CU's load path
 // exactly once, and W_h (L2-resident) once per 128 rows.
-using ProjGldsTile = TileB<128, 384, 64, 2, 4>;
+using ProjGldsTile = TileB<128, 384, 32, 2, 4>;
+constexpr int kProjStages = 4;
 
 __global__ __launch_bounds__(ProjGldsTile::THREADS) void k_proj_fwd_glds_bf16(
     const bf16_t* __restrict__ m, const bf16_t* __restrict__ x, const bf16_t* __restrict__ Wb,
     const float* __restrict__ bias, bf16_t* __restrict__ h, bf16_t* __restrict__ h_n, int rows, int T, int M, int D,
-    int Hd, int ldW) {
+    int Hd, int ldW, int dbg) {
   using TL = ProjGldsTile;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int n0 = blockIdx.x * TL::BN;
@@ -254,21 +257,23 @@ __global__ __launch_bounds__(ProjGldsTile::THREADS) void k_proj_fwd_glds_bf16(
   const int K = M + D;
 
   // A rows are [m[row] ; x[row]]: element k lives at m + row*M + k (k < M) or x + row*D + (k - M)
-  GldsOperand<TL::BM, TL::NW, true> oa(
+  typedef GldsOperand<TL::BM, TL::NW, true, TL::BK> OpA;
+  typedef GldsOperand<TL::BN, TL::NW, false, TL::BK> OpB;
+  OpA oa(
       smem_raw,
       [&](int r, const bf16_t*& q0, const bf16_t*& q1) {
         const long row = m0 + r;
-        if (row >= rows) return false;
+        if (row >= rows || (dbg & 4)) return false;
         q0 = m + row * M;
         q1 = x + row * D - M;
         return true;
       },
       M, K);
-  GldsOperand<TL::BN, TL::NW, false> ob(
-      smem_raw + 2 * GldsOperand<TL::BM, TL::NW, true>::STAGE_BYTES,
+  OpB ob(
+      smem_raw + kProjStages * OpA::STAGE_BYTES,
       [&](int r, const bf16_t*& q0, const bf16_t*&) {
         const int n = n0 + r;
-        if (n >= Hd) return false;
+        if (n >= Hd || (dbg & 8)) return false;
         q0 = Wb + (long)n * ldW;
         return true;
       },
@@ -277,7 +282,8 @@ __global__ __launch_bounds__(ProjGldsTile::THREADS) void k_proj_fwd_glds_bf16(
   WavePos<TL> w;
   f32x16 acc[TL::TM][TL::TN];
   tileb_zero<TL>(acc);
-  gemm_loop_glds<TL>(oa, ob, acc, 0, K, w);
+  gemm_loop_glds_deep<TL, kProjStages>(oa, ob, acc, 0, K, w, dbg);
+  if (dbg & 2) return;
 
   float bcol[TL::TN];
   preload_cols<TL>(bcol, w, [&](int nn) { return n0 + nn < Hd ? bias[n0 + nn] : 0.f; });
@@ -787,7 +793,7 @@ static WprepLayout wprep_layout(const lmufft_shape& s) {
   return l;
 }
 
-constexpr int kReluRowsPerBlock = 128;
+constexpr int kReluRowsPerBlock = 40;
 
 struct BwdPlanB {
   int S, rps, ntt, enc_blocks, relu_blocks, cb2_P;
@@ -798,7 +804,7 @@ static BwdPlanB plan_backward_b(const lmufft_shape& s) {
   const long rows = (long)s.B * s.T;
   const int MD = s.M + s.D;
   const int tiles = cdivb(s.Hd, WgradTileB::BM) * cdivb(MD, WgradTileB::BN);
-  int S = (2 * 256 + tiles - 1) / tiles;  // about two workgroups per CU
+  int S = (256 + tiles - 1) / tiles;  // about one workgroup per CU: every slab costs a write and a read of gW_h
   int rps = cdivb(rows, S);
   rps = cdivb(rps, WgradTileB::BK) * WgradTileB::BK;
   p.S = cdivb(rows, rps);
@@ -956,15 +962,16 @@ int lmufft_forward_bf16(const lmufft_shape* s, const void* x_, const float* w_u,
     if (vec) {  // LDS-DMA staging
       using TG = ProjGldsTile;
       const dim3 grid(cdivb(s->Hd, TG::BN), cdivb(rows, TG::BM));
-      const size_t lds = 2 * (size_t)(TG::BM + TG::BN) * kGldsRowBytes;
-      static_assert(2 * (TG::BM + TG::BN) * kGldsRowBytes >= TG::BM * (TG::BN + 8) * 2, "epilogue tile fits");
+      const size_t lds = (size_t)kProjStages * (TG::BM + TG::BN) * TG::BK * 2;
+      static_assert(kProjStages * (TG::BM + TG::BN) * TG::BK * 2 >= TG::BM * (TG::BN + 8) * 2, "epilogue tile fits");
       if (hipFuncSetAttribute((const void*)k_proj_fwd_glds_bf16, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds) != hipSuccess)
         return set_error("cannot reserve %zu bytes of LDS for k_proj_fwd_glds_bf16", lds);
       {
         PROFB("k_proj_fwd_bf16");
+        static const int dbg = getenv("LMUFFT_DBG") ? atoi(getenv("LMUFFT_DBG")) : 0;
         hipLaunchKernelGGL(k_proj_fwd_glds_bf16, grid, dim3(TG::THREADS), lds, st, m, x, Wb, b_h, h, h_n, (int)rows,
-                           s->T, s->M, s->D, s->Hd, ldW);
+                           s->T, s->M, s->D, s->Hd, ldW, dbg);
       }
     } else {
       const dim3 grid(cdivb(s->Hd, TL::BN), cdivb(rows, TL::BM));
