@@ -1,5 +1,7 @@
 """MI355X-native implementation of the FFT-LMU hot path (LMUFFT layer)."""
 from .lmu import LMU, LMUFFT  # noqa: F401
-from .functional import causal_conv, causal_conv_adjoint, lmufft_layer  # noqa: F401
+from .functional import (causal_conv, causal_conv_adjoint, lmufft_layer,  # noqa: F401
+                         prepare_impulse_bf16, prepare_impulse_fft)
 
-__all__ = ["LMUFFT", "LMU", "lmufft_layer", "causal_conv", "causal_conv_adjoint"]
+__all__ = ["LMUFFT", "LMU", "lmufft_layer", "causal_conv", "causal_conv_adjoint", "prepare_impulse_bf16",
+           "prepare_impulse_fft"]

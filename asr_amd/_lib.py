@@ -17,7 +17,7 @@ BF16 = 1
 CONV_AUTO = 0
 CONV_TOEPLITZ = 1
 CONV_FFT = 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class Shape(ctypes.Structure):
@@ -54,13 +54,17 @@ def _load():
     lib.lmufft_conv_workspace_bytes.restype = sz
     lib.lmufft_conv_workspace_bytes.argtypes = [sp, ci, ci]
     lib.lmufft_forward_f32.restype = ci
-    lib.lmufft_forward_f32.argtypes = [sp] + [vp] * 10 + [ci, vp, sz, vp]
+    lib.lmufft_forward_f32.argtypes = [sp] + [vp] * 11 + [ci, vp, sz, vp]
     lib.lmufft_backward_f32.restype = ci
-    lib.lmufft_backward_f32.argtypes = [sp] + [vp] * 15 + [ci, vp, sz, vp]
+    lib.lmufft_backward_f32.argtypes = [sp] + [vp] * 16 + [ci, vp, sz, vp]
     lib.lmufft_conv_forward_f32.restype = ci
-    lib.lmufft_conv_forward_f32.argtypes = [sp, vp, vp, vp, ci, vp, sz, vp]
+    lib.lmufft_conv_forward_f32.argtypes = [sp, vp, vp, vp, vp, ci, vp, sz, vp]
     lib.lmufft_conv_backward_f32.restype = ci
-    lib.lmufft_conv_backward_f32.argtypes = [sp, vp, vp, vp, ci, vp, sz, vp]
+    lib.lmufft_conv_backward_f32.argtypes = [sp, vp, vp, vp, vp, ci, vp, sz, vp]
+    lib.lmufft_fftprep_bytes.restype = sz
+    lib.lmufft_fftprep_bytes.argtypes = [sp]
+    lib.lmufft_fftprep_f32.restype = ci
+    lib.lmufft_fftprep_f32.argtypes = [sp, vp, vp, vp]
     lib.lmufft_hprep_bytes.restype = sz
     lib.lmufft_hprep_bytes.argtypes = [sp]
     lib.lmufft_hprep_bf16.restype = ci
@@ -101,6 +105,8 @@ EXPORTS = (
     "lmufft_conv_workspace_bytes",
     "lmufft_conv_forward_f32",
     "lmufft_conv_backward_f32",
+    "lmufft_fftprep_bytes",
+    "lmufft_fftprep_f32",
     "lmufft_hprep_bytes",
     "lmufft_hprep_bf16",
     "lmufft_wprep_bytes",

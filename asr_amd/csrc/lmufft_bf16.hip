@@ -609,26 +609,6 @@ __global__ __launch_bounds__(kThreads) void k_conv_bwd2_bf16(const bf16_t* __res
   }
 }
 
-// out[i] = sum_p part[p * n + i], optionally masked by u[i] > 0 (ReLU of the encoder)
-__global__ __launch_bounds__(kThreads) void k_sum_slabs_masked(const float* __restrict__ part,
-                                                               const float* __restrict__ u, float* __restrict__ out,
-                                                               long n, int P) {
-  for (long i = blockIdx.x * (long)kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int p = 0;
-    for (; p + 4 <= P; p += 4) {
-      s0 += part[(long)p * n + i];
-      s1 += part[(long)(p + 1) * n + i];
-      s2 += part[(long)(p + 2) * n + i];
-      s3 += part[(long)(p + 3) * n + i];
-    }
-    for (; p < P; ++p) s0 += part[(long)p * n + i];
-    float s = (s0 + s1) + (s2 + s3);
-    if (u) s = u[i] > 0.f ? s : 0.f;
-    out[i] = s;
-  }
-}
-
 // ---------------------------------------------------------------------------
 // gW_h[n][j] = sum_rows gz[row][n] [m;x][row][j]
 // k = frame index: both operands are k-strided in HBM -> transposed LDS reads.
@@ -1096,12 +1076,7 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
     }
 #undef LAUNCH_CB2
     LAUNCH_CHECKB("k_conv_bwd_bf16");
-    {
-      PROFB("k_sum_slabs_masked");
-      hipLaunchKernelGGL(k_sum_slabs_masked, dim3(min(cdivb(rows, kThreads), 2048)), dim3(kThreads), 0, st,
-                         (const float*)gupart, u, ga, rows, P);
-    }
-    LAUNCH_CHECKB("k_sum_slabs_masked");
+    if (int rc = launch_sum_slabs_masked(gupart, u, ga, rows, P, st)) return rc;
   } else {
     using TL = ConvBwdTileB;
     const dim3 grid(1, s->B, p.ntt);

@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "gemm_core_f32.h"
@@ -523,6 +524,26 @@ __global__ __launch_bounds__(kThreads) void k_reduce_slabs_tall(const float* __r
   }
 }
 
+// out[i] = sum_p part[p * n + i], optionally masked by u[i] > 0 (ReLU of the encoder)
+__global__ __launch_bounds__(kThreads) void k_sum_slabs_masked(const float* __restrict__ part,
+                                                               const float* __restrict__ u, float* __restrict__ out,
+                                                               long n, int P) {
+  for (long i = blockIdx.x * (long)kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int p = 0;
+    for (; p + 4 <= P; p += 4) {
+      s0 += part[(long)p * n + i];
+      s1 += part[(long)(p + 1) * n + i];
+      s2 += part[(long)(p + 2) * n + i];
+      s3 += part[(long)(p + 3) * n + i];
+    }
+    for (; p < P; ++p) s0 += part[(long)p * n + i];
+    float s = (s0 + s1) + (s2 + s3);
+    if (u) s = u[i] > 0.f ? s : 0.f;
+    out[i] = s;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -558,7 +579,7 @@ static BwdPlan plan_backward(const lmufft_shape& s) {
   p.off_wslab = off;
   off += align256(sizeof(float) * (size_t)p.S * ((size_t)s.Hd * MD + s.Hd));
   p.off_gupart = off;
-  off += align256(sizeof(float) * (size_t)s.B * p.ntt * s.T);
+  off += align256(sizeof(float) * (size_t)s.B * std::max(p.ntt, fft_conv_groups(s.M)) * s.T);
   p.off_ga = off;
   off += align256(sizeof(float) * (size_t)rows);
   p.off_encpart = off;
@@ -621,6 +642,32 @@ int launch_gu_reduce(const float* gu_part, const float* u, float* out, int B, in
                        T, ntt, tile_t);
   }
   LAUNCH_CHECK("k_gu_reduce");
+  return 0;
+}
+
+int launch_sum_slabs_masked(const float* part, const float* u, float* out, long n, int P, hipStream_t st) {
+  {
+    PROF("k_sum_slabs_masked");
+    hipLaunchKernelGGL(k_sum_slabs_masked, dim3(min(cdiv(n, kThreads), 2048)), dim3(kThreads), 0, st, part, u, out,
+                       n, P);
+  }
+  LAUNCH_CHECK("k_sum_slabs_masked");
+  return 0;
+}
+
+// FFT route when the caller supplied prepared spectra and the kernels can take T; Toeplitz otherwise
+static bool use_fft(const lmufft_shape& s, int conv_algo, const void* fftprep) {
+  if (conv_algo == LMUFFT_CONV_TOEPLITZ) return false;
+  if (conv_algo == LMUFFT_CONV_FFT) return true;
+  return fftprep != nullptr && fft_length(s.T) != 0;
+}
+static int check_algo(const lmufft_shape& s, int conv_algo, const void* fftprep) {
+  if (conv_algo != LMUFFT_CONV_AUTO && conv_algo != LMUFFT_CONV_TOEPLITZ && conv_algo != LMUFFT_CONV_FFT)
+    return set_error("unknown convolution algorithm %d", conv_algo);
+  if (conv_algo == LMUFFT_CONV_FFT) {
+    if (!fftprep) return set_error("the FFT convolution needs the prepared spectra (lmufft_fftprep_f32)");
+    if (!fft_length(s.T)) return set_error("the LDS-resident FFT convolution supports T <= 512 (got %d)", s.T);
+  }
   return 0;
 }
 
@@ -692,44 +739,58 @@ size_t lmufft_conv_workspace_bytes(const lmufft_shape* s, int dtype, int conv_al
   (void)conv_algo;
   if (!s || s->B <= 0 || s->T <= 0) return 0;
   const int ntt = cdiv(s->T, ConvBwdTile::BM);
-  return align256(sizeof(float) * (size_t)s->B * ntt * s->T);
+  return align256(sizeof(float) * (size_t)s->B * std::max(ntt, fft_conv_groups(s->M)) * s->T);
 }
 
-int lmufft_conv_forward_f32(const lmufft_shape* s, const float* u, const float* H, float* m, int conv_algo,
-                            void* workspace, size_t workspace_bytes, void* stream) {
+size_t lmufft_fftprep_bytes(const lmufft_shape* s) {
+  if (!s || s->M <= 0 || s->T <= 0) return 0;
+  return fftprep_bytes(s->M, s->T);
+}
+
+int lmufft_fftprep_f32(const lmufft_shape* s, const float* H, void* fftprep, void* stream) {
+  if (!s || s->M <= 0 || s->T <= 0 || s->T > s->ldH) return set_error("fftprep: bad shape");
+  if (!H || !fftprep) return set_error("fftprep: NULL pointer");
+  return fft_prepare(*s, H, fftprep, (hipStream_t)stream);
+}
+
+int lmufft_conv_forward_f32(const lmufft_shape* s, const float* u, const float* H, const void* fftprep, float* m,
+                            int conv_algo, void* workspace, size_t workspace_bytes, void* stream) {
   (void)workspace;
   (void)workspace_bytes;
   if (!s || s->B <= 0 || s->T <= 0 || s->M <= 0) return set_error("conv: bad shape");
   if (s->T > s->ldH) return set_error("sequence length %d exceeds the impulse response length %d", s->T, s->ldH);
   if (!u || !H || !m) return set_error("conv: NULL pointer");
-  if (conv_algo != LMUFFT_CONV_AUTO && conv_algo != LMUFFT_CONV_TOEPLITZ)
-    return set_error("conv algorithm %d is not available", conv_algo);
+  if (int rc = check_algo(*s, conv_algo, fftprep)) return rc;
+  if (use_fft(*s, conv_algo, fftprep)) return fft_conv_forward(*s, u, fftprep, m, (hipStream_t)stream);
   return conv_forward_toeplitz(*s, u, H, m, (hipStream_t)stream);
 }
 
-int lmufft_conv_backward_f32(const lmufft_shape* s, const float* gm, const float* H, float* gu, int conv_algo,
-                             void* workspace, size_t workspace_bytes, void* stream) {
+int lmufft_conv_backward_f32(const lmufft_shape* s, const float* gm, const float* H, const void* fftprep,
+                             float* gu, int conv_algo, void* workspace, size_t workspace_bytes, void* stream) {
   if (!s || s->B <= 0 || s->T <= 0 || s->M <= 0) return set_error("conv: bad shape");
   if (s->T > s->ldH) return set_error("sequence length %d exceeds the impulse response length %d", s->T, s->ldH);
   if (!gm || !H || !gu) return set_error("conv: NULL pointer");
-  if (conv_algo != LMUFFT_CONV_AUTO && conv_algo != LMUFFT_CONV_TOEPLITZ)
-    return set_error("conv algorithm %d is not available", conv_algo);
+  if (int rc = check_algo(*s, conv_algo, fftprep)) return rc;
   const size_t need = lmufft_conv_workspace_bytes(s, LMUFFT_F32, conv_algo);
   if (!workspace || workspace_bytes < need)
     return set_error("conv backward: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
-  return conv_backward_toeplitz(*s, gm, H, nullptr, (float*)workspace, gu, (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  if (use_fft(*s, conv_algo, fftprep)) {
+    if (int rc = fft_conv_backward(*s, gm, fftprep, (float*)workspace, st)) return rc;
+    return launch_sum_slabs_masked((const float*)workspace, nullptr, gu, (long)s->B * s->T, fft_conv_groups(s->M), st);
+  }
+  return conv_backward_toeplitz(*s, gm, H, nullptr, (float*)workspace, gu, st);
 }
 
 int lmufft_forward_f32(const lmufft_shape* s, const float* x, const float* w_u, const float* b_u,
-                       const float* W_h, const float* b_h, const float* H, float* u, float* m, float* h,
-                       float* h_n, int conv_algo, void* workspace, size_t workspace_bytes, void* stream) {
+                       const float* W_h, const float* b_h, const float* H, const void* fftprep, float* u, float* m,
+                       float* h, float* h_n, int conv_algo, void* workspace, size_t workspace_bytes, void* stream) {
   (void)workspace;
   (void)workspace_bytes;
   if (int rc = check_shape(s)) return rc;
   if (!x || !w_u || !b_u || !W_h || !b_h || !H || !u || !m || !h || !h_n)
     return set_error("forward: NULL pointer");
-  if (conv_algo != LMUFFT_CONV_AUTO && conv_algo != LMUFFT_CONV_TOEPLITZ)
-    return set_error("conv algorithm %d is not available", conv_algo);
+  if (int rc = check_algo(*s, conv_algo, fftprep)) return rc;
   hipStream_t st = (hipStream_t)stream;
   const long rows = (long)s->B * s->T;
   const int MD = s->M + s->D;
@@ -746,7 +807,11 @@ int lmufft_forward_f32(const lmufft_shape* s, const float* x, const float* w_u, 
     }
     LAUNCH_CHECK("k_encode_fwd");
   }
-  if (int rc = conv_forward_toeplitz(*s, u, H, m, st)) return rc;  // eq. 26
+  if (use_fft(*s, conv_algo, fftprep)) {  // eq. 26
+    if (int rc = fft_conv_forward(*s, u, fftprep, m, st)) return rc;
+  } else {
+    if (int rc = conv_forward_toeplitz(*s, u, H, m, st)) return rc;
+  }
   {  // eq. 20
     using TL = ProjTile;
     const bool vec = (s->M % 4 == 0) && (s->D % 4 == 0) && aligned16(m) && aligned16(x) && aligned16(W_h);
@@ -768,14 +833,14 @@ int lmufft_forward_f32(const lmufft_shape* s, const float* x, const float* w_u, 
 }
 
 int lmufft_backward_f32(const lmufft_shape* s, const float* x, const float* w_u, const float* W_h,
-                        const float* H, const float* u, const float* m, const float* h, const float* gh,
+                        const float* H, const void* fftprep, const float* u, const float* m, const float* h,
+                        const float* gh,
                         const float* gh_n, float* gx, float* gw_u, float* gb_u, float* gW_h, float* gb_h,
                         float* gm, int conv_algo, void* workspace, size_t workspace_bytes, void* stream) {
   if (int rc = check_shape(s)) return rc;
   if (!x || !w_u || !W_h || !H || !u || !m || !h || !gw_u || !gb_u || !gW_h || !gb_h || !gm)
     return set_error("backward: NULL pointer");
-  if (conv_algo != LMUFFT_CONV_AUTO && conv_algo != LMUFFT_CONV_TOEPLITZ)
-    return set_error("conv algorithm %d is not available", conv_algo);
+  if (int rc = check_algo(*s, conv_algo, fftprep)) return rc;
   const BwdPlan p = plan_backward(*s);
   if (!workspace || workspace_bytes < p.total)
     return set_error("backward: workspace of %zu bytes needed, %zu given", p.total, workspace_bytes);
@@ -810,7 +875,12 @@ int lmufft_backward_f32(const lmufft_shape* s, const float* x, const float* w_u,
   // gm = gz W_h[:, :M]
   if (int rc = dgrad(gm, 0, s->M, nullptr, nullptr)) return rc;
   // ga = (adjoint conv of gm) * (u > 0)
-  if (int rc = conv_backward_toeplitz(*s, gm, H, u, gupart, ga, st)) return rc;
+  if (use_fft(*s, conv_algo, fftprep)) {
+    if (int rc = fft_conv_backward(*s, gm, fftprep, gupart, st)) return rc;
+    if (int rc = launch_sum_slabs_masked(gupart, u, ga, rows, fft_conv_groups(s->M), st)) return rc;
+  } else {
+    if (int rc = conv_backward_toeplitz(*s, gm, H, u, gupart, ga, st)) return rc;
+  }
   // gx = gz W_h[:, M:] + ga w_u
   if (gx)
     if (int rc = dgrad(gx, s->M, s->D, ga, w_u)) return rc;

@@ -31,6 +31,16 @@ int launch_gu_reduce(const float* gu_part, const float* u, float* out, int B, in
 size_t forward_workspace_bf16(const lmufft_shape& s);
 size_t backward_workspace_bf16(const lmufft_shape& s);
 
+// FFT route of the causal convolution (defined in fft_conv_f32.hip)
+int fft_length(int T);                      // 0 when the LDS-resident kernels cannot take T
+size_t fftprep_bytes(int M, int T);
+int fft_prepare(const lmufft_shape& s, const float* H, void* prep, hipStream_t st);
+int fft_conv_forward(const lmufft_shape& s, const float* u, const void* prep, float* m, hipStream_t st);
+int fft_conv_groups(int M);
+int fft_conv_backward(const lmufft_shape& s, const float* gm, const void* prep, float* part, hipStream_t st);
+// out[i] = sum_p part[p*n + i], masked by u[i] > 0 when u != NULL (defined in lmufft_f32.hip)
+int launch_sum_slabs_masked(const float* part, const float* u, float* out, long n, int P, hipStream_t st);
+
 // Brackets one kernel launch with HIP events when profiling is enabled
 // (lmufft_profile_enable); a no-op otherwise.
 bool profiling_enabled();

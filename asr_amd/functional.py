@@ -58,11 +58,34 @@ def prepare_impulse_bf16(H: torch.Tensor) -> torch.Tensor:
     return buf
 
 
+def fft_supported(T: int, M: int = 1) -> bool:
+    """True when the LDS-resident FFT convolution kernels can take sequence length T."""
+    shp = _shape(1, T, 1, M, 1, T)
+    return _lib.lib.lmufft_fftprep_bytes(ctypes.byref(shp)) != 0
+
+
+def prepare_impulse_fft(H: torch.Tensor, T: int) -> torch.Tensor:
+    """Spectra of the first T taps of H for the FFT route (counterpart of the
+    reference's `fft_H` buffer, src/lmu.py:285).  Built once per (H, T)."""
+    _require_gpu(H, "H")
+    H = H.contiguous().float()
+    M, ldH = H.shape
+    shp = _shape(1, T, 1, M, 1, ldH)
+    nbytes = _lib.lib.lmufft_fftprep_bytes(ctypes.byref(shp))
+    if nbytes == 0:
+        raise RuntimeError(f"LMUFFT: the FFT convolution kernels do not support seq_len {T} (limit 512)")
+    buf = _workspace(nbytes, H.device)
+    with torch.cuda.device(H.device):
+        rc = _lib.lib.lmufft_fftprep_f32(ctypes.byref(shp), _ptr(H), _ptr(buf), _stream(H.device))
+    _lib.check(rc, "lmufft_fftprep_f32")
+    return buf
+
+
 class _LMUFFTFunction(torch.autograd.Function):
     """(x, w_u, b_u, W_h, b_h, H) -> (h, h_n); reference: src/lmu.py:290-320."""
 
     @staticmethod
-    def forward(ctx, x, w_u, b_u, W_h, b_h, H, conv_algo, hprep):
+    def forward(ctx, x, w_u, b_u, W_h, b_h, H, conv_algo, hprep, fftprep):
         _require_gpu(x, "x")
         if x.dtype not in _DTYPES:
             raise RuntimeError(f"LMUFFT: x has dtype {x.dtype}; supported: float32, bfloat16")
@@ -102,8 +125,10 @@ class _LMUFFTFunction(torch.autograd.Function):
         with torch.cuda.device(dev):
             ws = _workspace(_lib.lib.lmufft_forward_workspace_bytes(ctypes.byref(shp), _DTYPES[dt]), dev)
             if dt == torch.float32:
+                if fftprep is None and conv_algo == _lib.CONV_FFT:
+                    fftprep = prepare_impulse_fft(H, T)
                 rc = _lib.lib.lmufft_forward_f32(
-                    ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(b_u), _ptr(W_h), _ptr(b_h), _ptr(H),
+                    ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(b_u), _ptr(W_h), _ptr(b_h), _ptr(H), _ptr(fftprep),
                     _ptr(u), _ptr(m), _ptr(h), _ptr(h_n), conv_algo, _ptr(ws), ws.numel(), _stream(dev))
                 what = "lmufft_forward_f32"
             else:
@@ -118,7 +143,8 @@ class _LMUFFTFunction(torch.autograd.Function):
                     _ptr(u), _ptr(m), _ptr(h), _ptr(h_n), conv_algo, _ptr(ws), ws.numel(), _stream(dev))
                 what = "lmufft_forward_bf16"
         _lib.check(rc, what)
-        ctx.save_for_backward(x, w_u, W_h, H, u, m, h, hprep, wprep if dt != torch.float32 else None)
+        ctx.save_for_backward(x, w_u, W_h, H, u, m, h, hprep, wprep if dt != torch.float32 else None,
+                              fftprep if dt == torch.float32 else None)
         ctx.conv_algo = conv_algo
         ctx.shape = (B, T, D, M, Hd, ldH)
         ctx.set_materialize_grads(False)
@@ -126,13 +152,13 @@ class _LMUFFTFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gh, gh_n):
-        x, w_u, W_h, H, u, m, h, hprep, wprep = ctx.saved_tensors
+        x, w_u, W_h, H, u, m, h, hprep, wprep, fftprep = ctx.saved_tensors
         B, T, D, M, Hd, ldH = ctx.shape
         dev = x.device
         dt = x.dtype
         need_x = ctx.needs_input_grad[0]
         if gh is None and gh_n is None:
-            return (None,) * 8
+            return (None,) * 9
         if gh is not None:
             gh = gh.to(dt).contiguous()
         if gh_n is not None:
@@ -148,9 +174,9 @@ class _LMUFFTFunction(torch.autograd.Function):
             ws = _workspace(_lib.lib.lmufft_backward_workspace_bytes(ctypes.byref(shp), _DTYPES[dt]), dev)
             if dt == torch.float32:
                 rc = _lib.lib.lmufft_backward_f32(
-                    ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(W_h), _ptr(H), _ptr(u), _ptr(m), _ptr(h),
-                    _ptr(gh), _ptr(gh_n), _ptr(gx), _ptr(gw_u), _ptr(gb_u), _ptr(gW_h), _ptr(gb_h), _ptr(gm),
-                    ctx.conv_algo, _ptr(ws), ws.numel(), _stream(dev))
+                    ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(W_h), _ptr(H), _ptr(fftprep), _ptr(u), _ptr(m),
+                    _ptr(h), _ptr(gh), _ptr(gh_n), _ptr(gx), _ptr(gw_u), _ptr(gb_u), _ptr(gW_h), _ptr(gb_h),
+                    _ptr(gm), ctx.conv_algo, _ptr(ws), ws.numel(), _stream(dev))
                 what = "lmufft_backward_f32"
             else:
                 rc = _lib.lib.lmufft_backward_bf16(
@@ -162,19 +188,27 @@ class _LMUFFTFunction(torch.autograd.Function):
         if _DEBUG is not None:
             _DEBUG.update(gm=gm, u=u, m=m)
         pd = ctx.param_dtypes
-        return gx, gw_u.to(pd[0]), gb_u.to(pd[1]), gW_h.to(pd[2]), gb_h.to(pd[3]), None, None, None
+        return gx, gw_u.to(pd[0]), gb_u.to(pd[1]), gW_h.to(pd[2]), gb_h.to(pd[3]), None, None, None, None
 
 
-def lmufft_layer(x, w_u, b_u, W_h, b_h, H, conv_algo="auto", hprep=None):
+def lmufft_layer(x, w_u, b_u, W_h, b_h, H, conv_algo="auto", hprep=None, fftprep=None):
     """h, h_n = LMUFFT forward with autograd support (HIP kernels only).
 
     x float32 -> exact-fp32 kernels; x bfloat16 -> bf16 kernels with fp32
     accumulation (`hprep` = prepare_impulse_bf16(H), built on the fly if None).
+    `fftprep` = prepare_impulse_fft(H, T) enables the FFT convolution of the
+    fp32 path (required for conv_algo="fft", built on the fly if None).
     """
-    return _LMUFFTFunction.apply(x, w_u, b_u, W_h, b_h, H, _ALGOS[conv_algo], hprep)
+    return _LMUFFTFunction.apply(x, w_u, b_u, W_h, b_h, H, _ALGOS[conv_algo], hprep, fftprep)
 
 
-def causal_conv(u, H, conv_algo="auto"):
+def _conv_fftprep(H, T, conv_algo, fftprep):
+    if fftprep is None and conv_algo == "fft":
+        fftprep = prepare_impulse_fft(H, T)
+    return fftprep
+
+
+def causal_conv(u, H, conv_algo="auto", fftprep=None):
     """m[b,t,k] = sum_{s<=t} H[k,t-s] u[b,s]  (no autograd; kernel-level entry point)."""
     _require_gpu(u, "u")
     _require_gpu(H, "H")
@@ -184,14 +218,15 @@ def causal_conv(u, H, conv_algo="auto"):
     M, ldH = H.shape
     m = torch.empty((B, T, M), dtype=torch.float32, device=u.device)
     shp = _shape(B, T, 1, M, 1, ldH)
+    fftprep = _conv_fftprep(H, T, conv_algo, fftprep)
     with torch.cuda.device(u.device):
-        rc = _lib.lib.lmufft_conv_forward_f32(ctypes.byref(shp), _ptr(u), _ptr(H), _ptr(m), _ALGOS[conv_algo],
-                                              None, 0, _stream(u.device))
+        rc = _lib.lib.lmufft_conv_forward_f32(ctypes.byref(shp), _ptr(u), _ptr(H), _ptr(fftprep), _ptr(m),
+                                              _ALGOS[conv_algo], None, 0, _stream(u.device))
     _lib.check(rc, "lmufft_conv_forward_f32")
     return m
 
 
-def causal_conv_adjoint(gm, H, conv_algo="auto"):
+def causal_conv_adjoint(gm, H, conv_algo="auto", fftprep=None):
     """gu[b,s] = sum_{t>=s} sum_k H[k,t-s] gm[b,t,k]  (no autograd)."""
     _require_gpu(gm, "gm")
     _require_gpu(H, "H")
@@ -202,9 +237,10 @@ def causal_conv_adjoint(gm, H, conv_algo="auto"):
     gu = torch.empty((B, T), dtype=torch.float32, device=gm.device)
     shp = _shape(B, T, 1, M, 1, ldH)
     algo = _ALGOS[conv_algo]
+    fftprep = _conv_fftprep(H, T, conv_algo, fftprep)
     with torch.cuda.device(gm.device):
         ws = _workspace(_lib.lib.lmufft_conv_workspace_bytes(ctypes.byref(shp), _lib.F32, algo), gm.device)
-        rc = _lib.lib.lmufft_conv_backward_f32(ctypes.byref(shp), _ptr(gm), _ptr(H), _ptr(gu), algo, _ptr(ws),
-                                               ws.numel(), _stream(gm.device))
+        rc = _lib.lib.lmufft_conv_backward_f32(ctypes.byref(shp), _ptr(gm), _ptr(H), _ptr(fftprep), _ptr(gu), algo,
+                                               _ptr(ws), ws.numel(), _stream(gm.device))
     _lib.check(rc, "lmufft_conv_backward_f32")
     return gu

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from .functional import lmufft_layer, prepare_impulse_bf16
+from .functional import fft_supported, lmufft_layer, prepare_impulse_bf16, prepare_impulse_fft
 
 __all__ = ["LMUFFT", "LMU", "legendre_state_space", "impulse_response"]
 
@@ -57,6 +57,14 @@ def impulse_response(A: torch.Tensor, B: torch.Tensor, seq_len: int):
     return H, fft_H
 
 
+def _AUTO_PREFERS_FFT(T, M):
+    """Shape policy of conv_algo="auto" on the fp32 path, from kernel timings on MI355X
+    (batch 64, 192 memory channels, forward + adjoint): T=100 Toeplitz 37 us / FFT 44 us,
+    T=200 62 / 52, T=400 126 / 106, T=512 169 / 116.  The Toeplitz kernels' work grows
+    with T^2, the FFT's with the transform length."""
+    return T >= 192
+
+
 class LMUFFT(nn.Module):
     """Parallel (convolutional) Legendre Memory Unit layer on MI355X.
 
@@ -89,6 +97,7 @@ class LMUFFT(nn.Module):
         self.register_buffer("H", H)  # [memory_size, seq_len]
         self.register_buffer("fft_H", fft_H)  # [memory_size, seq_len + 1] complex64
         self._hprep = None  # (key, bf16 copies of H), rebuilt when H changes
+        self._fftprep = {}  # T -> (key, spectra of H[:, :T]) for the FFT route
 
     def _impulse_bf16(self):
         H = self.H
@@ -96,6 +105,15 @@ class LMUFFT(nn.Module):
         if self._hprep is None or self._hprep[0] != key:
             self._hprep = (key, prepare_impulse_bf16(H))
         return self._hprep[1]
+
+    def _impulse_fft(self, T):
+        H = self.H
+        key = (H.data_ptr(), H._version, H.device, H.dtype)
+        hit = self._fftprep.get(T)
+        if hit is None or hit[0] != key:
+            hit = (key, prepare_impulse_fft(H, T))
+            self._fftprep[T] = hit
+        return hit[1]
 
     def forward(self, x):
         """x [batch, seq_len, input_size] -> (h [batch, seq_len, hidden], h_n [batch, hidden]).
@@ -107,8 +125,16 @@ class LMUFFT(nn.Module):
         if torch.is_autocast_enabled() and x.is_cuda and torch.get_autocast_dtype("cuda") == torch.bfloat16:
             x = x.to(torch.bfloat16)
         hprep = self._impulse_bf16() if (x.is_cuda and x.dtype == torch.bfloat16) else None
+        fftprep = None
+        if x.is_cuda and x.dtype == torch.float32 and x.dim() == 3:
+            T = x.shape[1]
+            if T > self.H.shape[1]:
+                pass  # rejected with the layer's own message below
+            elif self.conv_algo == "fft" or (self.conv_algo == "auto" and _AUTO_PREFERS_FFT(T, self.memory_size)
+                                           and fft_supported(T)):
+                fftprep = self._impulse_fft(T)
         return lmufft_layer(x, self.W_u.weight, self.W_u.bias, self.W_h.weight, self.W_h.bias, self.H,
-                            conv_algo=self.conv_algo, hprep=hprep)
+                            conv_algo=self.conv_algo, hprep=hprep, fftprep=fftprep)
 
 
 class LMU(nn.Module):

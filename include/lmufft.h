@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMUFFT_ABI_VERSION 1
+#define LMUFFT_ABI_VERSION 2
 
 /* element types of the activations (x, h, gh, gx, m) */
 #define LMUFFT_F32 0
@@ -68,9 +68,9 @@ size_t lmufft_forward_workspace_bytes(const lmufft_shape* s, int dtype);
 
 int lmufft_forward_f32(const lmufft_shape* s, const float* x, const float* w_u,
                        const float* b_u, const float* W_h, const float* b_h,
-                       const float* H, float* u, float* m, float* h, float* h_n,
-                       int conv_algo, void* workspace, size_t workspace_bytes,
-                       void* stream);
+                       const float* H, const void* fftprep, float* u, float* m,
+                       float* h, float* h_n, int conv_algo, void* workspace,
+                       size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Backward of the whole layer (what autograd derives from src/lmu.py:300-318):
@@ -84,8 +84,8 @@ int lmufft_forward_f32(const lmufft_shape* s, const float* x, const float* w_u,
 size_t lmufft_backward_workspace_bytes(const lmufft_shape* s, int dtype);
 
 int lmufft_backward_f32(const lmufft_shape* s, const float* x, const float* w_u,
-                        const float* W_h, const float* H, const float* u,
-                        const float* m, const float* h, const float* gh,
+                        const float* W_h, const float* H, const void* fftprep,
+                        const float* u, const float* m, const float* h, const float* gh,
                         const float* gh_n, float* gx, float* gw_u, float* gb_u,
                         float* gW_h, float* gb_h, float* gm, int conv_algo,
                         void* workspace, size_t workspace_bytes, void* stream);
@@ -100,12 +100,25 @@ int lmufft_backward_f32(const lmufft_shape* s, const float* x, const float* w_u,
 size_t lmufft_conv_workspace_bytes(const lmufft_shape* s, int dtype, int conv_algo);
 
 int lmufft_conv_forward_f32(const lmufft_shape* s, const float* u, const float* H,
-                            float* m, int conv_algo, void* workspace,
-                            size_t workspace_bytes, void* stream);
+                            const void* fftprep, float* m, int conv_algo,
+                            void* workspace, size_t workspace_bytes, void* stream);
 
 int lmufft_conv_backward_f32(const lmufft_shape* s, const float* gm, const float* H,
-                             float* gu, int conv_algo, void* workspace,
-                             size_t workspace_bytes, void* stream);
+                             const void* fftprep, float* gu, int conv_algo,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Spectra of the impulse response for the FFT route (the counterpart of the
+ * reference's `fft_H` buffer, src/lmu.py:285, in the layout and transform
+ * length the kernels use).  They depend on H and on the call's T (the filter
+ * is truncated to the first T taps), so a caller prepares them once per
+ * (H, T): allocate lmufft_fftprep_bytes(s) (0 = this T is not supported by the
+ * FFT kernels), call lmufft_fftprep_f32, pass the buffer as `fftprep` above.
+ * fftprep == NULL selects the Toeplitz kernels (conv_algo AUTO) or is an error
+ * (conv_algo FFT).
+ * ---------------------------------------------------------------------- */
+size_t lmufft_fftprep_bytes(const lmufft_shape* s);
+int lmufft_fftprep_f32(const lmufft_shape* s, const float* H, void* fftprep, void* stream);
 
 /* ------------------------------------------------------------------------
  * bf16 variant: activations x, m, h, h_n, gh, gh_n, gx, gm are bf16 (passed as

@@ -38,7 +38,7 @@ def test_workspace_queries_and_shape_errors():
     assert _lib.lib.lmufft_backward_workspace_bytes(ctypes.byref(s), _lib.F32) > 0
     assert _lib.lib.lmufft_forward_workspace_bytes(ctypes.byref(s), _lib.F32) > 0
     bad = _lib.Shape(2, 500, 8, 6, 8, 400)  # T > seq_len
-    rc = _lib.lib.lmufft_forward_f32(ctypes.byref(bad), *([None] * 10), 0, None, 0, None)
+    rc = _lib.lib.lmufft_forward_f32(ctypes.byref(bad), *([None] * 11), 0, None, 0, None)
     assert rc != 0
     assert b"exceeds" in _lib.lib.lmufft_last_error()
     with pytest.raises(RuntimeError):
