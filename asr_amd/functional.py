@@ -81,11 +81,36 @@ def prepare_impulse_fft(H: torch.Tensor, T: int) -> torch.Tensor:
     return buf
 
 
+class GradSink:
+    """Destination of one layer's parameter gradients inside a flat exchange buffer.
+
+    The first backward of a step writes gw_u, gb_u, gW_h, gb_h straight into
+    these tensors (no autograd accumulation kernels) and calls `on_ready`;
+    further backwards of the same step return their gradients to autograd,
+    which adds them into `.grad` -- by then the same tensors.
+    """
+
+    def __init__(self, params, views, on_ready):
+        self.params = list(params)  # W_u.weight, W_u.bias, W_h.weight, W_h.bias
+        self.views = list(views)    # fp32, contiguous, 16-byte aligned, same shapes
+        self.on_ready = on_ready
+        self.filled = False
+
+    def usable(self, needs) -> bool:
+        return not self.filled and all(needs) and all(p.grad is None for p in self.params)
+
+    def commit(self) -> None:
+        self.filled = True
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+        self.on_ready(len(self.params))
+
+
 class _LMUFFTFunction(torch.autograd.Function):
     """(x, w_u, b_u, W_h, b_h, H) -> (h, h_n); reference: src/lmu.py:290-320."""
 
     @staticmethod
-    def forward(ctx, x, w_u, b_u, W_h, b_h, H, conv_algo, hprep, fftprep):
+    def forward(ctx, x, w_u, b_u, W_h, b_h, H, conv_algo, hprep, fftprep, grad_sink):
         _require_gpu(x, "x")
         if x.dtype not in _DTYPES:
             raise RuntimeError(f"LMUFFT: x has dtype {x.dtype}; supported: float32, bfloat16")
@@ -146,6 +171,7 @@ class _LMUFFTFunction(torch.autograd.Function):
         ctx.save_for_backward(x, w_u, W_h, H, u, m, h, hprep, wprep if dt != torch.float32 else None,
                               fftprep if dt == torch.float32 else None)
         ctx.conv_algo = conv_algo
+        ctx.grad_sink = grad_sink
         ctx.shape = (B, T, D, M, Hd, ldH)
         ctx.set_materialize_grads(False)
         return h, h_n
@@ -158,16 +184,21 @@ class _LMUFFTFunction(torch.autograd.Function):
         dt = x.dtype
         need_x = ctx.needs_input_grad[0]
         if gh is None and gh_n is None:
-            return (None,) * 9
+            return (None,) * 10
         if gh is not None:
             gh = gh.to(dt).contiguous()
         if gh_n is not None:
             gh_n = gh_n.to(dt).contiguous()
         gx = torch.empty_like(x) if need_x else None
-        gw_u = torch.empty_like(w_u)
-        gb_u = torch.empty((1,), dtype=torch.float32, device=dev)
-        gW_h = torch.empty_like(W_h)
-        gb_h = torch.empty((Hd,), dtype=torch.float32, device=dev)
+        sink = ctx.grad_sink
+        direct = sink is not None and sink.usable(ctx.needs_input_grad[1:5])
+        if direct:
+            gw_u, gb_u, gW_h, gb_h = sink.views
+        else:
+            gw_u = torch.empty_like(w_u)
+            gb_u = torch.empty((1,), dtype=torch.float32, device=dev)
+            gW_h = torch.empty_like(W_h)
+            gb_h = torch.empty((Hd,), dtype=torch.float32, device=dev)
         gm = torch.empty_like(m)
         shp = _shape(B, T, D, M, Hd, ldH)
         with torch.cuda.device(dev):
@@ -187,19 +218,23 @@ class _LMUFFTFunction(torch.autograd.Function):
         _lib.check(rc, what)
         if _DEBUG is not None:
             _DEBUG.update(gm=gm, u=u, m=m)
+        if direct:
+            sink.commit()
+            return (gx,) + (None,) * 9
         pd = ctx.param_dtypes
-        return gx, gw_u.to(pd[0]), gb_u.to(pd[1]), gW_h.to(pd[2]), gb_h.to(pd[3]), None, None, None, None
+        return gx, gw_u.to(pd[0]), gb_u.to(pd[1]), gW_h.to(pd[2]), gb_h.to(pd[3]), None, None, None, None, None
 
 
-def lmufft_layer(x, w_u, b_u, W_h, b_h, H, conv_algo="auto", hprep=None, fftprep=None):
+def lmufft_layer(x, w_u, b_u, W_h, b_h, H, conv_algo="auto", hprep=None, fftprep=None, grad_sink=None):
     """h, h_n = LMUFFT forward with autograd support (HIP kernels only).
 
     x float32 -> exact-fp32 kernels; x bfloat16 -> bf16 kernels with fp32
     accumulation (`hprep` = prepare_impulse_bf16(H), built on the fly if None).
     `fftprep` = prepare_impulse_fft(H, T) enables the FFT convolution of the
     fp32 path (required for conv_algo="fft", built on the fly if None).
+    `grad_sink` (a GradSink) receives the parameter gradients in place.
     """
-    return _LMUFFTFunction.apply(x, w_u, b_u, W_h, b_h, H, _ALGOS[conv_algo], hprep, fftprep)
+    return _LMUFFTFunction.apply(x, w_u, b_u, W_h, b_h, H, _ALGOS[conv_algo], hprep, fftprep, grad_sink)
 
 
 def _conv_fftprep(H, T, conv_algo, fftprep):

@@ -98,6 +98,7 @@ class LMUFFT(nn.Module):
         self.register_buffer("fft_H", fft_H)  # [memory_size, seq_len + 1] complex64
         self._hprep = None  # (key, bf16 copies of H), rebuilt when H changes
         self._fftprep = {}  # T -> (key, spectra of H[:, :T]) for the FFT route
+        self.grad_sink = None  # set by asr_amd.parallel.GradBuckets: gradients land in its flat buffer
 
     def _impulse_bf16(self):
         H = self.H
@@ -134,7 +135,8 @@ class LMUFFT(nn.Module):
                                            and fft_supported(T)):
                 fftprep = self._impulse_fft(T)
         return lmufft_layer(x, self.W_u.weight, self.W_u.bias, self.W_h.weight, self.W_h.bias, self.H,
-                            conv_algo=self.conv_algo, hprep=hprep, fftprep=fftprep)
+                            conv_algo=self.conv_algo, hprep=hprep, fftprep=fftprep,
+                            grad_sink=self.grad_sink)
 
 
 class LMU(nn.Module):

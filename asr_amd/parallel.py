@@ -18,38 +18,80 @@ import torch
 import torch.distributed as dist
 
 
+_ALIGN = 64  # every gradient starts on a 256-byte boundary of its bucket (vector stores in the kernels)
+
+
 class GradBuckets:
-    def __init__(self, param_groups: Sequence[Iterable[torch.nn.Parameter]], process_group=None,
-                 average: bool = True):
+    """groups: one entry per bucket, each an iterable of Parameters or an nn.Module.
+
+    For an LMUFFT module with fp32 parameters the bucket also becomes the
+    layer's gradient sink: its backward kernels write the gradients into the
+    flat buffer directly.  Every other parameter reaches the buffer through
+    autograd's accumulation into `.grad` (a view of the buffer).
+    Every parameter of a bucket must receive a gradient in every step (as with
+    DistributedDataParallel without find_unused_parameters).
+    """
+
+    def __init__(self, groups: Sequence, process_group=None, average: bool = True):
+        from .functional import GradSink
+        from .lmu import LMUFFT
+
         self.group = process_group
         self.average = average
         self.buckets: List[torch.Tensor] = []
         self._params: List[List[torch.nn.Parameter]] = []
+        self._views: List[List[torch.Tensor]] = []
+        self._sinks: List = []
         self._pending: List[int] = []
         self._handles = []
         self._hooks = []
-        for gi, params in enumerate(param_groups):
-            params = [p for p in params if p.requires_grad]
+        self._sunk_modules = []
+        for grp in groups:
+            module = grp if isinstance(grp, torch.nn.Module) else None
+            params = [p for p in (module.parameters() if module is not None else grp) if p.requires_grad]
             if not params:
                 continue
-            n = sum(p.numel() for p in params)
-            flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
-            off = 0
+            offs, n = [], 0
             for p in params:
-                p.grad = flat[off : off + p.numel()].view_as(p)
-                off += p.numel()
+                offs.append(n)
+                n += -(-p.numel() // _ALIGN) * _ALIGN
+            flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
+            views = [flat[o : o + p.numel()].view_as(p) for o, p in zip(offs, params)]
             bi = len(self.buckets)
             self.buckets.append(flat)
             self._params.append(params)
+            self._views.append(views)
             self._pending.append(len(params))
-            for p in params:
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+            sink = None
+            if (isinstance(module, LMUFFT) and len(params) == 4
+                    and all(p.dtype == torch.float32 for p in params)):
+                sink = GradSink(params, views, self._make_ready(bi))
+                module.grad_sink = sink
+                self._sunk_modules.append(module)
+            self._sinks.append(sink)
+            for p, v in zip(params, views):
+                p.grad = None if sink is not None else v
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi, v)))
 
-    def _make_hook(self, bi: int):
-        def hook(_param):
-            self._pending[bi] -= 1
+    def _make_ready(self, bi: int):
+        def ready(count: int):
+            self._pending[bi] -= count
             if self._pending[bi] == 0:
                 self._launch(bi)
+
+        return ready
+
+    def _make_hook(self, bi: int, view: torch.Tensor):
+        def hook(param):
+            # autograd delivered this gradient itself; make sure it lives in the bucket
+            g = param.grad
+            if g is not None and g.data_ptr() != view.data_ptr():
+                view.copy_(g)
+                param.grad = view
+            if self._pending[bi] > 0:
+                self._pending[bi] -= 1
+                if self._pending[bi] == 0:
+                    self._launch(bi)
 
         return hook
 
@@ -59,9 +101,16 @@ class GradBuckets:
                                                  async_op=True))
 
     def zero_grad(self) -> None:
-        """Clear the flat buffers (gradients stay views of them) and re-arm the hooks."""
+        """Start a step: re-arm the buckets.  Buckets fed by a gradient sink need no
+        clearing (their first backward overwrites); the others are zeroed in place."""
         for bi, flat in enumerate(self.buckets):
-            flat.zero_()
+            sink = self._sinks[bi]
+            if sink is not None:
+                sink.filled = False
+                for p in self._params[bi]:
+                    p.grad = None
+            else:
+                flat.zero_()
             self._pending[bi] = len(self._params[bi])
         self._handles = []
 
@@ -80,3 +129,6 @@ class GradBuckets:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        for m in self._sunk_modules:
+            m.grad_sink = None
+        self._sunk_modules = []

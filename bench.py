@@ -142,7 +142,7 @@ def main():
         torch.nn.init.zeros_(l.W_u.bias)
         torch.nn.init.zeros_(l.W_h.bias)
         layers.append(l.to(dev))
-    buckets = GradBuckets([list(l.parameters()) for l in reversed(layers)])
+    buckets = GradBuckets(list(reversed(layers)))
     g = torch.Generator(device=dev).manual_seed(1234 + 2 + rank)  # each rank its own utterances
     tdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     esize = 2 if args.dtype == "bf16" else 4

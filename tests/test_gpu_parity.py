@@ -279,3 +279,33 @@ def test_full_size_layer_properties(golden_dir):
         gz = (gh.double() * (h > 0)).reshape(-1, 384)
         ref_gW = gz.t() @ mx
     torch.testing.assert_close(gW, ref_gW, rtol=1e-4, atol=1e-5 * float(ref_gW.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gradient_sink_matches_autograd_accumulation(dtype):
+    """Gradients written straight into a flat exchange bucket equal the ones autograd
+    accumulates over two steps and a double backward within a step (to summation-order
+    rounding: the fp32 Toeplitz adjoint sums its diagonals with LDS atomics)."""
+    import copy
+
+    from asr_amd import LMUFFT
+    from asr_amd.parallel import GradBuckets
+
+    dev = _dev()
+    torch.manual_seed(7)
+    a = LMUFFT(48, 40, 24, 64, 16).to(dev)
+    b = copy.deepcopy(a)
+    buckets = GradBuckets([b])
+    x = torch.randn(3, 64, 48, device=dev).to(dtype)
+    gh = torch.randn(3, 64, 40, device=dev).to(dtype)
+    for step in range(2):
+        a.zero_grad(set_to_none=True)
+        buckets.zero_grad()
+        for rep in range(1 + step):  # second step: two backwards accumulate
+            a(x)[0].backward(gh)
+            b(x)[0].backward(gh)
+        buckets.finish()
+        for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
+            _close(pb.grad.cpu().numpy(), pa.grad.cpu().numpy(), f"{n} step {step}", rtol=1e-5, atol_rel=1e-6)
+            assert buckets.buckets[0].data_ptr() <= pb.grad.data_ptr() < buckets.buckets[0].data_ptr() + \
+                buckets.buckets[0].numel() * 4

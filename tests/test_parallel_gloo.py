@@ -20,6 +20,16 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _emulate_layer_backward(layer, value):
+    """What the layer's backward does with a gradient sink (asr_amd/functional.py): the kernels
+    write the four parameter gradients into the sink's views, then commit."""
+    sink = layer.grad_sink
+    assert sink is not None and sink.usable([True] * 4)
+    for v in sink.views:
+        v.fill_(value)
+    sink.commit()
+
+
 def _worker(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -29,26 +39,39 @@ def _worker(rank, world, port, ret):
 
         torch.manual_seed(0)  # same parameters on every rank
         layers = [LMUFFT(12, 10, 6, 16, 8) for _ in range(2)]
-        buckets = GradBuckets([list(l.parameters()) for l in reversed(layers)])
-        assert len(buckets.buckets) == 2
+        head = torch.nn.Linear(10, 5)  # an ordinary module fed by autograd itself
+        buckets = GradBuckets(list(reversed(layers)) + [head.parameters()])
+        assert len(buckets.buckets) == 3
         n_params = sum(p.numel() for l in layers for p in l.parameters())
-        assert sum(b.numel() for b in buckets.buckets) == n_params  # buffers are not in the buckets
-        for step in range(2):
+        # buffers (A, B, H, fft_H) are not in the buckets; every gradient starts 256-byte aligned
+        assert n_params <= sum(b.numel() for b in buckets.buckets[:2]) < n_params + 2 * 4 * 64
+        lo = min(b.data_ptr() for b in buckets.buckets)
+        hi = max(b.data_ptr() + b.numel() * 4 for b in buckets.buckets)
+        for step in range(3):
             buckets.zero_grad()
-            # emulate autograd: accumulate a rank-dependent gradient into every parameter, last layer first
-            for l in reversed(layers):
-                for p in l.parameters():
-                    g = torch.full_like(p, float(rank + 1 + step))
-                    # AccumulateGrad adds in place into the existing .grad (a view of the flat bucket)
-                    p.grad.add_(g)
-                    for hook in p._post_accumulate_grad_hooks.values():
-                        hook(p)
+            xin = torch.full((3, 10), float(rank + 1 + step))
+            head(xin).sum().backward()  # real autograd: hooks fire, fresh tensors are moved into the bucket
+            if step < 2:
+                for l in reversed(layers):
+                    _emulate_layer_backward(l, float(rank + 1 + step))
+            else:
+                # a step in which autograd delivers the layer gradients itself (sink not used)
+                for l in reversed(layers):
+                    for p in l.parameters():
+                        p.grad = torch.full_like(p, float(rank + 1 + step))
+                        for hook in p._post_accumulate_grad_hooks.values():
+                            hook(p)
             buckets.finish()
             want = sum(r + 1 + step for r in range(world)) / world
             for l in layers:
                 for p in l.parameters():
                     assert torch.allclose(p.grad, torch.full_like(p, want)), (rank, step)
-                    assert p.grad.data_ptr() >= min(b.data_ptr() for b in buckets.buckets)
+                    assert lo <= p.grad.data_ptr() < hi and p.grad.data_ptr() % 64 == 0
+            assert torch.allclose(head.weight.grad, torch.full_like(head.weight, 3 * want))
+            assert torch.allclose(head.bias.grad, torch.full_like(head.bias, 3.0))
+            assert lo <= head.weight.grad.data_ptr() < hi
+        buckets.remove()
+        assert all(l.grad_sink is None for l in layers)
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()
@@ -63,14 +86,20 @@ def test_grad_buckets_world2():
     assert dict(ret) == {0: "ok", 1: "ok"}
 
 
-def test_grad_buckets_single_process_is_noop():
+def test_grad_buckets_single_process():
     from asr_amd import LMUFFT
     from asr_amd.parallel import GradBuckets
 
     layer = LMUFFT(12, 10, 6, 16, 8)
-    b = GradBuckets([list(layer.parameters())])
+    b = GradBuckets([layer])
     b.zero_grad()
+    assert all(p.grad is None for p in layer.parameters())
+    _emulate_layer_backward(layer, 1.0)
+    # a second backward in the same step goes through autograd's accumulation into the same views
+    assert not layer.grad_sink.usable([True] * 4)
     for p in layer.parameters():
         p.grad.add_(1.0)
     b.finish()
-    assert all(torch.equal(p.grad, torch.ones_like(p)) for p in layer.parameters())
+    assert all(torch.equal(p.grad, torch.full_like(p, 2.0)) for p in layer.parameters())
+    b.zero_grad()
+    assert layer.grad_sink.usable([True] * 4) and not layer.grad_sink.usable([True, True, False, True])
