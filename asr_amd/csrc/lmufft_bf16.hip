@@ -1021,8 +1021,8 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
   }
 
   // out = gz W_h[:, j_begin : j_begin + ncols] (+ ga w_u), LDS-DMA kernel when everything is 16-byte friendly
-  auto dgrad = [&](auto glds_tag, auto fallback_tag, bf16_t* out, int j_begin, int ncols, const float* ga_,
-                   const float* wu_) -> int {
+  auto dgrad = [&](auto glds_tag, auto fallback_tag, const char* name, bf16_t* out, int j_begin, int ncols,
+                   const float* ga_, const float* wu_) -> int {
     using TG = decltype(glds_tag);
     using TF = decltype(fallback_tag);
     const bool fast = (s->Hd % 8 == 0) && (ncols % 8 == 0) && al16(out);
@@ -1033,22 +1033,22 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
       if (hipFuncSetAttribute((const void*)k_dgrad_glds_bf16<TG>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds) != hipSuccess)
         return set_error("cannot reserve %zu bytes of LDS for k_dgrad_glds_bf16", lds);
-      PROFB("k_dgrad_bf16");
+      PROFB(name);
       hipLaunchKernelGGL(k_dgrad_glds_bf16<TG>, grid, dim3(TG::THREADS), lds, st, (const bf16_t*)gz, WbT, out, ga_,
                          wu_, (int)rows, s->Hd, wl.ldWT, j_begin, ncols);
     } else {
       const dim3 grid(cdivb(ncols, TF::BN), cdivb(rows, TF::BM));
       const size_t lds = sizeof(bf16_t) * (size_t)(TF::BM + TF::BN) * (TF::BK + 8);
-      PROFB("k_dgrad_bf16");
+      PROFB(name);
       hipLaunchKernelGGL((k_dgrad_bf16<TF, false>), grid, dim3(kThreads), lds, st, (const bf16_t*)gz, WbT, out, ga_,
                          wu_, (int)rows, s->Hd, wl.ldWT, j_begin, ncols);
     }
-    LAUNCH_CHECKB("k_dgrad_bf16");
+    LAUNCH_CHECKB(name);
     return 0;
   };
 
   // gm = gz W_h[:, :M]
-  if (int rc = dgrad(DgradMTileB{}, DgradMTileB{}, gm, 0, s->M, nullptr, nullptr)) return rc;
+  if (int rc = dgrad(DgradMTileB{}, DgradMTileB{}, "k_dgrad_m_bf16", gm, 0, s->M, nullptr, nullptr)) return rc;
   // ga = (adjoint conv of gm) * (u > 0)
   const int KS = cdivb(s->M, 16);
   if (s->M % 8 == 0 && al16(gm) && (KS == 2 || KS == 4 || KS == 8 || KS == 12 || KS == 16)) {
@@ -1101,7 +1101,7 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
   }
   // gx = gz W_h[:, M:] + ga w_u
   if (gx)
-    if (int rc = dgrad(DgradXGldsTile{}, DgradXTileB{}, gx, s->M, s->D, (const float*)ga, w_u)) return rc;
+    if (int rc = dgrad(DgradXGldsTile{}, DgradXTileB{}, "k_dgrad_x_bf16", gx, s->M, s->D, (const float*)ga, w_u)) return rc;
   {  // gW_h
     using TL = WgradTileB;
     const bool vec = (s->Hd % 8 == 0) && (s->M % 8 == 0) && (s->D % 8 == 0) && al16(m) && al16(x);

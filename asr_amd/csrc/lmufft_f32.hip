@@ -854,13 +854,13 @@ int lmufft_backward_f32(const lmufft_shape* s, const float* x, const float* w_u,
   const int MD = s->M + s->D;
   const bool vec_h = (s->Hd % 4 == 0) && aligned16(h) && (!gh || aligned16(gh)) && (!gh_n || aligned16(gh_n));
 
-  auto dgrad = [&](float* out, int j_begin, int ncols, const float* ga_, const float* wu_) -> int {
+  auto dgrad = [&](const char* name, float* out, int j_begin, int ncols, const float* ga_, const float* wu_) -> int {
     using TL = DgradTile;
     const bool vec = vec_h && (MD % 4 == 0) && (j_begin % 4 == 0) && (ncols % 4 == 0) && aligned16(W_h);
     const dim3 grid(cdiv(ncols, TL::BN), cdiv(rows, TL::BM));
     const size_t lds = TL::SMEM_FLOATS * sizeof(float);
     {
-      PROF("k_dgrad");
+      PROF(name);
       if (vec)
         hipLaunchKernelGGL(k_dgrad<true>, grid, dim3(kThreads), lds, st, h, gh, gh_n, W_h, out, ga_, wu_,
                            (int)rows, s->T, s->Hd, MD, j_begin, ncols);
@@ -868,12 +868,12 @@ int lmufft_backward_f32(const lmufft_shape* s, const float* x, const float* w_u,
         hipLaunchKernelGGL(k_dgrad<false>, grid, dim3(kThreads), lds, st, h, gh, gh_n, W_h, out, ga_, wu_,
                            (int)rows, s->T, s->Hd, MD, j_begin, ncols);
     }
-    LAUNCH_CHECK("k_dgrad");
+    LAUNCH_CHECK(name);
     return 0;
   };
 
   // gm = gz W_h[:, :M]
-  if (int rc = dgrad(gm, 0, s->M, nullptr, nullptr)) return rc;
+  if (int rc = dgrad("k_dgrad_m", gm, 0, s->M, nullptr, nullptr)) return rc;
   // ga = (adjoint conv of gm) * (u > 0)
   if (use_fft(*s, conv_algo, fftprep)) {
     if (int rc = fft_conv_backward(*s, gm, fftprep, gupart, st)) return rc;
@@ -883,7 +883,7 @@ int lmufft_backward_f32(const lmufft_shape* s, const float* x, const float* w_u,
   }
   // gx = gz W_h[:, M:] + ga w_u
   if (gx)
-    if (int rc = dgrad(gx, s->M, s->D, ga, w_u)) return rc;
+    if (int rc = dgrad("k_dgrad_x", gx, s->M, s->D, ga, w_u)) return rc;
   {  // gW_h, gb_h slabs
     using TL = WgradTile;
     const bool vec = vec_h && (s->M % 4 == 0) && (s->D % 4 == 0) && aligned16(m) && aligned16(x);

@@ -52,15 +52,19 @@ def kernel_work(name, B, T, D, M, Hd, s=4):
 
     Bytes are what the kernel's contract makes it move at least once: its inputs read once, its
     outputs written once (s = bytes per activation element; parameters, u, gu, H are fp32)."""
+    bf16 = name.endswith("_bf16")
     name = name.replace("_bf16", "")
     rows = B * T
     MD = M + D
-    wbytes = Hd * MD * s
+    # the bf16 backward reads the masked upstream gradient gz (written once by k_relu_bwd);
+    # the fp32 kernels re-derive it from h and gh in their loaders
+    gz_in = Hd * s if bf16 else 2 * Hd * s
     table = {
-        "k_proj_fwd": (2.0 * rows * MD * Hd, rows * (MD + Hd) * s + wbytes),
-        # two launches: (h, gh) -> gm and (h, gh) -> gx
-        "k_dgrad": (2.0 * rows * MD * Hd, rows * (4 * Hd + MD) * s + wbytes),
-        "k_wgrad": (2.0 * rows * MD * Hd, rows * (2 * Hd + MD) * s + Hd * MD * 4),
+        "k_proj_fwd": (2.0 * rows * MD * Hd, rows * (MD + Hd) * s + Hd * MD * s),
+        "k_dgrad_m": (2.0 * rows * M * Hd, rows * (gz_in + M * s) + Hd * M * s),
+        "k_dgrad_x": (2.0 * rows * D * Hd, rows * (gz_in + D * s + 4) + Hd * D * s),
+        "k_wgrad": (2.0 * rows * MD * Hd, rows * (gz_in + MD * s) + Hd * MD * 4),
+        "k_relu_bwd": (2.0 * rows * Hd, rows * 3 * Hd * s),
         "k_conv_fwd": (1.0 * B * T * (T + 1) * M, rows * M * s + rows * 4 + M * T * s),
         "k_conv_bwd": (1.0 * B * T * (T + 1) * M, rows * M * s + rows * 4 + M * T * s),
         "k_encode_fwd": (2.0 * rows * D, rows * D * s + rows * 4),
