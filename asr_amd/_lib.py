@@ -61,6 +61,15 @@ def _load():
     lib.lmufft_conv_forward_f32.argtypes = [sp, vp, vp, vp, vp, ci, vp, sz, vp]
     lib.lmufft_conv_backward_f32.restype = ci
     lib.lmufft_conv_backward_f32.argtypes = [sp, vp, vp, vp, vp, ci, vp, sz, vp]
+    lib.lmufft_melprep_bytes.restype = sz
+    lib.lmufft_melprep_bytes.argtypes = []
+    lib.lmufft_melprep.restype = ci
+    lib.lmufft_melprep.argtypes = [vp, vp]
+    lib.lmufft_mel_frames.restype = ci
+    lib.lmufft_mel_frames.argtypes = [ctypes.c_int32]
+    lib.lmufft_mel_forward_f32.restype = ci
+    lib.lmufft_mel_forward_f32.argtypes = [vp, vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, vp,
+                                           ctypes.c_int32, ci, vp, vp]
     lib.lmufft_fftprep_bytes.restype = sz
     lib.lmufft_fftprep_bytes.argtypes = [sp]
     lib.lmufft_fftprep_f32.restype = ci
@@ -107,6 +116,10 @@ EXPORTS = (
     "lmufft_conv_backward_f32",
     "lmufft_fftprep_bytes",
     "lmufft_fftprep_f32",
+    "lmufft_melprep_bytes",
+    "lmufft_melprep",
+    "lmufft_mel_frames",
+    "lmufft_mel_forward_f32",
     "lmufft_hprep_bytes",
     "lmufft_hprep_bf16",
     "lmufft_wprep_bytes",

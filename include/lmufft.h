@@ -155,6 +155,30 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x, const float* w_u,
                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Log-mel frontend.  Replaces AudioPreprocessor.extract_mel_features and
+ * _normalize_features, src/data/preprocessing.py:76-117, for the transform the
+ * reference constructs at src/data/preprocessing.py:41-51 (16 kHz, n_fft =
+ * win_length = 400, hop 160, 80 HTK mel bins, power 2, AmplitudeToDB):
+ *   wave [B][ld_wave] f32 samples, utterance b holds lengths[b] <= L of them
+ *   (lengths = NULL: all hold L; every utterance needs more than 200 samples,
+ *   the reflect padding's limit);
+ *   mel [B][Tmax][80] f32, Tmax >= lmufft_mel_frames(L); utterance b has
+ *   lmufft_mel_frames(lengths[b]) = 1 + lengths[b]/160 frames, the rows after
+ *   them are written as zero (the reference's collate_fn pads with zeros,
+ *   src/data/preprocessing.py:351-353);
+ *   normalize != 0: per utterance and mel bin (x - mean_t) / std_t, unbiased
+ *   std, std == 0 -> 1 (src/data/preprocessing.py:111-117).
+ * `melprep` = constants (twiddles, window, filterbank) in device memory:
+ * allocate lmufft_melprep_bytes(), fill once with lmufft_melprep.
+ * ---------------------------------------------------------------------- */
+size_t lmufft_melprep_bytes(void);
+int lmufft_melprep(void* melprep, void* stream);
+int lmufft_mel_frames(int32_t samples);
+int lmufft_mel_forward_f32(const float* wave, const int32_t* lengths, int32_t B,
+                           int64_t ld_wave, int32_t L, float* mel, int32_t Tmax,
+                           int normalize, const void* melprep, void* stream);
+
+/* ------------------------------------------------------------------------
  * Per-kernel timing with HIP events on the caller's stream (no counterpart in
  * the reference, which has no profiling hooks).  While enabled, every kernel
  * launch made by this library is bracketed by two events; the totals are read
