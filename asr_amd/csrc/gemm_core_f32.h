@@ -132,6 +132,20 @@ __device__ __forceinline__ void tile_store(float* S, const typename Load::raw_t 
   }
 }
 
+// Workgroups are dealt to the chip's 8 XCDs round-robin by linear workgroup id, and every XCD
+// has its own L2.  Workgroups that read the same operand panel are therefore given ids that are
+// neighbours ON ONE XCD: with a 1-D grid of xcd_grid(groups, inner) workgroups, xcd_slot maps
+// blockIdx.x -> (group, member) such that group % 8 == blockIdx.x % 8 and the `inner` members
+// of a group follow each other in that XCD's dispatch order.  Slots with group >= groups are idle.
+struct XcdSlot {
+  int group, member;
+};
+__device__ __forceinline__ XcdSlot xcd_slot(int inner) {
+  const int id = blockIdx.x, seq = id >> 3;
+  return {(seq / inner) * 8 + (id & 7), seq % inner};
+}
+static inline int xcd_grid(long groups, int inner) { return (int)(8 * ((groups + 7) / 8) * inner); }
+
 template <class T>
 struct WavePos {
   int wm0, wn0, r, hh;

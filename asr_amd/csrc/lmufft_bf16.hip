@@ -304,66 +304,43 @@ __global__ __launch_bounds__(ProjGldsTile::THREADS) void k_proj_fwd_glds_bf16(
 }
 
 // ---------------------------------------------------------------------------
-// gz = (h > 0) ? gh (+ gh_n on the last frame) : 0   and   partial gb_h = sum_rows gz
-// One pass over h and gh; the three GEMMs of the backward read gz afterwards.
-// Slab per workgroup: [Hd] fp32.
+// gz = (h > 0) ? gh (+ gh_n on the last frame) : 0
+// One pass over h and gh; the three GEMMs of the backward read gz afterwards
+// (the weight-gradient kernel also takes gb_h = sum_rows gz from its staged tiles).
 // ---------------------------------------------------------------------------
 template <bool VEC>
 __global__ __launch_bounds__(kThreads) void k_relu_bwd_bf16(const bf16_t* __restrict__ h,
                                                             const bf16_t* __restrict__ gh,
                                                             const bf16_t* __restrict__ gh_n,
-                                                            bf16_t* __restrict__ gz, float* __restrict__ part,
-                                                            int rows, int T, int Hd, int rows_per_block) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [row groups][Hd rounded up to 8]
-  const int r0 = blockIdx.x * rows_per_block;
-  const int r1 = min(rows, r0 + rows_per_block);
-  float* slab = part + (long)blockIdx.x * Hd;
+                                                            bf16_t* __restrict__ gz, int rows, int T, int Hd) {
   if (VEC) {
-    const int CH = Hd / 8;                 // 16-byte chunks per row
-    const int RP = kThreads / CH;          // rows per pass (threads beyond RP*CH idle)
-    const int c = threadIdx.x % CH, rg = threadIdx.x / CH;
-    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (rg < RP) {
-      for (int row = r0 + rg; row < r1; row += RP) {
-        const long off = (long)row * Hd + c * 8;
-        const bf16x8 hv = *reinterpret_cast<const bf16x8*>(h + off);
-        bf16x8 g = gh ? *reinterpret_cast<const bf16x8*>(gh + off) : bzero8();
-        if (gh_n) {
-          const unsigned b = (unsigned)row / (unsigned)T;
-          if ((unsigned)row - b * (unsigned)T == (unsigned)(T - 1)) {
-            const bf16x8 gl = *reinterpret_cast<const bf16x8*>(gh_n + (long)b * Hd + c * 8);
+    const unsigned CH = (unsigned)Hd / 8;  // 16-byte chunks per row
+    const long total = (long)rows * CH;
+    for (long i = blockIdx.x * (long)kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
+      const unsigned row = (unsigned)(i / CH), c = (unsigned)(i - (long)row * CH);
+      const long off = (long)row * Hd + c * 8;
+      const bf16x8 hv = *reinterpret_cast<const bf16x8*>(h + off);
+      bf16x8 g = gh ? *reinterpret_cast<const bf16x8*>(gh + off) : bzero8();
+      if (gh_n) {
+        const unsigned b = row / (unsigned)T;
+        if (row - b * (unsigned)T == (unsigned)(T - 1)) {
+          const bf16x8 gl = *reinterpret_cast<const bf16x8*>(gh_n + (long)b * Hd + c * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) g[j] = (bf16_t)((float)g[j] + (float)gl[j]);
-          }
+          for (int j = 0; j < 8; ++j) g[j] = (bf16_t)((float)g[j] + (float)gl[j]);
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          g[j] = (float)hv[j] > 0.f ? g[j] : (bf16_t)0.f;
-          cs[j] += (float)g[j];
-        }
-        *reinterpret_cast<bf16x8*>(gz + off) = g;
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) red[rg * Hd + c * 8 + j] = cs[j];
-    }
-    __syncthreads();
-    for (int n = threadIdx.x; n < Hd; n += kThreads) {
-      float s = 0.f;
-      for (int q = 0; q < RP; ++q) s += red[q * Hd + n];
-      slab[n] = s;
+      for (int j = 0; j < 8; ++j) g[j] = (float)hv[j] > 0.f ? g[j] : (bf16_t)0.f;
+      *reinterpret_cast<bf16x8*>(gz + off) = g;
     }
   } else {
-    for (int n = threadIdx.x; n < Hd; n += kThreads) {
-      float s = 0.f;
-      for (int row = r0; row < r1; ++row) {
-        const long off = (long)row * Hd + n;
-        float g = gh ? (float)gh[off] : 0.f;
-        if (gh_n && row % T == T - 1) g += (float)gh_n[(long)(row / T) * Hd + n];
-        const bf16_t gb = (float)h[off] > 0.f ? (bf16_t)g : (bf16_t)0.f;
-        gz[off] = gb;
-        s += (float)gb;
-      }
-      slab[n] = s;
+    const long total = (long)rows * Hd;
+    for (long i = blockIdx.x * (long)kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
+      const long row = i / Hd;
+      const int n = (int)(i - row * Hd);
+      float g = gh ? (float)gh[i] : 0.f;
+      if (gh_n && row % T == T - 1) g += (float)gh_n[(row / T) * Hd + n];
+      gz[i] = (float)h[i] > 0.f ? (bf16_t)g : (bf16_t)0.f;
     }
   }
 }
@@ -612,24 +589,39 @@ __global__ __launch_bounds__(kThreads) void k_conv_bwd2_bf16(const bf16_t* __res
 // ---------------------------------------------------------------------------
 // gW_h[n][j] = sum_rows gz[row][n] [m;x][row][j]
 // k = frame index: both operands are k-strided in HBM -> transposed LDS reads.
-// Row range split over gridDim.z; fp32 slabs [Hd*(M+D)] summed afterwards.
+// The row range is split over workgroups; each row range writes one fp32 slab
+//   [ gW_h : Hd*(M+D) | gb_h : Hd | gw_u : D | gb_u : 1 ]   (segments padded to 4)
+// whose small segments come from the staged tiles for free:
+//   gb_h[n] = sum_rows gz[row][n]        column sums of the A tile  (first j tile)
+//   gw_u[d] = sum_rows ga[row] x[row][d] ga-weighted column sums of the B tile (first n tile)
+//   gb_u    = sum_rows ga[row]
+// The slabs are summed afterwards in a fixed order.
 // ---------------------------------------------------------------------------
-using WgradTileB = TileB<128, 192, 32, 2, 2>;
+using WgradTileB = TileB<128, 192, 64, 2, 2>;
+static_assert(WgradTileB::BK <= 64, "one wave stages the ga slice of a k tile");
 
 template <bool VEC>
 __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restrict__ gz,
                                                          const bf16_t* __restrict__ m,
-                                                         const bf16_t* __restrict__ x, float* __restrict__ slabs,
+                                                         const bf16_t* __restrict__ x,
+                                                         const float* __restrict__ ga, float* __restrict__ slabs,
                                                          int rows, int rows_per_split, int M, int D, int Hd) {
   using TL = WgradTileB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
-  const int j0 = blockIdx.x * TL::BN;
-  const int n0 = blockIdx.y * TL::BM;
   const int MD = M + D;
-  const int kbeg = blockIdx.z * rows_per_split;
+  // all output tiles of one row range share its slices of gz and [m;x]: same XCD
+  const int tiles_j = (MD + TL::BN - 1) / TL::BN, tiles_n = (Hd + TL::BM - 1) / TL::BM;
+  const XcdSlot slot = xcd_slot(tiles_j * tiles_n);
+  const int tile_j = slot.member % tiles_j, tile_n = slot.member / tiles_j;
+  const int j0 = tile_j * TL::BN;
+  const int n0 = tile_n * TL::BM;
+  const int kbeg = slot.group * rows_per_split;
+  if (kbeg >= rows) return;
   const int kend = min(rows, kbeg + rows_per_split);
-  float* slab = slabs + blockIdx.z * ((long)Hd * MD);
+  const long off_gbh = ((long)Hd * MD + 3) & ~3L, off_gwu = off_gbh + (long)tiles_j * TL::WGN * ((Hd + 3) & ~3),
+             off_gbu = off_gwu + (long)tiles_n * TL::WGM * ((D + 3) & ~3);
+  float* slab = slabs + slot.group * (off_gbu + 4);
 
   auto la = plain_load_b([=](int r, int k) -> bf16x8 {
     const int n = n0 + r;
@@ -661,17 +653,51 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
   WavePos<TL> w;
   f32x16 acc[TL::TM][TL::TN];
   tileb_zero<TL>(acc);
+  // The small gradients ride on the MFMA pipe:
+  //   gb_h: A fragments times a fragment of ones;
+  //   gw_u: a fragment whose 32 rows all hold ga[k] (split into two bf16 so that ga keeps
+  //         16 mantissa bits) times the B fragments.
+  // An A fragment is held by WGN waves of each of the tiles_j workgroups of a tile row, so
+  // those RB = tiles_j * WGN waves take turns, one k-step of 16 each, and leave RB partial
+  // copies of gb_h in the slab; likewise RU = tiles_n * WGM copies of gw_u.
+  const int tid = threadIdx.x;
+  const int RB = tiles_j * TL::WGN, RU = tiles_n * TL::WGM;
+  const int slot_b = tile_j * TL::WGN + w.wn0 / TL::WN, slot_u = tile_n * TL::WGM + w.wm0 / TL::WM;
+  int cnt_b = slot_b, cnt_u = slot_u;  // k-steps until this wave's next turn
+  float* gaS = reinterpret_cast<float*>(smem + OpA::ELEMS + OpB::ELEMS);
+  f32x16 accb[TL::TM], accu[TL::TN][2];
+#pragma unroll
+  for (int t = 0; t < TL::TM; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accb[t][i] = 0.f;
+#pragma unroll
+  for (int t = 0; t < TL::TN; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accu[t][0][i] = accu[t][1][i] = 0.f;
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.f;
+  float ga_reg = 0.f, gbu = 0.f;
+  auto fetch_ga = [&](int k0) {
+    if (tid < TL::BK) ga_reg = (k0 + tid < kend) ? ga[k0 + tid] : 0.f;
+  };
   if (kbeg < kend) {
     oa.fetch(kbeg);
     ob.fetch(kbeg);
+    fetch_ga(kbeg);
   }
   for (int k0 = kbeg; k0 < kend; k0 += TL::BK) {
     oa.store();
     ob.store();
+    if (tid < TL::BK) {
+      gaS[tid] = ga_reg;
+      gbu += ga_reg;
+    }
     __syncthreads();
     if (k0 + TL::BK < kend) {
       oa.fetch(k0 + TL::BK);
       ob.fetch(k0 + TL::BK);
+      fetch_ga(k0 + TL::BK);
     }
 #pragma unroll
     for (int kl = 0; kl < TL::BK; kl += 16) {
@@ -685,6 +711,31 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
 #pragma unroll
         for (int tn = 0; tn < TL::TN; ++tn)
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bfr[tn], acc[tm][tn], 0, 0, 0);
+      if (cnt_b == 0) {  // wave-uniform
+        cnt_b = RB;
+#pragma unroll
+        for (int tm = 0; tm < TL::TM; ++tm)
+          accb[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], ones, accb[tm], 0, 0, 0);
+      }
+      --cnt_b;
+      if (cnt_u == 0) {  // wave-uniform
+        cnt_u = RU;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(&gaS[kl + 8 * w.hh]);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(&gaS[kl + 8 * w.hh + 4]);
+        bf16x8 ghi, glo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float g = j < 4 ? g0[j] : g1[j - 4];
+          ghi[j] = (bf16_t)g;
+          glo[j] = (bf16_t)(g - (float)ghi[j]);
+        }
+#pragma unroll
+        for (int tn = 0; tn < TL::TN; ++tn) {
+          accu[tn][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ghi, bfr[tn], accu[tn][0], 0, 0, 0);
+          accu[tn][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(glo, bfr[tn], accu[tn][1], 0, 0, 0);
+        }
+      }
+      --cnt_u;
     }
     __syncthreads();
   }
@@ -693,56 +744,32 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
     const int n = n0 + mm, j = j0 + nn;
     if (n < Hd && j < MD) slab[(long)n * MD + j] = v;
   });
-}
-
-// ---------------------------------------------------------------------------
-// partial gw_u = sum_rows ga[row] x[row,:], partial gb_u = sum_rows ga[row]
-// ---------------------------------------------------------------------------
-template <bool VEC>
-__global__ __launch_bounds__(kThreads) void k_encode_bwd_bf16(const float* __restrict__ ga,
-                                                              const bf16_t* __restrict__ x,
-                                                              float* __restrict__ part, int rows, int D,
-                                                              int rows_per_block) {
-  __shared__ float red[4][512];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int r0 = blockIdx.x * rows_per_block;
-  const int r1 = min(rows, r0 + rows_per_block);
-  float* slab = part + (long)blockIdx.x * (D + 1);
-
-  for (int c0 = 0; c0 < D; c0 += 512) {
-    const int c = c0 + lane * 8;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float gsum = 0.f;
-    for (int row = r0 + wave; row < r1; row += 4) {
-      const float g = ga[row];
-      gsum += g;
-      if (g != 0.f && c < D) {
-        const bf16x8 xv = bload8<VEC>(x, (long)row * D + c, c, D);
+  if (w.r == 0) {  // every column of accb holds the row sums; column 0 writes them
+    float* dst = slab + off_gbh + (long)slot_b * ((Hd + 3) & ~3);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += g * (float)xv[j];
+    for (int tm = 0; tm < TL::TM; ++tm)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int n = n0 + w.wm0 + tm * 32 + (i & 3) + 8 * (i >> 2) + 4 * w.hh;
+        if (n < Hd) dst[n] = accb[tm][i];
       }
-    }
-    __syncthreads();
+  }
+  if (w.hh == 0) {  // every row of accu holds gw_u; row 0 (register 0, lanes 0..31) writes it
+    float* dst = slab + off_gwu + (long)slot_u * ((D + 3) & ~3);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) red[wave][lane * 8 + j] = acc[j];
-    __syncthreads();
-    for (int q = threadIdx.x; q < 512; q += kThreads) {
-      const int cc = c0 + q;
-      if (cc < D) slab[cc] = red[0][q] + red[1][q] + red[2][q] + red[3][q];
+    for (int tn = 0; tn < TL::TN; ++tn) {
+      const int j = j0 + w.wn0 + tn * 32 + w.r;
+      if (j >= M && j < MD) dst[j - M] = accu[tn][0][0] + accu[tn][1][0];
     }
-    if (c0 == 0) {
-      __syncthreads();
-      if (lane == 0) red[wave][0] = gsum;
-      __syncthreads();
-      if (threadIdx.x == 0) slab[D] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
-    }
+  }
+  if (tile_n == 0 && tile_j == 0 && tid < 64) {  // gb_u = sum of ga over the row range
+    float v = gbu;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (tid == 0) slab[off_gbu] = v;
   }
 }
 
-// ---------------------------------------------------------------------------
-// host side
-// ---------------------------------------------------------------------------
-constexpr int kEncRowsPerBlockB = 64;
 
 struct HprepLayout {
   int ldHb, ldHT;
@@ -773,32 +800,41 @@ static WprepLayout wprep_layout(const lmufft_shape& s) {
   return l;
 }
 
-constexpr int kReluRowsPerBlock = 40;
 
 struct BwdPlanB {
-  int S, rps, ntt, enc_blocks, relu_blocks, cb2_P;
-  size_t off_gz, off_relupart, off_wslab, off_gupart, off_ga, off_encpart, total;
+  int S, rps, ntt, cb2_P;
+  long slab_floats;
+  size_t off_gz, off_wslab, off_gupart, off_ga, total;
 };
+// slab of the weight-gradient kernel: gW_h | RB copies of gb_h | RU copies of gw_u | gb_u
+static SlabOutputs wgrad_outputs(const lmufft_shape& s, float* gW_h, float* gb_h, float* gw_u, float* gb_u) {
+  using TL = WgradTileB;
+  const int MD = s.M + s.D;
+  const int tiles_j = cdivb(MD, TL::BN), tiles_n = cdivb(s.Hd, TL::BM);
+  return SlabOutputs{{gW_h, gb_h, gw_u, gb_u},
+                     {(long)s.Hd * MD, s.Hd, s.D, 1},
+                     {1, tiles_j * TL::WGN, tiles_n * TL::WGM, 1}};
+}
+
 static BwdPlanB plan_backward_b(const lmufft_shape& s) {
   BwdPlanB p;
   const long rows = (long)s.B * s.T;
   const int MD = s.M + s.D;
   const int tiles = cdivb(s.Hd, WgradTileB::BM) * cdivb(MD, WgradTileB::BN);
-  int S = (256 + tiles - 1) / tiles;  // about one workgroup per CU: every slab costs a write and a read of gW_h
+  // whole row ranges per XCD (32 CUs each), one workgroup per CU at most; every slab also costs a
+  // write and a read of gW_h
+  int S = 8 * std::max(1, 32 / tiles);
   int rps = cdivb(rows, S);
   rps = cdivb(rps, WgradTileB::BK) * WgradTileB::BK;
   p.S = cdivb(rows, rps);
   p.rps = rps;
   p.ntt = cdivb(s.T, ConvBwdTileB::BM);
-  p.enc_blocks = cdivb(rows, kEncRowsPerBlockB);
-  p.relu_blocks = cdivb(rows, kReluRowsPerBlock);
+  p.slab_floats = slab_stride(wgrad_outputs(s, nullptr, nullptr, nullptr, nullptr));
   size_t off = 0;
   p.off_gz = off;
   off += align256b(sizeof(bf16_t) * (size_t)rows * s.Hd);
-  p.off_relupart = off;
-  off += align256b(sizeof(float) * (size_t)p.relu_blocks * s.Hd);
   p.off_wslab = off;
-  off += align256b(sizeof(float) * (size_t)p.S * ((size_t)s.Hd * MD));
+  off += align256b(sizeof(float) * (size_t)p.S * (size_t)p.slab_floats);
   {  // second form of the adjoint convolution: P frame ranges per s tile
     const int tiles = cdivb(s.T, kCb2St) * cdivb(s.B, kCb2Bt);
     p.cb2_P = std::max(1, std::min(std::min(32, s.T), (768 + tiles - 1) / tiles));
@@ -807,8 +843,6 @@ static BwdPlanB plan_backward_b(const lmufft_shape& s) {
   off += align256b(sizeof(float) * std::max((size_t)s.B * p.ntt * s.T, (size_t)p.cb2_P * s.B * s.T));
   p.off_ga = off;
   off += align256b(sizeof(float) * (size_t)rows);
-  p.off_encpart = off;
-  off += align256b(sizeof(float) * (size_t)p.enc_blocks * (s.D + 1));
   p.total = off;
   return p;
 }
@@ -993,31 +1027,26 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
   float* wslab = (float*)(ws + p.off_wslab);
   float* gupart = (float*)(ws + p.off_gupart);
   float* ga = (float*)(ws + p.off_ga);
-  float* encpart = (float*)(ws + p.off_encpart);
   const long rows = (long)s->B * s->T;
   const int MD = s->M + s->D;
   const HprepLayout hl = hprep_layout(s->M, s->ldH);
   const bf16_t* HbT = (const bf16_t*)((const char*)hprep + hl.off_HbT);
   bf16_t* gz = (bf16_t*)(ws + p.off_gz);
-  float* relupart = (float*)(ws + p.off_relupart);
   const bool vec_h = (s->Hd % 8 == 0) && (s->Hd / 8 <= kThreads) && al16(h) && (!gh || al16(gh)) &&
                      (!gh_n || al16(gh_n));
 
-  {  // gz = relu'(h) * (gh + gh_n), gb_h
-    const dim3 grid(p.relu_blocks);
+  {  // gz = relu'(h) * (gh + gh_n)
+    const long work = vec_h ? rows * (s->Hd / 8) : rows * s->Hd;
+    const dim3 grid(std::min<long>((work + kThreads - 1) / kThreads, 8192));
     {
       PROFB("k_relu_bwd_bf16");
-      if (vec_h) {
-        const int RP = kThreads / (s->Hd / 8);
-        hipLaunchKernelGGL(k_relu_bwd_bf16<true>, grid, dim3(kThreads), sizeof(float) * (size_t)RP * s->Hd, st, h, gh,
-                           gh_n, gz, relupart, (int)rows, s->T, s->Hd, kReluRowsPerBlock);
-      } else {
-        hipLaunchKernelGGL(k_relu_bwd_bf16<false>, grid, dim3(kThreads), 0, st, h, gh, gh_n, gz, relupart,
-                           (int)rows, s->T, s->Hd, kReluRowsPerBlock);
-      }
+      if (vec_h)
+        hipLaunchKernelGGL(k_relu_bwd_bf16<true>, grid, dim3(kThreads), 0, st, h, gh, gh_n, gz, (int)rows, s->T, s->Hd);
+      else
+        hipLaunchKernelGGL(k_relu_bwd_bf16<false>, grid, dim3(kThreads), 0, st, h, gh, gh_n, gz, (int)rows, s->T,
+                           s->Hd);
     }
     LAUNCH_CHECKB("k_relu_bwd_bf16");
-    if (int rc = launch_reduce_slabs(relupart, p.relu_blocks, (long)s->Hd, gb_h, (long)s->Hd, gb_h, 0L, st)) return rc;
   }
 
   // out = gz W_h[:, j_begin : j_begin + ncols] (+ ga w_u), LDS-DMA kernel when everything is 16-byte friendly
@@ -1102,39 +1131,22 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
   // gx = gz W_h[:, M:] + ga w_u
   if (gx)
     if (int rc = dgrad(DgradXGldsTile{}, DgradXTileB{}, "k_dgrad_x_bf16", gx, s->M, s->D, (const float*)ga, w_u)) return rc;
-  {  // gW_h
+  {  // gW_h, gb_h, gw_u, gb_u
     using TL = WgradTileB;
     const bool vec = (s->Hd % 8 == 0) && (s->M % 8 == 0) && (s->D % 8 == 0) && al16(m) && al16(x);
-    const dim3 grid(cdivb(MD, TL::BN), cdivb(s->Hd, TL::BM), p.S);
-    const size_t lds = sizeof(bf16_t) * (size_t)TL::BK * ((TL::BM + 32) + (TL::BN + 32));
+    const dim3 grid(xcd_grid(p.S, cdivb(MD, TL::BN) * cdivb(s->Hd, TL::BM)));
+    const size_t lds = sizeof(bf16_t) * (size_t)TL::BK * ((TL::BM + 32) + (TL::BN + 32)) + sizeof(float) * TL::BK;
     {
       PROFB("k_wgrad_bf16");
       if (vec)
-        hipLaunchKernelGGL(k_wgrad_bf16<true>, grid, dim3(kThreads), lds, st, (const bf16_t*)gz, m, x, wslab,
-                           (int)rows, p.rps, s->M, s->D, s->Hd);
+        hipLaunchKernelGGL(k_wgrad_bf16<true>, grid, dim3(kThreads), lds, st, (const bf16_t*)gz, m, x,
+                           (const float*)ga, wslab, (int)rows, p.rps, s->M, s->D, s->Hd);
       else
-        hipLaunchKernelGGL(k_wgrad_bf16<false>, grid, dim3(kThreads), lds, st, (const bf16_t*)gz, m, x, wslab,
-                           (int)rows, p.rps, s->M, s->D, s->Hd);
+        hipLaunchKernelGGL(k_wgrad_bf16<false>, grid, dim3(kThreads), lds, st, (const bf16_t*)gz, m, x,
+                           (const float*)ga, wslab, (int)rows, p.rps, s->M, s->D, s->Hd);
     }
     LAUNCH_CHECKB("k_wgrad_bf16");
-    const long n0 = (long)s->Hd * MD;
-    if (int rc = launch_reduce_slabs(wslab, p.S, n0, gW_h, n0, gW_h, 0L, st)) return rc;
-  }
-  {  // gw_u, gb_u
-    const bool vec = (s->D % 8 == 0) && al16(x);
-    const dim3 grid(p.enc_blocks);
-    {
-      PROFB("k_encode_bwd_bf16");
-      if (vec)
-        hipLaunchKernelGGL(k_encode_bwd_bf16<true>, grid, dim3(kThreads), 0, st, ga, x, encpart, (int)rows, s->D,
-                           kEncRowsPerBlockB);
-      else
-        hipLaunchKernelGGL(k_encode_bwd_bf16<false>, grid, dim3(kThreads), 0, st, ga, x, encpart, (int)rows, s->D,
-                           kEncRowsPerBlockB);
-    }
-    LAUNCH_CHECKB("k_encode_bwd_bf16");
-    if (int rc = launch_reduce_slabs(encpart, p.enc_blocks, (long)(s->D + 1), gw_u, (long)s->D, gb_u, 1L, st))
-      return rc;
+    if (int rc = launch_reduce_slabs(wslab, p.S, wgrad_outputs(*s, gW_h, gb_h, gw_u, gb_u), st)) return rc;
   }
   return 0;
 }

@@ -121,8 +121,11 @@ __global__ __launch_bounds__(kThreads) void k_proj_fwd(const float* __restrict__
                                                        int rows, int T, int M, int D, int Hd) {
   using TL = ProjTile;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int n0 = blockIdx.x * TL::BN;
-  const int m0 = blockIdx.y * TL::BM;
+  // the column tiles of one row tile share [m;x]: same XCD
+  const XcdSlot slot = xcd_slot((Hd + TL::BN - 1) / TL::BN);
+  const int n0 = slot.member * TL::BN;
+  const int m0 = slot.group * TL::BM;
+  if (m0 >= rows) return;
   const int K = M + D;
 
   auto la = plain_load([=](int r, int k) -> f32x4 {
@@ -241,8 +244,11 @@ __global__ __launch_bounds__(kThreads) void k_dgrad(const float* __restrict__ h,
                                                     int ldw, int j_begin, int ncols) {
   using TL = DgradTile;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int n0 = blockIdx.x * TL::BN;
-  const int m0 = blockIdx.y * TL::BM;
+  // the column tiles of one row tile share h and gh: same XCD
+  const XcdSlot slot = xcd_slot((ncols + TL::BN - 1) / TL::BN);
+  const int n0 = slot.member * TL::BN;
+  const int m0 = slot.group * TL::BM;
+  if (m0 >= rows) return;
 
   const GzRowsLoad<VEC> la{{h, gh, gh_n, T, Hd}, (long)m0, rows};
   // B[k = hidden index][j]: W_h rows are contiguous along j -> NC layout
@@ -282,13 +288,18 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(const float* __restrict__ h,
                                                     int T, int M, int D, int Hd) {
   using TL = WgradTile;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int j0 = blockIdx.x * TL::BN;
-  const int n0 = blockIdx.y * TL::BM;
   const int MD = M + D;
-  const int kbeg = blockIdx.z * rows_per_split;
+  // all output tiles of one row range share its slices of gz and [m;x]: same XCD
+  const int tiles_j = (MD + TL::BN - 1) / TL::BN, tiles_n = (Hd + TL::BM - 1) / TL::BM;
+  const XcdSlot slot = xcd_slot(tiles_j * tiles_n);
+  const int tile_j = slot.member % tiles_j;
+  const int j0 = tile_j * TL::BN;
+  const int n0 = (slot.member / tiles_j) * TL::BM;
+  const int kbeg = slot.group * rows_per_split;
+  if (kbeg >= rows) return;
   const int kend = min(rows, kbeg + rows_per_split);
-  const long slab_stride = (long)Hd * MD + Hd;
-  float* slab = slabs + blockIdx.z * slab_stride;
+  const long bias_off = ((long)Hd * MD + 3) & ~3L;  // segments start on multiples of four floats
+  float* slab = slabs + slot.group * (bias_off + ((Hd + 3) & ~3));
 
   const GzColsLoad<VEC> la{{h, gh, gh_n, T, Hd}, n0, kend};
   auto lb = plain_load([=](int r, int k) -> f32x4 {
@@ -321,7 +332,7 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(const float* __restrict__ h,
   typename decltype(la)::raw_t ra[TL::A_VECS];
   typename decltype(lb)::raw_t rb[TL::B_VECS];
   float colsum = 0.f;
-  const bool do_bias = blockIdx.x == 0 && threadIdx.x < TL::BM;
+  const bool do_bias = tile_j == 0 && threadIdx.x < TL::BM;
   if (kbeg < kend) {
     tile_fetch<TL::BM, TL::BK, TL::ALAY>(ra, la, kbeg);
     tile_fetch<TL::BN, TL::BK, TL::BLAY>(rb, lb, kbeg);
@@ -346,7 +357,7 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(const float* __restrict__ h,
     const int n = n0 + mm, j = j0 + nn;
     if (n < Hd && j < MD) slab[(long)n * MD + j] = v;
   });
-  if (do_bias && n0 + (int)threadIdx.x < Hd) slab[(long)Hd * MD + n0 + threadIdx.x] = colsum;
+  if (do_bias && n0 + (int)threadIdx.x < Hd) slab[bias_off + n0 + threadIdx.x] = colsum;
 }
 
 // ---------------------------------------------------------------------------
@@ -419,7 +430,7 @@ __global__ __launch_bounds__(kThreads) void k_gu_reduce(const float* __restrict_
 // ---------------------------------------------------------------------------
 // partial gw_u = sum_rows ga[row] x[row,:], partial gb_u = sum_rows ga[row]
 // One wave per row; rows with ga == 0 (ReLU-dead frames, about half of them)
-// do not touch x.  Slab per workgroup: [D + 1].
+// do not touch x.  Slab per workgroup: [D rounded up to 4 | gb_u + 3 unused].
 // ---------------------------------------------------------------------------
 template <bool VEC>
 __global__ __launch_bounds__(kThreads) void k_encode_bwd(const float* __restrict__ ga,
@@ -429,7 +440,8 @@ __global__ __launch_bounds__(kThreads) void k_encode_bwd(const float* __restrict
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(rows, r0 + rows_per_block);
-  float* slab = part + (long)blockIdx.x * (D + 1);
+  const int Dp = (D + 3) & ~3;
+  float* slab = part + (long)blockIdx.x * (Dp + 4);
 
   for (int c0 = 0; c0 < D; c0 += 256) {
     const int c = c0 + lane * 4;
@@ -450,58 +462,85 @@ __global__ __launch_bounds__(kThreads) void k_encode_bwd(const float* __restrict
       __syncthreads();
       if (lane == 0) red[wave][0] = gsum;
       __syncthreads();
-      if (threadIdx.x == 0) slab[D] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+      if (threadIdx.x == 0) slab[Dp] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
     }
   }
 }
 
-// out0[i] (i < n0) and out1[i - n0] (n0 <= i < n0+n1) = sum_s in[s*stride + i],
-// slabs added in index order (deterministic).  Eight slabs are in flight per
-// thread; with VEC each thread owns four consecutive outputs (stride, n0 % 4 == 0).
-template <bool VEC>
+// Sum of S slabs (and of the partial copies inside a slab), added in a fixed order
+// (deterministic).  A thread owns four consecutive outputs and keeps eight slabs in flight;
+// in a segment with several copies per slab, eight neighbouring lanes share the four outputs,
+// each summing the copies r, r + 8, ... and a fixed xor tree combining them.
+struct SlabBounds {
+  long tb[5];    // boundaries of the segments in thread slots (multiples of 8)
+  long so[4];    // offset of every segment inside a slab
+  long pn[4];    // padded copy length
+  int reps[4];
+  int lanes[4];  // 1 or 8 lanes per four outputs
+};
+__device__ __forceinline__ int slab_segment(const long* bounds, long i) {
+  return (i >= bounds[1]) + (i >= bounds[2]) + (i >= bounds[3]);
+}
+template <class T>
+__device__ __forceinline__ T pick4(const T* a, int q) {
+  return q == 0 ? a[0] : (q == 1 ? a[1] : (q == 2 ? a[2] : a[3]));
+}
+__device__ __forceinline__ void slab_store4(const SlabOutputs& o, int seg, long local, const float (&v)[4]) {
+  float* dst = pick4(o.out, seg);
+  const long nn = pick4(o.n, seg);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (local + j < nn) dst[local + j] = v[j];
+}
+
 __global__ __launch_bounds__(kThreads) void k_reduce_slabs(const float* __restrict__ in, int S, long stride,
-                                                           float* __restrict__ out0, long n0,
-                                                           float* __restrict__ out1, long n1) {
-  const long n = n0 + n1;
-  constexpr int W = VEC ? 4 : 1;
-  typedef typename std::conditional<VEC, f32x4, float>::type vec_t;
-  for (long i = (blockIdx.x * (long)kThreads + threadIdx.x) * W; i < n; i += (long)gridDim.x * kThreads * W) {
-    vec_t s = vec_t(0.f);
-    int k = 0;
-    for (; k + 8 <= S; k += 8) {
-      vec_t v[8];
+                                                           SlabOutputs o, SlabBounds sb) {
+  // tb[4] and the grid stride are multiples of 8: the eight lanes of a group leave the loop together
+  for (long t = blockIdx.x * (long)kThreads + threadIdx.x; t < sb.tb[4]; t += (long)gridDim.x * kThreads) {
+    const int seg = slab_segment(sb.tb, t);
+    const long lt = t - pick4(sb.tb, seg);
+    const int L = pick4(sb.lanes, seg);
+    const long local = (L == 8 ? lt >> 3 : lt) * 4;
+    const int r0 = L == 8 ? (int)(lt & 7) : 0;
+    const long pn = pick4(sb.pn, seg);
+    const int reps = pick4(sb.reps, seg);
+    f32x4 s = f32x4(0.f);
+    if (local < pn) {
+      const float* src = in + pick4(sb.so, seg) + local + (long)r0 * pn;
+      for (int r = r0; r < reps; r += L, src += (long)L * pn) {
+        int k = 0;
+        for (; k + 8 <= S; k += 8) {
+          f32x4 v[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const vec_t*>(in + (k + q) * stride + i);
+          for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const f32x4*>(src + (k + q) * stride);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) s += v[q];
+          for (int q = 0; q < 8; ++q) s += v[q];
+        }
+        for (; k < S; ++k) s += *reinterpret_cast<const f32x4*>(src + k * stride);
+      }
     }
-    for (; k < S; ++k) s += *reinterpret_cast<const vec_t*>(in + k * stride + i);
-    float o[4];
-    *reinterpret_cast<vec_t*>(o) = s;
+    float o4[4] = {s[0], s[1], s[2], s[3]};
 #pragma unroll
-    for (int j = 0; j < W; ++j) {
-      const long idx = i + j;
-      if (idx < n0)
-        out0[idx] = o[j];
-      else if (idx < n)
-        out1[idx - n0] = o[j];
-    }
+    for (int m = 1; m < 8; m <<= 1)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float other = __shfl_xor(o4[j], m);
+        o4[j] += L == 8 ? other : 0.f;
+      }
+    if (r0 == 0 && local < pn) slab_store4(o, seg, local, o4);
   }
 }
 
-// Same sum for FEW outputs and MANY slabs (the encoder's weight gradient:
-// D + 1 outputs, one slab per 32 frames): a workgroup owns 32 outputs, its 8
-// thread rows split the slabs; partial sums are combined through LDS in a
-// fixed order, so the result is deterministic.
+// Same sum for FEW outputs and MANY slabs (the encoder's weight gradient: D + 1 outputs, one
+// slab per 64 frames): a workgroup owns 32 slab positions, its 8 thread rows split the slabs;
+// partial sums are combined through LDS in a fixed order.
 __global__ __launch_bounds__(kThreads) void k_reduce_slabs_tall(const float* __restrict__ in, int S, long stride,
-                                                                float* __restrict__ out0, long n0,
-                                                                float* __restrict__ out1, long n1) {
+                                                                SlabOutputs o, SlabBounds sb) {
   __shared__ float red[8][32];
   const int col = threadIdx.x & 31, part = threadIdx.x >> 5;
-  const long i = blockIdx.x * 32L + col;
-  const long n = n0 + n1;
+  const long i = blockIdx.x * 32L + col;  // one copy per segment here: slab offset == output index
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (i < n) {
+  if (i < stride) {
     int k = part;
     for (; k + 24 < S; k += 32) {
       s0 += in[(long)k * stride + i];
@@ -513,14 +552,17 @@ __global__ __launch_bounds__(kThreads) void k_reduce_slabs_tall(const float* __r
   }
   red[part][col] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (part == 0 && i < n) {
-    float s = 0.f;
+  if (part == 0 && (col & 3) == 0 && i < stride) {
+    float v[4];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) s += red[q][col];
-    if (i < n0)
-      out0[i] = s;
-    else
-      out1[i - n0] = s;
+    for (int j = 0; j < 4; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += red[q][col + j];
+      v[j] = s;
+    }
+    const int seg = slab_segment(sb.so, i);
+    slab_store4(o, seg, i - pick4(sb.so, seg), v);
   }
 }
 
@@ -555,7 +597,8 @@ constexpr int kEncRowsPerBlock = 64;
 
 static int wgrad_splits(long rows, int Hd, int MD, int* rows_per_split) {
   const int tiles = cdiv(Hd, WgradTile::BM) * cdiv(MD, WgradTile::BN);
-  int S = (256 + tiles - 1) / tiles;  // about one workgroup per CU
+  // whole row ranges per XCD (32 CUs each), one workgroup per CU at most
+  int S = 8 * std::max(1, 32 / tiles);
   int rps = cdiv(rows, S);
   rps = cdiv(rps, WgradTile::BK) * WgradTile::BK;
   S = cdiv(rows, rps);
@@ -577,13 +620,13 @@ static BwdPlan plan_backward(const lmufft_shape& s) {
   p.enc_blocks = cdiv(rows, kEncRowsPerBlock);
   size_t off = 0;
   p.off_wslab = off;
-  off += align256(sizeof(float) * (size_t)p.S * ((size_t)s.Hd * MD + s.Hd));
+  off += align256(sizeof(float) * (size_t)p.S * (slab_seg_pad((long)s.Hd * MD) + slab_seg_pad(s.Hd)));
   p.off_gupart = off;
   off += align256(sizeof(float) * (size_t)s.B * std::max(p.ntt, fft_conv_groups(s.M)) * s.T);
   p.off_ga = off;
   off += align256(sizeof(float) * (size_t)rows);
   p.off_encpart = off;
-  off += align256(sizeof(float) * (size_t)p.enc_blocks * (s.D + 1));
+  off += align256(sizeof(float) * (size_t)p.enc_blocks * (slab_seg_pad(s.D) + 4));
   p.total = off;
   return p;
 }
@@ -606,28 +649,33 @@ static int check_shape(const lmufft_shape* s) {
     if (e_ != hipSuccess) return set_error("launch of %s failed: %s", name, hipGetErrorString(e_)); \
   } while (0)
 
-int launch_reduce_slabs(const float* in, int S, long stride, float* out0, long n0, float* out1, long n1,
-                        hipStream_t st) {
-  if (n0 + n1 <= 4096 && S >= 64) {  // few outputs, many slabs
+int launch_reduce_slabs(const float* in, int S, const SlabOutputs& o, hipStream_t st) {
+  if (!aligned16(in)) return set_error("workspace must be 16-byte aligned");
+  const long stride = slab_stride(o);
+  SlabBounds sb;
+  bool single = true;
+  sb.tb[0] = 0;
+  for (int q = 0; q < 4; ++q) {
+    sb.pn[q] = slab_seg_pad(o.n[q]);
+    sb.reps[q] = slab_reps(o, q);
+    sb.lanes[q] = sb.reps[q] > 1 ? 8 : 1;
+    sb.so[q] = slab_seg_offset(o, q);
+    const long slots = sb.pn[q] / 4 * sb.lanes[q];
+    sb.tb[q + 1] = sb.tb[q] + ((slots + 7) & ~7L);
+    single = single && sb.reps[q] == 1;
+  }
+  if (single && stride <= 4096 && S >= 64) {  // few outputs, many slabs
     {
       PROF("k_reduce_slabs_tall");
-      hipLaunchKernelGGL(k_reduce_slabs_tall, dim3(cdiv(n0 + n1, 32)), dim3(kThreads), 0, st, in, S, stride, out0,
-                         n0, out1, n1);
+      hipLaunchKernelGGL(k_reduce_slabs_tall, dim3(cdiv(stride, 32)), dim3(kThreads), 0, st, in, S, stride, o, sb);
     }
     LAUNCH_CHECK("k_reduce_slabs_tall");
     return 0;
   }
-  // vector path: every slab row and both outputs stay 16-byte aligned and n0 + n1 is a multiple of 4
-  const bool vec = (stride % 4 == 0) && (n0 % 4 == 0) && (n1 % 4 == 0) && aligned16(in) && aligned16(out0) &&
-                   aligned16(out1);
-  const long work = vec ? (n0 + n1) / 4 : (n0 + n1);
-  const dim3 grid(min(cdiv(work, kThreads), 4096));
+  const dim3 grid(min(cdiv(sb.tb[4], kThreads), 4096));
   {
     PROF("k_reduce_slabs");
-    if (vec)
-      hipLaunchKernelGGL(k_reduce_slabs<true>, grid, dim3(kThreads), 0, st, in, S, stride, out0, n0, out1, n1);
-    else
-      hipLaunchKernelGGL(k_reduce_slabs<false>, grid, dim3(kThreads), 0, st, in, S, stride, out0, n0, out1, n1);
+    hipLaunchKernelGGL(k_reduce_slabs, grid, dim3(kThreads), 0, st, in, S, stride, o, sb);
   }
   LAUNCH_CHECK("k_reduce_slabs");
   return 0;
@@ -815,7 +863,7 @@ int lmufft_forward_f32(const lmufft_shape* s, const float* x, const float* w_u, 
   {  // eq. 20
     using TL = ProjTile;
     const bool vec = (s->M % 4 == 0) && (s->D % 4 == 0) && aligned16(m) && aligned16(x) && aligned16(W_h);
-    const dim3 grid(cdiv(s->Hd, TL::BN), cdiv(rows, TL::BM));
+    const dim3 grid(xcd_grid(cdiv(rows, TL::BM), cdiv(s->Hd, TL::BN)));
     const size_t lds = TL::SMEM_FLOATS * sizeof(float);
     {
     PROF("k_proj_fwd");
@@ -857,7 +905,7 @@ int lmufft_backward_f32(const lmufft_shape* s, const float* x, const float* w_u,
   auto dgrad = [&](const char* name, float* out, int j_begin, int ncols, const float* ga_, const float* wu_) -> int {
     using TL = DgradTile;
     const bool vec = vec_h && (MD % 4 == 0) && (j_begin % 4 == 0) && (ncols % 4 == 0) && aligned16(W_h);
-    const dim3 grid(cdiv(ncols, TL::BN), cdiv(rows, TL::BM));
+    const dim3 grid(xcd_grid(cdiv(rows, TL::BM), cdiv(ncols, TL::BN)));
     const size_t lds = TL::SMEM_FLOATS * sizeof(float);
     {
       PROF(name);
@@ -887,7 +935,7 @@ int lmufft_backward_f32(const lmufft_shape* s, const float* x, const float* w_u,
   {  // gW_h, gb_h slabs
     using TL = WgradTile;
     const bool vec = vec_h && (s->M % 4 == 0) && (s->D % 4 == 0) && aligned16(m) && aligned16(x);
-    const dim3 grid(cdiv(MD, TL::BN), cdiv(s->Hd, TL::BM), p.S);
+    const dim3 grid(xcd_grid(p.S, cdiv(MD, TL::BN) * cdiv(s->Hd, TL::BM)));
     const size_t lds = TL::SMEM_FLOATS * sizeof(float);
     {
       PROF("k_wgrad");
@@ -900,7 +948,8 @@ int lmufft_backward_f32(const lmufft_shape* s, const float* x, const float* w_u,
     }
     LAUNCH_CHECK("k_wgrad");
     const long n0 = (long)s->Hd * MD;
-    if (int rc = launch_reduce_slabs(wslab, p.S, n0 + s->Hd, gW_h, n0, gb_h, (long)s->Hd, st)) return rc;
+    if (int rc = launch_reduce_slabs(wslab, p.S, SlabOutputs{{gW_h, gb_h, nullptr, nullptr}, {n0, s->Hd, 0, 0}, {1, 1, 1, 1}}, st))
+      return rc;
   }
   {  // gw_u, gb_u
     const bool vec = (s->D % 4 == 0) && aligned16(x);
@@ -915,7 +964,9 @@ int lmufft_backward_f32(const lmufft_shape* s, const float* x, const float* w_u,
                            kEncRowsPerBlock);
     }
     LAUNCH_CHECK("k_encode_bwd");
-    if (int rc = launch_reduce_slabs(encpart, p.enc_blocks, (long)(s->D + 1), gw_u, (long)s->D, gb_u, 1L, st)) return rc;
+    if (int rc = launch_reduce_slabs(encpart, p.enc_blocks, SlabOutputs{{gw_u, gb_u, nullptr, nullptr}, {s->D, 1, 0, 0}, {1, 1, 1, 1}},
+                                     st))
+      return rc;
   }
   return 0;
 }

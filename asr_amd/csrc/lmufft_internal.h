@@ -22,9 +22,24 @@ inline int set_error(const char* fmt, ...) {
   return 1;
 }
 
-// shared launchers (defined in lmufft_f32.hip)
-int launch_reduce_slabs(const float* in, int S, long stride, float* out0, long n0, float* out1, long n1,
-                        hipStream_t st);
+// Partial results of split reductions are written as S "slabs" of `stride` floats; a slab holds up
+// to four segments (e.g. gW_h | gb_h | gw_u | gb_u).  Segment q is reps[q] partial copies of n[q]
+// floats, every copy starting on a multiple of four floats.
+struct SlabOutputs {
+  float* out[4];  // destination of every segment (NULL / n = 0 for unused ones)
+  long n[4];      // elements per segment
+  int reps[4];    // partial copies per slab (0 is read as 1)
+};
+inline long slab_seg_pad(long n) { return (n + 3) & ~3L; }
+inline int slab_reps(const SlabOutputs& o, int q) { return o.reps[q] > 0 ? o.reps[q] : 1; }
+inline long slab_seg_offset(const SlabOutputs& o, int q) {
+  long off = 0;
+  for (int i = 0; i < q; ++i) off += slab_reps(o, i) * slab_seg_pad(o.n[i]);
+  return off;
+}
+inline long slab_stride(const SlabOutputs& o) { return slab_seg_offset(o, 4); }
+// out[q][i] = sum over slabs and copies, added in a fixed order (deterministic); defined in lmufft_f32.hip
+int launch_reduce_slabs(const float* in, int S, const SlabOutputs& o, hipStream_t st);
 int launch_gu_reduce(const float* gu_part, const float* u, float* out, int B, int T, int ntt, int tile_t,
                      hipStream_t st);
 // workspace sizes of the bf16 path (defined in lmufft_bf16.hip)

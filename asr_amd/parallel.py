@@ -32,12 +32,16 @@ class GradBuckets:
     DistributedDataParallel without find_unused_parameters).
     """
 
-    def __init__(self, groups: Sequence, process_group=None, average: bool = True):
+    def __init__(self, groups: Sequence, process_group=None, average: bool = True, overlap: bool = True):
         from .functional import GradSink
         from .lmu import LMUFFT
 
         self.group = process_group
         self.average = average
+        # overlap=True: a bucket's all-reduce starts as soon as its gradients are complete, during the
+        # backward.  overlap=False: finish() starts them all -- for steps replayed from a HIP graph,
+        # whose backward runs no Python.
+        self.overlap = overlap
         self.buckets: List[torch.Tensor] = []
         self._params: List[List[torch.nn.Parameter]] = []
         self._views: List[List[torch.Tensor]] = []
@@ -95,7 +99,9 @@ class GradBuckets:
 
         return hook
 
-    def _launch(self, bi: int) -> None:
+    def _launch(self, bi: int, force: bool = False) -> None:
+        if not (self.overlap or force):
+            return
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
             self._handles.append(dist.all_reduce(self.buckets[bi], op=dist.ReduceOp.SUM, group=self.group,
                                                  async_op=True))
@@ -116,6 +122,9 @@ class GradBuckets:
 
     def finish(self) -> None:
         """Wait for the outstanding all-reduces and turn sums into means."""
+        if not self.overlap:
+            for bi in range(len(self.buckets)):
+                self._launch(bi, force=True)
         for h in self._handles:
             h.wait()
         self._handles = []
@@ -124,6 +133,25 @@ class GradBuckets:
             if ws > 1:
                 for flat in self.buckets:
                     flat.div_(ws)
+
+    def capture_step(self, fn):
+        """Capture fn() -- forward and backward of one step on static tensors -- into a HIP graph
+        and return a callable that replays it and then exchanges the gradients.  The kernels of
+        this library allocate nothing and launch on the capturing stream; gradients land in the
+        flat buckets, whose addresses are fixed.  Call after a few eager warm-up steps."""
+        self.overlap = False
+        self.zero_grad()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            fn()
+        self._graph = graph  # keeps the graph's private memory pool alive
+
+        def step():
+            self._handles = []
+            graph.replay()
+            self.finish()
+
+        return step
 
     def remove(self) -> None:
         for h in self._hooks:

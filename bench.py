@@ -43,6 +43,7 @@ def parse_args():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"],
                     help="activation / MFMA operand type (fp32 accumulation either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
@@ -153,14 +154,19 @@ def main():
     x = torch.randn(B, T, D, device=dev, generator=g).to(tdt).requires_grad_(True)
     gy = torch.randn(B, T, Hd, device=dev, generator=g).to(tdt)
 
-    def step():
-        buckets.zero_grad()
-        x.grad = None
+    def fwd_bwd():
         y = x
         for l in layers:
             y, _ = l(y)
         y.backward(gy)
+
+    def step_eager():
+        buckets.zero_grad()
+        x.grad = None
+        fwd_bwd()
         buckets.finish()
+
+    step = step_eager
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -168,8 +174,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
+    for _ in range(max(1, args.warmup if args.no_graph else 3)):
+        step_eager()
+    if not args.no_graph:
+        # the whole forward+backward as one HIP graph: the step is ~40 short kernels, and launching
+        # them one by one from Python costs about as much as running them
+        x.grad = None
+        step = buckets.capture_step(fwd_bwd)
+        for _ in range(args.warmup):
+            step()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -187,8 +200,9 @@ def main():
     if rank == 0:
         _lib.profile_reset()
         _lib.profile_enable(True)
+    buckets.overlap = True
     for _ in range(min(args.steps, 10)):
-        step()
+        step_eager()
     torch.cuda.synchronize(dev)
     if rank == 0:
         _lib.profile_enable(False)
@@ -245,6 +259,7 @@ def main():
                             f"accumulation and fp32 parameters, conv={args.conv}; "
                             "BASELINE config 2 layer shape",
                 "batch_per_gpu": B, "frames": T, "layers": args.layers, "parallelism": f"dp{world}",
+                "launch": "eager" if args.no_graph else "hip graph replay",
             },
             "roofline": roofline,
             "step_hbm": {"algorithmic_bytes_per_step": layer_bytes,
