@@ -145,7 +145,7 @@ __device__ __forceinline__ void gemm_loop_glds(const OA& a, const OB& b, f32x16 
 // All LDS of the kernel must live in the one dynamic array the stages are carved from.
 template <class T, int NS, class OA, class OB>
 __device__ __forceinline__ void gemm_loop_glds_deep(const OA& a, const OB& b, f32x16 (&acc)[T::TM][T::TN],
-                                                    int kbeg, int kend, const WavePos<T>& w, int dbg = 0) {
+                                                    int kbeg, int kend, const WavePos<T>& w) {
   static_assert(T::BK == 32, "k-tile of 32");
   constexpr int G = OA::NI + OB::NI;          // LDS-DMA instructions per wave and k-tile
   constexpr int KEEP = G * (NS - 2);          // may stay outstanding when a tile is consumed
@@ -161,7 +161,6 @@ __device__ __forceinline__ void gemm_loop_glds_deep(const OA& a, const OB& b, f3
     __builtin_amdgcn_s_barrier();
     a.issue(pf, k0 + (NS - 1) * T::BK);
     b.issue(pf, k0 + (NS - 1) * T::BK);
-    if (!(dbg & 1)) {
 #pragma unroll
     for (int kl = 0; kl < T::BK; kl += 16) {
       bf16x8 af[T::TM], bfr[T::TN];
@@ -174,7 +173,6 @@ __device__ __forceinline__ void gemm_loop_glds_deep(const OA& a, const OB& b, f3
 #pragma unroll
         for (int tn = 0; tn < T::TN; ++tn)
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bfr[tn], acc[tm][tn], 0, 0, 0);
-    }
     }
     stage = stage + 1 == NS ? 0 : stage + 1;
     pf = pf + 1 == NS ? 0 : pf + 1;

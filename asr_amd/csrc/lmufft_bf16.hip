@@ -249,7 +249,7 @@ constexpr int kProjStages = 4;
 __global__ __launch_bounds__(ProjGldsTile::THREADS) void k_proj_fwd_glds_bf16(
     const bf16_t* __restrict__ m, const bf16_t* __restrict__ x, const bf16_t* __restrict__ Wb,
     const float* __restrict__ bias, bf16_t* __restrict__ h, bf16_t* __restrict__ h_n, int rows, int T, int M, int D,
-    int Hd, int ldW, int dbg) {
+    int Hd, int ldW) {
   using TL = ProjGldsTile;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int n0 = blockIdx.x * TL::BN;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(ProjGldsTile::THREADS) void k_proj_fwd_glds_bf16(
       smem_raw,
       [&](int r, const bf16_t*& q0, const bf16_t*& q1) {
         const long row = m0 + r;
-        if (row >= rows || (dbg & 4)) return false;
+        if (row >= rows) return false;
         q0 = m + row * M;
         q1 = x + row * D - M;
         return true;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(ProjGldsTile::THREADS) void k_proj_fwd_glds_bf16(
       smem_raw + kProjStages * OpA::STAGE_BYTES,
       [&](int r, const bf16_t*& q0, const bf16_t*&) {
         const int n = n0 + r;
-        if (n >= Hd || (dbg & 8)) return false;
+        if (n >= Hd) return false;
         q0 = Wb + (long)n * ldW;
         return true;
       },
@@ -282,8 +282,7 @@ __global__ __launch_bounds__(ProjGldsTile::THREADS) void k_proj_fwd_glds_bf16(
   WavePos<TL> w;
   f32x16 acc[TL::TM][TL::TN];
   tileb_zero<TL>(acc);
-  gemm_loop_glds_deep<TL, kProjStages>(oa, ob, acc, 0, K, w, dbg);
-  if (dbg & 2) return;
+  gemm_loop_glds_deep<TL, kProjStages>(oa, ob, acc, 0, K, w);
 
   float bcol[TL::TN];
   preload_cols<TL>(bcol, w, [&](int nn) { return n0 + nn < Hd ? bias[n0 + nn] : 0.f; });
@@ -983,9 +982,8 @@ int lmufft_forward_bf16(const lmufft_shape* s, const void* x_, const float* w_u,
         return set_error("cannot reserve %zu bytes of LDS for k_proj_fwd_glds_bf16", lds);
       {
         PROFB("k_proj_fwd_bf16");
-        static const int dbg = getenv("LMUFFT_DBG") ? atoi(getenv("LMUFFT_DBG")) : 0;
         hipLaunchKernelGGL(k_proj_fwd_glds_bf16, grid, dim3(TG::THREADS), lds, st, m, x, Wb, b_h, h, h_n, (int)rows,
-                           s->T, s->M, s->D, s->Hd, ldW, dbg);
+                           s->T, s->M, s->D, s->Hd, ldW);
       }
     } else {
       const dim3 grid(cdivb(s->Hd, TL::BN), cdivb(rows, TL::BM));

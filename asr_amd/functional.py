@@ -11,8 +11,6 @@ import torch
 
 from . import _lib
 
-_DEBUG = None  # set to a dict by kernel-debugging scripts to capture intermediates of the last backward
-
 _ALGOS = {"auto": _lib.CONV_AUTO, "toeplitz": _lib.CONV_TOEPLITZ, "fft": _lib.CONV_FFT}
 _DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
 
@@ -216,8 +214,6 @@ class _LMUFFTFunction(torch.autograd.Function):
                     ctx.conv_algo, _ptr(ws), ws.numel(), _stream(dev))
                 what = "lmufft_backward_bf16"
         _lib.check(rc, what)
-        if _DEBUG is not None:
-            _DEBUG.update(gm=gm, u=u, m=m)
         if direct:
             sink.commit()
             return (gx,) + (None,) * 9

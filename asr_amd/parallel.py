@@ -142,7 +142,9 @@ class GradBuckets:
         self.overlap = False
         self.zero_grad()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: calls made meanwhile by other threads (e.g. the process group's watchdog)
+        # neither break nor join the capture
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             fn()
         self._graph = graph  # keeps the graph's private memory pool alive
 

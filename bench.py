@@ -180,7 +180,13 @@ def main():
         # the whole forward+backward as one HIP graph: the step is ~40 short kernels, and launching
         # them one by one from Python costs about as much as running them
         x.grad = None
-        step = buckets.capture_step(fwd_bwd)
+        try:
+            step = buckets.capture_step(fwd_bwd)
+        except Exception as e:  # fall back to eager launches rather than lose the measurement
+            print(f"[bench] HIP graph capture failed ({type(e).__name__}: {e}); launching eagerly", file=sys.stderr)
+            args.no_graph = True
+            buckets.overlap = True
+            torch.cuda.synchronize(dev)
         for _ in range(args.warmup):
             step()
     sync()

@@ -94,6 +94,7 @@ SHAPES = [
     (2, 65, 80, 192, 384, 100),
     (3, 200, 384, 192, 384, 200),  # BASELINE config 1c
     (2, 400, 80, 192, 384, 400),   # BASELINE config 1a
+    (1, 1200, 24, 192, 64, 1200),  # long utterance: many k-parts in both convolution kernels
 ]
 
 

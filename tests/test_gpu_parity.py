@@ -89,6 +89,27 @@ def test_conv_backward_matches_oracle(B, T, M, ldH):
     _close(got, orc.anticausal_corr_direct(gm, H[:, :T]), "gu")
 
 
+def test_conv_long_utterance_3000_frames():
+    """BASELINE's long-utterance shape (T = 3000, memory 192) on the Toeplitz kernels, against
+    the oracle's FFT evaluation of the same sums (the direct double sum is O(T^2) on the CPU)."""
+    from asr_amd import causal_conv, causal_conv_adjoint
+
+    dev = _dev()
+    rng = np.random.default_rng(3000)
+    B, T, M = 2, 3000, 192
+    u = np.maximum(rng.standard_normal((B, T)), 0).astype(np.float32)
+    gm = rng.standard_normal((B, T, M)).astype(np.float32)
+    H = _rand_H(rng, M, T)
+    m = causal_conv(_t(u, dev), _t(H, dev)).cpu().numpy()
+    _close(m, orc.causal_conv_fft(u.astype(np.float64), H.astype(np.float64)), "m")
+    # adjoint through the identity <conv(v), gm> = <v, adj(gm)> for unit impulses v = e_s
+    gu = causal_conv_adjoint(_t(gm, dev), _t(H, dev)).cpu().numpy()
+    Hd = H.astype(np.float64)
+    for s in (0, 1, 1499, 2999):
+        want = np.einsum("btk,kt->b", gm[:, s:, :].astype(np.float64), Hd[:, : T - s])
+        np.testing.assert_allclose(gu[:, s], want, rtol=1e-4, atol=1e-5 * np.abs(gu).max())
+
+
 def test_conv_known_answers_full_size(golden_dir):
     """Size-independent properties at BASELINE's full size (B=64, T=400, M=192)."""
     from asr_amd import causal_conv, causal_conv_adjoint
