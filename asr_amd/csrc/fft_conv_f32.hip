@@ -12,23 +12,33 @@
 // spectrum: M/2 forward FFTs and ONE inverse FFT per batch item and k group.
 //
 // One wave owns one 1024-point (or smaller) transform: 64 lanes x N/64 points,
-// Stockham autosort stages of radix 16, 16, N/256 with the butterflies in
-// registers and the exchanges through a wave-private LDS buffer whose index is
-// padded by one element per 16 (conflict-free ds_read_b64 / ds_write_b64).
+// Stockham stages of radix 16, 16, N/256 with the butterflies in registers and
+// the exchanges through ONE wave-private LDS buffer (a stage reads all its
+// inputs into registers before it writes), index padded by one element per 16
+// (conflict-free ds_read_b64 / ds_write_b64).  A wave's LDS operations complete
+// in program order, so the stages of a transform need no workgroup barrier and
+// the eight waves of a workgroup run their transforms independently.
 // The first stage reads straight from its source (global u, the LDS copy of a
 // gm tile, or the spectrum product) and the last stage writes straight to its
 // sink (the [T][k] output tile, or the spectrum accumulator), so a transform
 // makes two LDS round trips.  Output tiles are transposed through LDS so that
 // m is written, and gm read, in 128-byte row segments.
+//
+// Kernels: k_fft_u (spectrum of every u[b], B small transforms) -> k_conv_fwd_fft;
+// k_conv_bwd_fft (partial spectra per 32-channel group) -> k_fft_gu (sum of the
+// groups, one inverse transform per batch item, ReLU mask of the encoder).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <algorithm>
 
 #include "lmufft.h"
 #include "lmufft_internal.h"
 
 namespace lmufft {
 
-constexpr int kFftThreads = 256;   // 4 waves, one transform each at a time
+constexpr int kFftWaves = 8;                     // one transform per wave at a time
+constexpr int kFftThreads = 64 * kFftWaves;
 constexpr int kFftPairs = 16;      // channel pairs per workgroup (32 memory channels, 128-byte rows)
 constexpr int kFftCols = 2 * kFftPairs;
 constexpr int kTileLd = kFftCols + 1;  // LDS row stride of the [T][32] tile in floats
@@ -126,57 +136,64 @@ __device__ __forceinline__ void dftR(float2 (&v)[R]) {
 
 __device__ __forceinline__ int fpad(int i) { return i + (i >> 4); }
 
+// Orders this wave's LDS traffic: everything issued so far has completed, and the compiler
+// moves no memory access across this point.
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // One Stockham stage of an N-point transform done by ONE wave.
-//   src(i)      -> element i of the stage input   (i in [0, N))
+//   src(i, slot) -> element i of the stage input  (i in [0, N)); slot = q*R + r counts the lane's
+//                  inputs in a fixed order (a compile-time constant after unrolling)
 //   dst(i, v, slot) -> element i of the stage output; slot = q*R + r counts the lane's outputs
 //                  in a fixed order (the same for every transform of that stage)
 //   tw[k] = exp(-2 pi i k / N), k in [0, N)
 // Butterfly j (of N/R) reads i = j + r*N/R, multiplies by W^(r * (j % NS) * N/(NS*R)),
 // takes the R-point DFT and writes i = (j / NS)*NS*R + (j % NS) + r*NS.
+// All inputs are read before the first output is written (src and dst may be one buffer).
 template <int N, int R, int NS, bool INV, class Src, class Dst>
 __device__ __forceinline__ void fft_stage(const float2* __restrict__ tw, Src&& src, Dst&& dst) {
   constexpr int NB = N / R;
+  constexpr int NQ = (NB + 63) / 64;
   const int lane = threadIdx.x & 63;
+  float2 v[NQ][R];
 #pragma unroll
-  for (int q = 0; q < (NB + 63) / 64; ++q) {
+  for (int q = 0; q < NQ; ++q) {
     const int j = lane + 64 * q;
     if (NB % 64 != 0 && j >= NB) break;
-    float2 v[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) v[r] = src(j + r * NB);
+    for (int r = 0; r < R; ++r) v[q][r] = src(j + r * NB, q * R + r);
+  }
+  wave_lds_fence();
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int j = lane + 64 * q;
+    if (NB % 64 != 0 && j >= NB) break;
     const int kk = j & (NS - 1);
     if (NS > 1) {
       const int tstep = kk * (N / (NS * R));
 #pragma unroll
-      for (int r = 1; r < R; ++r) v[r] = twiddle<INV>(v[r], tw[(r * tstep) & (N - 1)]);
+      for (int r = 1; r < R; ++r) v[q][r] = twiddle<INV>(v[q][r], tw[(r * tstep) & (N - 1)]);
     }
-    dftR<R, INV>(v);
+    dftR<R, INV>(v[q]);
     const int j0 = (j / NS) * (NS * R) + kk;
 #pragma unroll
-    for (int r = 0; r < R; ++r) dst(j0 + r * NS, v[r], q * R + r);
+    for (int r = 0; r < R; ++r) dst(j0 + r * NS, v[q][r], q * R + r);
   }
+  wave_lds_fence();
 }
 
-// Whole transform: radix 16, 16, then N/256 (absent for N = 256).  bufA / bufB are
-// wave-private LDS buffers of fpad(N) float2.  The caller places a workgroup
-// barrier before reading what the last stage wrote; barriers between the stages
-// are inside (every wave of the workgroup must call this the same number of
-// times; `active` = false makes the wave only keep the barriers company).
+// Whole transform by one wave: radix 16, 16, then N/256 (absent for N = 256).  buf is a
+// wave-private LDS buffer of fpad(N) float2.  No workgroup barrier inside.
 template <int N, bool INV, class Src, class Dst>
-__device__ __forceinline__ void wave_fft(bool active, const float2* __restrict__ tw, float2* bufA, float2* bufB,
-                                         Src&& src, Dst&& dst) {
+__device__ __forceinline__ void wave_fft(const float2* __restrict__ tw, float2* buf, Src&& src, Dst&& dst) {
   constexpr int R3 = N / 256;
   static_assert(R3 == 1 || R3 == 2 || R3 == 4, "N in {256, 512, 1024}");
-  if (active) fft_stage<N, 16, 1, INV>(tw, src, [&](int i, float2 v, int) { bufA[fpad(i)] = v; });
-  __syncthreads();
+  fft_stage<N, 16, 1, INV>(tw, src, [&](int i, float2 v, int) { buf[fpad(i)] = v; });
   if constexpr (R3 == 1) {
-    if (active) fft_stage<N, 16, 16, INV>(tw, [&](int i) { return bufA[fpad(i)]; }, dst);
+    fft_stage<N, 16, 16, INV>(tw, [&](int i, int) { return buf[fpad(i)]; }, dst);
   } else {
-    if (active)
-      fft_stage<N, 16, 16, INV>(tw, [&](int i) { return bufA[fpad(i)]; },
-                                [&](int i, float2 v, int) { bufB[fpad(i)] = v; });
-    __syncthreads();
-    if (active) fft_stage<N, R3, 256, INV>(tw, [&](int i) { return bufB[fpad(i)]; }, dst);
+    fft_stage<N, 16, 16, INV>(tw, [&](int i, int) { return buf[fpad(i)]; },
+                              [&](int i, float2 v, int) { buf[fpad(i)] = v; });
+    fft_stage<N, R3, 256, INV>(tw, [&](int i, int) { return buf[fpad(i)]; }, dst);
   }
 }
 
@@ -188,41 +205,47 @@ __device__ __forceinline__ void fill_twiddles(float2* tw) {
     tw[k] = make_float2(cs, -sn);
   }
 }
+// the same table, copied from the prepared buffer (cheaper than N sincos per workgroup)
+template <int N>
+__device__ __forceinline__ void load_twiddles(float2* tw, const float2* __restrict__ table) {
+  for (int k = threadIdx.x; k < N; k += blockDim.x) tw[k] = table[k];
+}
 
-// LDS carve (floats): tw[2N] | U[2*fpad(N)] | per wave A,B [4 * 2*fpad(N)] each | tile [T * kTileLd]
+// LDS carve (floats): tw[2N] | per wave one buffer [waves * 2*fpad(N)] | tile [T * kTileLd]
 template <int N>
 struct FftLds {
   static constexpr int PADN = N + N / 16;
   static constexpr int TW = 0;
-  static constexpr int U = TW + 2 * N;
-  static constexpr int WORK = U + 2 * PADN;
-  static constexpr int TILE = WORK + 4 * 2 * 2 * PADN;
+  static constexpr int WORK = TW + 2 * N;
+  static constexpr int TILE = WORK + kFftWaves * 2 * PADN;
   static size_t bytes(int T) { return sizeof(float) * ((size_t)TILE + (size_t)T * kTileLd); }
+  static size_t bytes_single() { return sizeof(float) * (size_t)(2 * N + 4 * PADN); }  // one-wave kernels
 };
 
 // ---------------------------------------------------------------------------
 // spectra of the filters, once per (H, T):
 //   G [p][f] = fft(H_2p + i H_2p+1)[f] / N                  (forward conv)
 //   Gr[p][f] = fft(rev(H_2p) - i rev(H_2p+1))[f] / N        (adjoint), rev(h)[j] = h[T-1-j]
-// one workgroup (one active wave) per pair and kind
+// one workgroup (one wave) per pair and kind
 // ---------------------------------------------------------------------------
 template <int N>
 __global__ __launch_bounds__(64) void k_fft_prep(const float* __restrict__ H, float2* __restrict__ G, int M, int T,
                                                  int ldH, int npairs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float2* tw = reinterpret_cast<float2*>(lds);
-  float2* bufA = tw + N;
-  float2* bufB = bufA + FftLds<N>::PADN;
+  float2* buf = tw + N;
   const int p = blockIdx.x, adj = blockIdx.y;
   fill_twiddles<N>(tw);
   __syncthreads();
+  if (p == 0 && adj == 0)  // the twiddle table follows the spectra
+    for (int k = threadIdx.x; k < N; k += 64) G[(long)2 * npairs * N + k] = tw[k];
   const float* h0 = H + (long)(2 * p) * ldH;
   const float* h1 = (2 * p + 1 < M) ? H + (long)(2 * p + 1) * ldH : nullptr;
   float2* out = G + ((long)adj * npairs + p) * N;
   const float scale = 1.0f / (float)N;
   wave_fft<N, false>(
-      true, tw, bufA, bufB,
-      [&](int i) {
+      tw, buf,
+      [&](int i, int) {
         if (i >= T) return make_float2(0.f, 0.f);
         const int j = adj ? T - 1 - i : i;
         const float a = h0[j], b = h1 ? h1[j] : 0.f;
@@ -231,47 +254,61 @@ __global__ __launch_bounds__(64) void k_fft_prep(const float* __restrict__ H, fl
       [&](int i, float2 v, int) { out[i] = make_float2(v.x * scale, v.y * scale); });
 }
 
+// spectrum of u[b] (zero-padded to N), one wave per batch item: U[b][f]
+template <int N>
+__global__ __launch_bounds__(64) void k_fft_u(const float* __restrict__ u, const float2* __restrict__ table,
+                                              float2* __restrict__ U, int T) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float2* tw = reinterpret_cast<float2*>(lds);
+  float2* buf = tw + N;
+  const int b = blockIdx.x;
+  load_twiddles<N>(tw, table);
+  __syncthreads();
+  const float* ub = u + (long)b * T;
+  float2* Ub = U + (long)b * N;
+  wave_fft<N, false>(
+      tw, buf,
+      [&](int i, int) {  // clamped address + select: the sixteen loads of a lane stay in flight together
+        const float v = ub[min(i, T - 1)];
+        return make_float2(i < T ? v : 0.f, 0.f);
+      },
+      [&](int i, float2 v, int) { Ub[i] = v; });
+}
+
 // ---------------------------------------------------------------------------
 // forward: m[b][t][k0 .. k0+31] for one batch item and 16 channel pairs
 // ---------------------------------------------------------------------------
 template <int N>
-__global__ __launch_bounds__(kFftThreads) void k_conv_fwd_fft(const float* __restrict__ u,
+__global__ __launch_bounds__(kFftThreads) void k_conv_fwd_fft(const float2* __restrict__ U,
                                                               const float2* __restrict__ G,
+                                                              const float2* __restrict__ table,
                                                               float* __restrict__ m, int T, int M, int npairs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using L = FftLds<N>;
   float2* tw = reinterpret_cast<float2*>(lds + L::TW);
-  float2* U = reinterpret_cast<float2*>(lds + L::U);
   const int wave = threadIdx.x >> 6;
-  float2* bufA = reinterpret_cast<float2*>(lds + L::WORK) + (size_t)wave * 2 * L::PADN;
-  float2* bufB = bufA + L::PADN;
+  float2* buf = reinterpret_cast<float2*>(lds + L::WORK) + (size_t)wave * L::PADN;
   float* tile = lds + L::TILE;
   const int b = blockIdx.y, p0 = blockIdx.x * kFftPairs;
-  const float* ub = u + (long)b * T;
+  const float2* Ub = U + (long)b * N;
 
-  fill_twiddles<N>(tw);
+  load_twiddles<N>(tw, table);
   __syncthreads();
-  // spectrum of u (wave 0)
-  wave_fft<N, false>(
-      wave == 0, tw, bufA, bufB, [&](int i) { return make_float2(i < T ? ub[i] : 0.f, 0.f); },
-      [&](int i, float2 v, int) { U[fpad(i)] = v; });
-  __syncthreads();
-  // four pairs per wave: ifft(U * G_p) -> columns 2*pl, 2*pl+1 of the tile
-  for (int q = 0; q < kFftPairs / 4; ++q) {
-    const int pl = q * 4 + wave;
+  // ifft(U * G_p) -> columns 2*pl, 2*pl+1 of the tile; the waves take the pairs in turn
+  for (int pl = wave; pl < kFftPairs; pl += kFftWaves) {
     const int p = p0 + pl;
-    const bool active = p < npairs;
-    const float2* Gp = G + (long)(active ? p : 0) * N;
+    if (p >= npairs) break;
+    const float2* Gp = G + (long)p * N;
     wave_fft<N, true>(
-        active, tw, bufA, bufB, [&](int i) { return cmul(U[fpad(i)], Gp[i]); },
+        tw, buf, [&](int i, int) { return cmul(Ub[i], Gp[i]); },
         [&](int i, float2 v, int) {
           if (i < T) {
             tile[i * kTileLd + 2 * pl] = v.x;
             tile[i * kTileLd + 2 * pl + 1] = v.y;
           }
         });
-    __syncthreads();  // bufA / bufB are reused by the next pair
   }
+  __syncthreads();
   // tile -> m[b][t][k0 + c], 128-byte row segments
   const int k0 = 2 * p0;
   float* mb = m + (long)b * T * M;
@@ -282,26 +319,25 @@ __global__ __launch_bounds__(kFftThreads) void k_conv_fwd_fft(const float* __res
 }
 
 // ---------------------------------------------------------------------------
-// adjoint: partial gu[b][s] from the 32 channels k0 .. k0+31 of one batch item
-// slab layout part[(kgroup * B + b) * T + s]
+// adjoint, first kernel: spectrum of the contribution of the 32 channels k0 .. k0+31 of one
+// batch item, Sp[(kgroup * B + b)][f] = sum_pairs fft(gm_2p + i gm_2p+1)[f] * Gr_p[f]
 // ---------------------------------------------------------------------------
 template <int N>
 __global__ __launch_bounds__(kFftThreads) void k_conv_bwd_fft(const float* __restrict__ gm,
                                                               const float2* __restrict__ Gr,
-                                                              float* __restrict__ part, int B, int T, int M,
+                                                              const float2* __restrict__ table,
+                                                              float2* __restrict__ Sp, int B, int T, int M,
                                                               int npairs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using L = FftLds<N>;
   float2* tw = reinterpret_cast<float2*>(lds + L::TW);
-  float2* S = reinterpret_cast<float2*>(lds + L::U);  // summed spectrum
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float2* bufA = reinterpret_cast<float2*>(lds + L::WORK) + (size_t)wave * 2 * L::PADN;
-  float2* bufB = bufA + L::PADN;
+  float2* buf = reinterpret_cast<float2*>(lds + L::WORK) + (size_t)wave * L::PADN;
   float* tile = lds + L::TILE;
   const int b = blockIdx.y, p0 = blockIdx.x * kFftPairs, k0 = 2 * p0;
   const float* gmb = gm + (long)b * T * M;
 
-  fill_twiddles<N>(tw);
+  load_twiddles<N>(tw, table);
   for (int idx = threadIdx.x; idx < T * kFftCols; idx += kFftThreads) {
     const int t = idx / kFftCols, c = idx % kFftCols;
     tile[t * kTileLd + c] = (k0 + c < M) ? gmb[(long)t * M + k0 + c] : 0.f;
@@ -310,59 +346,86 @@ __global__ __launch_bounds__(kFftThreads) void k_conv_bwd_fft(const float* __res
 
   // every lane accumulates the spectrum elements that the last stage hands it:
   // the (index -> lane, slot) map of a stage is the same for every transform
-  constexpr int R3_ = N / 256;
-  constexpr int RL_ = R3_ == 1 ? 16 : R3_;                  // radix of the last stage
-  constexpr int PER = ((N / RL_ + 63) / 64) * RL_;          // outputs of the last stage per lane
+  constexpr int R3 = N / 256;
+  constexpr int RL = R3 == 1 ? 16 : R3;                   // radix of the last stage
+  constexpr int NSL = R3 == 1 ? 16 : 256;
+  constexpr int NBL = N / RL;
+  constexpr int PER = ((NBL + 63) / 64) * RL;             // outputs of the last stage per lane
   float2 acc[PER];
 #pragma unroll
   for (int i = 0; i < PER; ++i) acc[i] = make_float2(0.f, 0.f);
 
-  for (int q = 0; q < kFftPairs / 4; ++q) {
-    const int pl = q * 4 + wave;
+  for (int pl = wave; pl < kFftPairs; pl += kFftWaves) {
     const int p = p0 + pl;
-    const bool active = p < npairs;
-    const float2* Gp = Gr + (long)(active ? p : 0) * N;
+    if (p >= npairs) break;
+    const float2* Gp = Gr + (long)p * N;
     wave_fft<N, false>(
-        active, tw, bufA, bufB,
-        [&](int i) {
-          return i < T ? make_float2(tile[i * kTileLd + 2 * pl], tile[i * kTileLd + 2 * pl + 1])
-                       : make_float2(0.f, 0.f);
+        tw, buf,
+        [&](int i, int) {  // clamped address + select keeps the reads of a lane in flight together
+          const float* t2 = tile + min(i, T - 1) * kTileLd + 2 * pl;
+          const float re = t2[0], im = t2[1];
+          return make_float2(i < T ? re : 0.f, i < T ? im : 0.f);
         },
         [&](int i, float2 v, int slot) { acc[slot] = acc[slot] + cmul(v, Gp[i]); });
-    __syncthreads();
   }
-  // the four waves' spectra, in the index order of the last stage, are summed into S
-  {
-    // replay the last stage's index sequence to know which element each slot holds
-    constexpr int R3 = N / 256;
-    constexpr int RL = R3 == 1 ? 16 : R3;
-    constexpr int NSL = R3 == 1 ? 16 : 256;
-    constexpr int NB = N / RL;
-    float2* mine = bufA;  // wave-private
+  // replay the last stage's index sequence: slot -> spectrum index; park the wave's sum in its buffer
 #pragma unroll
-    for (int q = 0; q < (NB + 63) / 64; ++q) {
-      const int j = lane + 64 * q;
-      if (NB % 64 != 0 && j >= NB) break;
-      const int kk = j & (NSL - 1);
-      const int j0 = (j / NSL) * (NSL * RL) + kk;
+  for (int q = 0; q < (NBL + 63) / 64; ++q) {
+    const int j = lane + 64 * q;
+    if (NBL % 64 != 0 && j >= NBL) break;
+    const int kk = j & (NSL - 1);
+    const int j0 = (j / NSL) * (NSL * RL) + kk;
 #pragma unroll
-      for (int r = 0; r < RL; ++r) mine[fpad(j0 + r * NSL)] = acc[q * RL + r];
-    }
+    for (int r = 0; r < RL; ++r) buf[fpad(j0 + r * NSL)] = acc[q * RL + r];
   }
   __syncthreads();
-  {
-    float2* w0 = reinterpret_cast<float2*>(lds + L::WORK);
-    for (int i = threadIdx.x; i < N; i += kFftThreads) {
-      const int pi = fpad(i);
-      S[pi] = ((w0[pi] + w0[2 * L::PADN + pi]) + w0[4 * L::PADN + pi]) + w0[6 * L::PADN + pi];
-    }
+  // the waves' spectra summed in a fixed order -> Sp, coalesced
+  const float2* w0 = reinterpret_cast<const float2*>(lds + L::WORK);
+  float2* out = Sp + ((long)blockIdx.x * B + b) * N;
+  for (int i = threadIdx.x; i < N; i += kFftThreads) {
+    const int pi = fpad(i);
+    float2 s = w0[pi];
+#pragma unroll
+    for (int wv = 1; wv < kFftWaves; ++wv) s = s + w0[(size_t)wv * L::PADN + pi];
+    out[i] = s;
   }
+}
+
+// adjoint, second kernel: gu[b][s] = Re ifft(sum_groups Sp[g][b])[T-1+s], times (u[b][s] > 0) when
+// u is given (the encoder's ReLU); one wave per batch item
+template <int N>
+__global__ __launch_bounds__(64) void k_fft_gu(const float2* __restrict__ Sp, const float2* __restrict__ table,
+                                               const float* __restrict__ u, float* __restrict__ gu, int B, int T,
+                                               int groups) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float2* tw = reinterpret_cast<float2*>(lds);
+  float2* buf = tw + N;
+  float2* sum = buf + FftLds<N>::PADN;
+  const int b = blockIdx.x, lane = threadIdx.x;
+  load_twiddles<N>(tw, table);
+  // the groups' spectra summed in group order, coalesced, all loads of a group in flight together
+  float2 s[N / 64];
+#pragma unroll
+  for (int q = 0; q < N / 64; ++q) s[q] = Sp[(long)b * N + lane + 64 * q];
+  for (int g = 1; g < groups; ++g) {
+    float2 t[N / 64];
+#pragma unroll
+    for (int q = 0; q < N / 64; ++q) t[q] = Sp[((long)g * B + b) * N + lane + 64 * q];
+#pragma unroll
+    for (int q = 0; q < N / 64; ++q) s[q] = s[q] + t[q];
+  }
+#pragma unroll
+  for (int q = 0; q < N / 64; ++q) sum[fpad(lane + 64 * q)] = s[q];
   __syncthreads();
-  float* out = part + ((long)blockIdx.x * B + b) * T;
+  const float* ub = u ? u + (long)b * T : nullptr;
+  float* out = gu + (long)b * T;
   wave_fft<N, true>(
-      wave == 0, tw, bufA, bufB, [&](int i) { return S[fpad(i)]; },
+      tw, buf, [&](int i, int) { return sum[fpad(i)]; },
       [&](int i, float2 v, int) {
-        if (i >= T - 1 && i < 2 * T - 1) out[i - (T - 1)] = v.x;
+        if (i >= T - 1 && i < 2 * T - 1) {
+          const int sidx = i - (T - 1);
+          out[sidx] = (ub && !(ub[sidx] > 0.f)) ? 0.f : v.x;
+        }
       });
 }
 
@@ -380,7 +443,7 @@ int fft_length(int T) {
 size_t fftprep_bytes(int M, int T) {
   const int N = fft_length(T);
   if (!N) return 0;
-  return sizeof(float2) * 2 * (size_t)((M + 1) / 2) * N;
+  return sizeof(float2) * (2 * (size_t)((M + 1) / 2) + 1) * N;  // G | Gr | twiddle table
 }
 
 #define FFT_DISPATCH(N_, CALL)  \
@@ -411,7 +474,7 @@ int fft_prepare(const lmufft_shape& s, const float* H, void* prep, hipStream_t s
   const int npairs = (s.M + 1) / 2;
   const dim3 grid(npairs, 2);
   FFT_DISPATCH(N, {
-    const size_t lds = sizeof(float2) * (size_t)(NN + 2 * FftLds<NN>::PADN);
+    const size_t lds = FftLds<NN>::bytes_single();
     if (int rc = reserve_lds(k_fft_prep<NN>, lds, "k_fft_prep")) return rc;
     ProfScope ps("k_fft_prep", st);
     hipLaunchKernelGGL(k_fft_prep<NN>, grid, dim3(64), lds, st, H, (float2*)prep, s.M, s.T, s.ldH, npairs);
@@ -420,36 +483,61 @@ int fft_prepare(const lmufft_shape& s, const float* H, void* prep, hipStream_t s
   return 0;
 }
 
-int fft_conv_forward(const lmufft_shape& s, const float* u, const void* prep, float* m, hipStream_t st) {
+int fft_conv_groups(int M) { return cdivf((M + 1) / 2, kFftPairs); }
+
+// scratch of the FFT route: spectra of u (forward) or per-group partial spectra (adjoint)
+size_t fft_conv_workspace_bytes(const lmufft_shape& s) {
+  const int N = fft_length(s.T);
+  if (!N) return 0;
+  return sizeof(float2) * (size_t)std::max(1, fft_conv_groups(s.M)) * s.B * N;
+}
+
+int fft_conv_forward(const lmufft_shape& s, const float* u, const void* prep, float* m, void* ws, hipStream_t st) {
   const int N = fft_length(s.T);
   if (!N) return set_error("the LDS-resident FFT convolution supports T <= 512 (got %d)", s.T);
   const int npairs = (s.M + 1) / 2;
-  const dim3 grid(cdivf(npairs, kFftPairs), s.B);
+  float2* U = (float2*)ws;
+  const float2* table = (const float2*)prep + (size_t)2 * npairs * N;
   FFT_DISPATCH(N, {
+    const size_t lds1 = FftLds<NN>::bytes_single();
+    if (int rc = reserve_lds(k_fft_u<NN>, lds1, "k_fft_u")) return rc;
+    {
+      ProfScope ps("k_fft_u", st);
+      hipLaunchKernelGGL(k_fft_u<NN>, dim3(s.B), dim3(64), lds1, st, u, table, U, s.T);
+    }
     const size_t lds = FftLds<NN>::bytes(s.T);
     if (int rc = reserve_lds(k_conv_fwd_fft<NN>, lds, "k_conv_fwd_fft")) return rc;
     ProfScope ps("k_conv_fwd_fft", st);
-    hipLaunchKernelGGL(k_conv_fwd_fft<NN>, grid, dim3(kFftThreads), lds, st, u, (const float2*)prep, m, s.T, s.M,
-                       npairs);
+    hipLaunchKernelGGL(k_conv_fwd_fft<NN>, dim3(cdivf(npairs, kFftPairs), s.B), dim3(kFftThreads), lds, st,
+                       (const float2*)U, (const float2*)prep, table, m, s.T, s.M, npairs);
   });
   FFT_LAUNCH_CHECK("k_conv_fwd_fft");
   return 0;
 }
 
-int fft_conv_groups(int M) { return cdivf((M + 1) / 2, kFftPairs); }
-
-// part: [groups][B][T] floats
-int fft_conv_backward(const lmufft_shape& s, const float* gm, const void* prep, float* part, hipStream_t st) {
+// gu[b][s] (masked by u > 0 when u != NULL); ws as sized by fft_conv_workspace_bytes
+int fft_conv_backward(const lmufft_shape& s, const float* gm, const void* prep, const float* u, float* gu, void* ws,
+                      hipStream_t st) {
   const int N = fft_length(s.T);
   if (!N) return set_error("the LDS-resident FFT convolution supports T <= 512 (got %d)", s.T);
   const int npairs = (s.M + 1) / 2;
-  const dim3 grid(cdivf(npairs, kFftPairs), s.B);
+  const int groups = fft_conv_groups(s.M);
   const float2* Gr = (const float2*)prep + (size_t)npairs * N;
+  float2* Sp = (float2*)ws;
+  const float2* table = (const float2*)prep + (size_t)2 * npairs * N;
   FFT_DISPATCH(N, {
     const size_t lds = FftLds<NN>::bytes(s.T);
     if (int rc = reserve_lds(k_conv_bwd_fft<NN>, lds, "k_conv_bwd_fft")) return rc;
-    ProfScope ps("k_conv_bwd_fft", st);
-    hipLaunchKernelGGL(k_conv_bwd_fft<NN>, grid, dim3(kFftThreads), lds, st, gm, Gr, part, s.B, s.T, s.M, npairs);
+    {
+      ProfScope ps("k_conv_bwd_fft", st);
+      hipLaunchKernelGGL(k_conv_bwd_fft<NN>, dim3(groups, s.B), dim3(kFftThreads), lds, st, gm, Gr, table, Sp, s.B,
+                         s.T, s.M, npairs);
+    }
+    const size_t lds1 = FftLds<NN>::bytes_single();
+    if (int rc = reserve_lds(k_fft_gu<NN>, lds1, "k_fft_gu")) return rc;
+    ProfScope ps("k_fft_gu", st);
+    hipLaunchKernelGGL(k_fft_gu<NN>, dim3(s.B), dim3(64), lds1, st, (const float2*)Sp, table, u, gu, s.B, s.T,
+                       groups);
   });
   FFT_LAUNCH_CHECK("k_conv_bwd_fft");
   return 0;

@@ -622,7 +622,7 @@ static BwdPlan plan_backward(const lmufft_shape& s) {
   p.off_wslab = off;
   off += align256(sizeof(float) * (size_t)p.S * (slab_seg_pad((long)s.Hd * MD) + slab_seg_pad(s.Hd)));
   p.off_gupart = off;
-  off += align256(sizeof(float) * (size_t)s.B * std::max(p.ntt, fft_conv_groups(s.M)) * s.T);
+  off += align256(std::max(sizeof(float) * (size_t)s.B * p.ntt * s.T, fft_conv_workspace_bytes(s)));
   p.off_ga = off;
   off += align256(sizeof(float) * (size_t)rows);
   p.off_encpart = off;
@@ -773,7 +773,9 @@ const char* lmufft_last_error(void) { return last_error_buffer(); }
 
 size_t lmufft_forward_workspace_bytes(const lmufft_shape* s, int dtype) {
   if (dtype == LMUFFT_BF16) return check_shape(s) ? 0 : forward_workspace_bf16(*s);
-  return 256;  // the fp32 forward needs no scratch; never return 0 so callers can always allocate
+  if (!s || s->B <= 0 || s->T <= 0 || s->M <= 0) return 0;
+  // the FFT route keeps the spectra of u here; never return 0 so callers can always allocate
+  return std::max((size_t)256, align256(fft_conv_workspace_bytes(*s)));
 }
 
 size_t lmufft_backward_workspace_bytes(const lmufft_shape* s, int dtype) {
@@ -787,7 +789,7 @@ size_t lmufft_conv_workspace_bytes(const lmufft_shape* s, int dtype, int conv_al
   (void)conv_algo;
   if (!s || s->B <= 0 || s->T <= 0) return 0;
   const int ntt = cdiv(s->T, ConvBwdTile::BM);
-  return align256(sizeof(float) * (size_t)s->B * std::max(ntt, fft_conv_groups(s->M)) * s->T);
+  return align256(std::max(sizeof(float) * (size_t)s->B * ntt * s->T, fft_conv_workspace_bytes(*s)));
 }
 
 size_t lmufft_fftprep_bytes(const lmufft_shape* s) {
@@ -803,13 +805,16 @@ int lmufft_fftprep_f32(const lmufft_shape* s, const float* H, void* fftprep, voi
 
 int lmufft_conv_forward_f32(const lmufft_shape* s, const float* u, const float* H, const void* fftprep, float* m,
                             int conv_algo, void* workspace, size_t workspace_bytes, void* stream) {
-  (void)workspace;
-  (void)workspace_bytes;
   if (!s || s->B <= 0 || s->T <= 0 || s->M <= 0) return set_error("conv: bad shape");
   if (s->T > s->ldH) return set_error("sequence length %d exceeds the impulse response length %d", s->T, s->ldH);
   if (!u || !H || !m) return set_error("conv: NULL pointer");
   if (int rc = check_algo(*s, conv_algo, fftprep)) return rc;
-  if (use_fft(*s, conv_algo, fftprep)) return fft_conv_forward(*s, u, fftprep, m, (hipStream_t)stream);
+  if (use_fft(*s, conv_algo, fftprep)) {
+    const size_t need = fft_conv_workspace_bytes(*s);
+    if (!workspace || workspace_bytes < need)
+      return set_error("conv forward (FFT): workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+    return fft_conv_forward(*s, u, fftprep, m, workspace, (hipStream_t)stream);
+  }
   return conv_forward_toeplitz(*s, u, H, m, (hipStream_t)stream);
 }
 
@@ -824,8 +829,7 @@ int lmufft_conv_backward_f32(const lmufft_shape* s, const float* gm, const float
     return set_error("conv backward: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
   hipStream_t st = (hipStream_t)stream;
   if (use_fft(*s, conv_algo, fftprep)) {
-    if (int rc = fft_conv_backward(*s, gm, fftprep, (float*)workspace, st)) return rc;
-    return launch_sum_slabs_masked((const float*)workspace, nullptr, gu, (long)s->B * s->T, fft_conv_groups(s->M), st);
+    return fft_conv_backward(*s, gm, fftprep, nullptr, gu, workspace, st);
   }
   return conv_backward_toeplitz(*s, gm, H, nullptr, (float*)workspace, gu, st);
 }
@@ -856,7 +860,10 @@ int lmufft_forward_f32(const lmufft_shape* s, const float* x, const float* w_u, 
     LAUNCH_CHECK("k_encode_fwd");
   }
   if (use_fft(*s, conv_algo, fftprep)) {  // eq. 26
-    if (int rc = fft_conv_forward(*s, u, fftprep, m, st)) return rc;
+    const size_t need = fft_conv_workspace_bytes(*s);
+    if (!workspace || workspace_bytes < need)
+      return set_error("forward (FFT): workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+    if (int rc = fft_conv_forward(*s, u, fftprep, m, workspace, st)) return rc;
   } else {
     if (int rc = conv_forward_toeplitz(*s, u, H, m, st)) return rc;
   }
@@ -924,8 +931,7 @@ int lmufft_backward_f32(const lmufft_shape* s, const float* x, const float* w_u,
   if (int rc = dgrad("k_dgrad_m", gm, 0, s->M, nullptr, nullptr)) return rc;
   // ga = (adjoint conv of gm) * (u > 0)
   if (use_fft(*s, conv_algo, fftprep)) {
-    if (int rc = fft_conv_backward(*s, gm, fftprep, gupart, st)) return rc;
-    if (int rc = launch_sum_slabs_masked(gupart, u, ga, rows, fft_conv_groups(s->M), st)) return rc;
+    if (int rc = fft_conv_backward(*s, gm, fftprep, u, ga, gupart, st)) return rc;
   } else {
     if (int rc = conv_backward_toeplitz(*s, gm, H, u, gupart, ga, st)) return rc;
   }

@@ -50,9 +50,12 @@ size_t backward_workspace_bf16(const lmufft_shape& s);
 int fft_length(int T);                      // 0 when the LDS-resident kernels cannot take T
 size_t fftprep_bytes(int M, int T);
 int fft_prepare(const lmufft_shape& s, const float* H, void* prep, hipStream_t st);
-int fft_conv_forward(const lmufft_shape& s, const float* u, const void* prep, float* m, hipStream_t st);
+size_t fft_conv_workspace_bytes(const lmufft_shape& s);  // scratch of either direction
+int fft_conv_forward(const lmufft_shape& s, const float* u, const void* prep, float* m, void* ws, hipStream_t st);
 int fft_conv_groups(int M);
-int fft_conv_backward(const lmufft_shape& s, const float* gm, const void* prep, float* part, hipStream_t st);
+// gu[b][s], times (u[b][s] > 0) when u != NULL
+int fft_conv_backward(const lmufft_shape& s, const float* gm, const void* prep, const float* u, float* gu, void* ws,
+                      hipStream_t st);
 // out[i] = sum_p part[p*n + i], masked by u[i] > 0 when u != NULL (defined in lmufft_f32.hip)
 int launch_sum_slabs_masked(const float* part, const float* u, float* out, long n, int P, hipStream_t st);
 

@@ -250,9 +250,11 @@ def causal_conv(u, H, conv_algo="auto", fftprep=None):
     m = torch.empty((B, T, M), dtype=torch.float32, device=u.device)
     shp = _shape(B, T, 1, M, 1, ldH)
     fftprep = _conv_fftprep(H, T, conv_algo, fftprep)
+    algo = _ALGOS[conv_algo]
     with torch.cuda.device(u.device):
-        rc = _lib.lib.lmufft_conv_forward_f32(ctypes.byref(shp), _ptr(u), _ptr(H), _ptr(fftprep), _ptr(m),
-                                              _ALGOS[conv_algo], None, 0, _stream(u.device))
+        ws = _workspace(_lib.lib.lmufft_conv_workspace_bytes(ctypes.byref(shp), _lib.F32, algo), u.device)
+        rc = _lib.lib.lmufft_conv_forward_f32(ctypes.byref(shp), _ptr(u), _ptr(H), _ptr(fftprep), _ptr(m), algo,
+                                              _ptr(ws), ws.numel(), _stream(u.device))
     _lib.check(rc, "lmufft_conv_forward_f32")
     return m
 

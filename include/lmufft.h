@@ -95,7 +95,9 @@ int lmufft_backward_f32(const lmufft_shape* s, const float* x, const float* w_u,
  * adjoint, exposed for kernel-level parity and roofline measurement.
  *   forward : u [B][T], H [M][ldH]  ->  m [B][T][M]
  *   backward: gm [B][T][M]          ->  gu [B][T]
- * Only B, T, M, ldH of the shape are read.
+ * Only B, T, M, ldH of the shape are read.  Both directions take a workspace
+ * of lmufft_conv_workspace_bytes (the FFT route keeps spectra there; the
+ * Toeplitz forward uses none).
  * ---------------------------------------------------------------------- */
 size_t lmufft_conv_workspace_bytes(const lmufft_shape* s, int dtype, int conv_algo);
 
