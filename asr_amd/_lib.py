@@ -10,7 +10,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblmufft_hip.so")
+# LMUFFT_LIBRARY selects another build of the library (kernel experiments)
+LIB_PATH = os.environ.get("LMUFFT_LIBRARY") or os.path.join(_HERE, "csrc", "liblmufft_hip.so")
 
 F32 = 0
 BF16 = 1

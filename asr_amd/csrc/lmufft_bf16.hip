@@ -663,7 +663,6 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
   const int RB = tiles_j * TL::WGN, RU = tiles_n * TL::WGM;
   const int slot_b = tile_j * TL::WGN + w.wn0 / TL::WN, slot_u = tile_n * TL::WGM + w.wm0 / TL::WM;
   int cnt_b = slot_b, cnt_u = slot_u;  // k-steps until this wave's next turn
-  float* gaS = reinterpret_cast<float*>(smem + OpA::ELEMS + OpB::ELEMS);
   f32x16 accb[TL::TM], accu[TL::TN][2];
 #pragma unroll
   for (int t = 0; t < TL::TM; ++t)
@@ -676,35 +675,54 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
   bf16x8 ones;
 #pragma unroll
   for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.f;
+  // Pipeline over k-tiles: tile i is multiplied out of LDS stage i & 1 while tile i + 1 waits in
+  // registers and is then written to the other stage, and the loads of tile i + 2 start: one
+  // barrier per k-tile, and a wave's LDS writes overlap the other waves' MFMAs.
+  constexpr int kStageElems = OpA::ELEMS + OpB::ELEMS + 2 * TL::BK;  // + the ga slice (BK floats)
+  auto stage_A = [&](int st) { return smem + st * kStageElems; };
+  auto stage_B = [&](int st) { return smem + st * kStageElems + OpA::ELEMS; };
+  auto stage_ga = [&](int st) { return reinterpret_cast<float*>(smem + st * kStageElems + OpA::ELEMS + OpB::ELEMS); };
   float ga_reg = 0.f, gbu = 0.f;
-  auto fetch_ga = [&](int k0) {
+  auto fetch = [&](int k0) {
+    oa.fetch(k0);
+    ob.fetch(k0);
     if (tid < TL::BK) ga_reg = (k0 + tid < kend) ? ga[k0 + tid] : 0.f;
   };
-  if (kbeg < kend) {
-    oa.fetch(kbeg);
-    ob.fetch(kbeg);
-    fetch_ga(kbeg);
-  }
-  for (int k0 = kbeg; k0 < kend; k0 += TL::BK) {
+  auto store = [&](int st) {
+    oa.S = stage_A(st);
+    ob.S = stage_B(st);
     oa.store();
     ob.store();
     if (tid < TL::BK) {
-      gaS[tid] = ga_reg;
+      stage_ga(st)[tid] = ga_reg;
       gbu += ga_reg;
     }
-    __syncthreads();
-    if (k0 + TL::BK < kend) {
-      oa.fetch(k0 + TL::BK);
-      ob.fetch(k0 + TL::BK);
-      fetch_ga(k0 + TL::BK);
-    }
+  };
+  auto read_frags = [&](bf16x8 (&af)[TL::TM], bf16x8 (&bfr)[TL::TN], int kl) {
 #pragma unroll
-    for (int kl = 0; kl < TL::BK; kl += 16) {
-      bf16x8 af[TL::TM], bfr[TL::TN];
+    for (int tm = 0; tm < TL::TM; ++tm) af[tm] = oa.frag32(w.wm0 + tm * 32, kl);
 #pragma unroll
-      for (int tm = 0; tm < TL::TM; ++tm) af[tm] = oa.frag32(w.wm0 + tm * 32, kl);
+    for (int tn = 0; tn < TL::TN; ++tn) bfr[tn] = ob.frag32(w.wn0 + tn * 32, kl);
+  };
+  if (kbeg < kend) {
+    fetch(kbeg);
+    store(0);
+    if (kbeg + TL::BK < kend) fetch(kbeg + TL::BK);
+  }
+  __syncthreads();
+  int st = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += TL::BK, st ^= 1) {
+    oa.S = stage_A(st);
+    ob.S = stage_B(st);
+    const float* gaS = stage_ga(st);
+    bf16x8 fa[2][TL::TM], fb[2][TL::TN];
+    read_frags(fa[0], fb[0], 0);
 #pragma unroll
-      for (int tn = 0; tn < TL::TN; ++tn) bfr[tn] = ob.frag32(w.wn0 + tn * 32, kl);
+    for (int ks = 0; ks < TL::BK / 16; ++ks) {
+      const int kl = ks * 16;
+      bf16x8(&af)[TL::TM] = fa[ks & 1];
+      bf16x8(&bfr)[TL::TN] = fb[ks & 1];
+      if (ks + 1 < TL::BK / 16) read_frags(fa[(ks + 1) & 1], fb[(ks + 1) & 1], kl + 16);
 #pragma unroll
       for (int tm = 0; tm < TL::TM; ++tm)
 #pragma unroll
@@ -724,9 +742,9 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
         bf16x8 ghi, glo;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float g = j < 4 ? g0[j] : g1[j - 4];
-          ghi[j] = (bf16_t)g;
-          glo[j] = (bf16_t)(g - (float)ghi[j]);
+          const float gv = j < 4 ? g0[j] : g1[j - 4];
+          ghi[j] = (bf16_t)gv;
+          glo[j] = (bf16_t)(gv - (float)ghi[j]);
         }
 #pragma unroll
         for (int tn = 0; tn < TL::TN; ++tn) {
@@ -736,13 +754,36 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
       }
       --cnt_u;
     }
+    if (k0 + TL::BK < kend) {
+      store(st ^ 1);
+      if (k0 + 2 * TL::BK < kend) fetch(k0 + 2 * TL::BK);
+    }
     __syncthreads();
   }
 
-  tileb_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
-    const int n = n0 + mm, j = j0 + nn;
-    if (n < Hd && j < MD) slab[(long)n * MD + j] = v;
-  });
+  // gW_h tile -> slab through LDS: 16-byte stores of whole row segments (the operand area is free
+  // after the loop's last barrier; the launch reserves BM * (BN + 4) floats)
+  {
+    constexpr int LDT = TL::BN + 4;
+    float* tile = reinterpret_cast<float*>(smem);
+    tileb_epilogue<TL>(acc, w, [&](int mm, int nn, float v) { tile[mm * LDT + nn] = v; });
+    __syncthreads();
+    const bool vec_out = (MD % 4 == 0);
+    for (int idx = tid; idx < TL::BM * (TL::BN / 4); idx += kThreads) {
+      const int mm = idx / (TL::BN / 4), c = (idx % (TL::BN / 4)) * 4;
+      const int n = n0 + mm, j = j0 + c;
+      if (n >= Hd) continue;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&tile[mm * LDT + c]);
+      float* dst = slab + (long)n * MD + j;
+      if (vec_out && j + 3 < MD) {
+        *reinterpret_cast<f32x4*>(dst) = v;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (j + q < MD) dst[q] = v[q];
+      }
+    }
+  }
   if (w.r == 0) {  // every column of accb holds the row sums; column 0 writes them
     float* dst = slab + off_gbh + (long)slot_b * ((Hd + 3) & ~3);
 #pragma unroll
@@ -1133,7 +1174,11 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
     using TL = WgradTileB;
     const bool vec = (s->Hd % 8 == 0) && (s->M % 8 == 0) && (s->D % 8 == 0) && al16(m) && al16(x);
     const dim3 grid(xcd_grid(p.S, cdivb(MD, TL::BN) * cdivb(s->Hd, TL::BM)));
-    const size_t lds = sizeof(bf16_t) * (size_t)TL::BK * ((TL::BM + 32) + (TL::BN + 32)) + sizeof(float) * TL::BK;
+    const size_t lds = std::max(2 * (sizeof(bf16_t) * (size_t)TL::BK * ((TL::BM + 32) + (TL::BN + 32)) + sizeof(float) * TL::BK),
+                                sizeof(float) * (size_t)TL::BM * (TL::BN + 4));
+    if (hipFuncSetAttribute(vec ? (const void*)k_wgrad_bf16<true> : (const void*)k_wgrad_bf16<false>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return set_error("cannot reserve %zu bytes of LDS for k_wgrad_bf16", lds);
     {
       PROFB("k_wgrad_bf16");
       if (vec)
