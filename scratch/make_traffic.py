@@ -27,6 +27,7 @@ def classify(name, seq):
              ("k_reduce_slabs_tall", "k_reduce_slabs_tall"), ("k_reduce_slabs", "k_reduce_slabs"),
              ("k_sum_slabs_masked", "k_sum_slabs_masked"), ("k_gu_reduce", "k_gu_reduce"),
              ("k_conv_fwd_fft", "k_conv_fwd_fft"), ("k_conv_bwd_fft", "k_conv_bwd_fft"),
+             ("k_fft_u", "k_fft_u"), ("k_fft_gu", "k_fft_gu"),
              ("k_conv_fwd", "k_conv_fwd"), ("k_conv_bwd", "k_conv_bwd"), ("k_proj_fwd", "k_proj_fwd"),
              ("k_wgrad", "k_wgrad"), ("k_encode_fwd", "k_encode_fwd"), ("k_encode_bwd", "k_encode_bwd"),
              ("k_mel_power", "k_mel_power"), ("k_mel_norm", "k_mel_norm")]
