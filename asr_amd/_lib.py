@@ -71,6 +71,11 @@ def _load():
     lib.lmufft_mel_forward_f32.restype = ci
     lib.lmufft_mel_forward_f32.argtypes = [vp, vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, vp,
                                            ctypes.c_int32, ci, vp, vp]
+    i32 = ctypes.c_int32
+    lib.lmufft_ctc_workspace_bytes.restype = sz
+    lib.lmufft_ctc_workspace_bytes.argtypes = [i32, i32]
+    lib.lmufft_ctc_greedy.restype = ci
+    lib.lmufft_ctc_greedy.argtypes = [vp, ci, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]
     lib.lmufft_fftprep_bytes.restype = sz
     lib.lmufft_fftprep_bytes.argtypes = [sp]
     lib.lmufft_fftprep_f32.restype = ci
@@ -121,6 +126,8 @@ EXPORTS = (
     "lmufft_melprep",
     "lmufft_mel_frames",
     "lmufft_mel_forward_f32",
+    "lmufft_ctc_workspace_bytes",
+    "lmufft_ctc_greedy",
     "lmufft_hprep_bytes",
     "lmufft_hprep_bf16",
     "lmufft_wprep_bytes",

@@ -56,7 +56,8 @@ struct GldsOperand {
   const bf16_t* p0[NI];
   const bf16_t* p1[NI];
   unsigned okmask;
-  int koff, split, kmax, wave_off;
+  int kof[NI];  // swizzled column offset (elements) of every staging instruction
+  int split, kmax, wave_off;
   const bf16_t* zero;
 
   template <class RowFn>
@@ -66,7 +67,6 @@ struct GldsOperand {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     wave_off = wave * (R / NW) * ROWB;
-    koff = 0;  // the swizzled column offset differs per instruction (bit 3 of r enters the swizzle)
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int r = wave * (R / NW) + RPI * i + lane / CPR;
@@ -76,14 +76,14 @@ struct GldsOperand {
       p0[i] = q0 + 8 * d;
       p1[i] = q1 + 8 * d;
       okmask |= (ok ? 1u : 0u) << i;
-      koff |= (8 * d) << (6 * i);  // 6 bits per instruction (values 0..56)
+      kof[i] = 8 * d;
     }
   }
 
   __device__ __forceinline__ void issue(int stage, int k0) const {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int k = k0 + ((koff >> (6 * i)) & 63);
+      const int k = k0 + kof[i];
       const bf16_t* p = (TWO_PIECES && k >= split) ? p1[i] : p0[i];
       p = (((okmask >> i) & 1u) && k < kmax) ? p + k0 : zero;
       unsigned char* dst = base + stage * STAGE_BYTES + wave_off + i * 1024;

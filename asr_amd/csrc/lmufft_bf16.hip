@@ -243,8 +243,8 @@ __global__ __launch_bounds__(kThreads) void k_proj_fwd_bf16(const bf16_t* __rest
 // Tile 128 rows x 384 columns on eight waves: with hidden_size <= 384 every row
 // of [m;x] -- the operand that comes from HBM -- passes through a CU's load path
 // exactly once, and W_h (L2-resident) once per 128 rows.
-using ProjGldsTile = TileB<128, 384, 32, 2, 4>;
-constexpr int kProjStages = 4;
+using ProjGldsTile = TileB<128, 384, 64, 2, 4>;
+constexpr int kProjStages = 2;
 
 __global__ __launch_bounds__(ProjGldsTile::THREADS) void k_proj_fwd_glds_bf16(
     const bf16_t* __restrict__ m, const bf16_t* __restrict__ x, const bf16_t* __restrict__ Wb,
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(ProjGldsTile::THREADS) void k_proj_fwd_glds_bf16(
   WavePos<TL> w;
   f32x16 acc[TL::TM][TL::TN];
   tileb_zero<TL>(acc);
-  gemm_loop_glds_deep<TL, kProjStages>(oa, ob, acc, 0, K, w);
+  gemm_loop_glds<TL>(oa, ob, acc, 0, K, w);
 
   float bcol[TL::TN];
   preload_cols<TL>(bcol, w, [&](int nn) { return n0 + nn < Hd ? bias[n0 + nn] : 0.f; });

@@ -1,0 +1,70 @@
+"""CTC head for inference on the GPU: projection to the vocabulary, log-softmax and greedy decode.
+
+Host-side mirror of the reference's CTCDecoder (src/models/asr_model.py:13-50: a module holding
+`ctc_projection = nn.Linear(input_size, vocab_size)`, forward -> log-probabilities) and of
+LMUASRModel.decode with beam_width=1 (src/models/asr_model.py:158-213), which there is a Python
+loop with one device-to-host `.item()` per frame.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import _lib
+
+_DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
+
+
+class CTCDecoder(nn.Module):
+    def __init__(self, input_size: int, vocab_size: int):
+        super().__init__()
+        self.input_size = input_size
+        self.vocab_size = vocab_size
+        self.ctc_projection = nn.Linear(input_size, vocab_size)
+
+    def _run(self, enc: torch.Tensor, lengths: Optional[torch.Tensor], want_log_probs: bool):
+        if not enc.is_cuda:
+            raise RuntimeError(f"CTCDecoder: encoder output lives on {enc.device}; the head runs only as HIP "
+                               "kernels on a GPU (there is no CPU fallback)")
+        if enc.dim() != 3 or enc.shape[-1] != self.input_size:
+            raise RuntimeError(f"CTCDecoder: expected [batch, frames, {self.input_size}], got {tuple(enc.shape)}")
+        if enc.dtype not in _DTYPES:
+            raise RuntimeError(f"CTCDecoder: dtype {enc.dtype}; supported: float32, bfloat16")
+        enc = enc.detach().contiguous()
+        B, T, Hd = enc.shape
+        dev = enc.device
+        V = self.vocab_size
+        W = self.ctc_projection.weight.detach().float().contiguous()
+        b = self.ctc_projection.bias.detach().float().contiguous()
+        if lengths is not None:
+            lengths = lengths.to(device=dev, dtype=torch.int32).contiguous()
+        lp = torch.empty((B, T, V), dtype=torch.float32, device=dev) if want_log_probs else None
+        tokens = torch.empty((B, T), dtype=torch.int32, device=dev)
+        counts = torch.empty((B,), dtype=torch.int32, device=dev)
+        ws = torch.empty(max(_lib.lib.lmufft_ctc_workspace_bytes(B, T), 256), dtype=torch.uint8, device=dev)
+        p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        with torch.cuda.device(dev):
+            rc = _lib.lib.lmufft_ctc_greedy(p(enc), _DTYPES[enc.dtype], p(W), p(b), p(lengths), B, T, Hd, V, V - 1,
+                                            p(lp), p(tokens), p(counts), p(ws), ws.numel(),
+                                            ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        _lib.check(rc, "lmufft_ctc_greedy")
+        return lp, tokens, counts
+
+    def forward(self, encoder_output: torch.Tensor) -> torch.Tensor:
+        """[batch, frames, input_size] -> log-probabilities [batch, frames, vocab_size] (no autograd)."""
+        return self._run(encoder_output, None, True)[0]
+
+    def greedy(self, encoder_output: torch.Tensor, input_lengths: Optional[torch.Tensor] = None
+               ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Device-side result: tokens [batch, frames] int32 (row b: counts[b] tokens, then -1), counts [batch]."""
+        _, tokens, counts = self._run(encoder_output, input_lengths, False)
+        return tokens, counts
+
+    def decode(self, encoder_output: torch.Tensor, input_lengths: Optional[torch.Tensor] = None) -> List[List[int]]:
+        """Greedy CTC decode to Python lists (one host transfer for the whole batch)."""
+        tokens, counts = self.greedy(encoder_output, input_lengths)
+        tokens, counts = tokens.cpu(), counts.cpu()
+        return [tokens[i, : int(counts[i])].tolist() for i in range(tokens.shape[0])]

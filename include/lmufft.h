@@ -181,6 +181,24 @@ int lmufft_mel_forward_f32(const float* wave, const int32_t* lengths, int32_t B,
                            int normalize, const void* melprep, void* stream);
 
 /* ------------------------------------------------------------------------
+ * CTC head for inference.  Replaces CTCDecoder.forward (src/models/asr_model.py:
+ * 34-50: log_probs = log_softmax(enc W^T + b)) followed by LMUASRModel.decode
+ * with beam_width = 1 (src/models/asr_model.py:158-213: per utterance, arg-max
+ * over the vocabulary for the first lengths[b] frames, then blanks and
+ * consecutive repeats removed).
+ *   enc [B][T][Hd] f32 or bf16 (dtype), W [V][Hd], bias [V] f32, V <= 64,
+ *   lengths [B] (NULL = all T), blank = index of the blank (the reference uses
+ *   vocab_size - 1);
+ *   log_probs [B][T][V] f32 (may be NULL), tokens [B][T] (row b holds counts[b]
+ *   tokens, then -1), counts [B].
+ * ---------------------------------------------------------------------- */
+size_t lmufft_ctc_workspace_bytes(int32_t B, int32_t T);
+int lmufft_ctc_greedy(const void* enc, int dtype, const float* W, const float* bias,
+                      const int32_t* lengths, int32_t B, int32_t T, int32_t Hd, int32_t V,
+                      int32_t blank, float* log_probs, int32_t* tokens, int32_t* counts,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
  * Per-kernel timing with HIP events on the caller's stream (no counterpart in
  * the reference, which has no profiling hooks).  While enabled, every kernel
  * launch made by this library is bracketed by two events; the totals are read

@@ -35,7 +35,7 @@ __global__ void k_lds(long long* out, int iters, int ld_elems) {
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-      const int kl = (r & 3) * 16, row0 = (r >> 2) * 32;
+      const int kl = ((r + it) & 3) * 16, row0 = (r >> 2) * 32;  // loop-variant address: nothing can be hoisted
       if (MODE == 0) {
         typedef bf16x4 __attribute__((address_space(3))) * lp;
         const __bf16* a0 = &S[(kl + 8 * hh + q) * ld_elems + row0 + 16 * g1 + 4 * p];

@@ -1,0 +1,91 @@
+"""CTC head: the oracle against the reference's golden vectors (CPU), the HIP kernels against
+both (GPU).  Token lists must be identical; log-probabilities within fp32 rounding."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ctc_oracle as co
+
+
+def _golden(golden_dir):
+    return dict(np.load(os.path.join(golden_dir, "ctc_greedy.npz")))
+
+
+def _lists(tokens, counts):
+    return [list(map(int, tokens[i, : int(counts[i])])) for i in range(len(counts))]
+
+
+def test_ctc_oracle_matches_reference_golden(golden_dir):
+    g = _golden(golden_dir)
+    lp = co.log_probs(g["enc"], g["W"], g["b"])
+    np.testing.assert_allclose(lp, g["log_probs"], rtol=1e-5, atol=1e-5)
+    assert co.greedy_decode(g["log_probs"], g["lengths"]) == _lists(g["tokens"], g["counts"])
+    assert co.greedy_decode(lp, g["lengths"]) == _lists(g["tokens"], g["counts"])
+    # collapse rules on a hand-made path: blank = 3
+    lp2 = np.full((1, 8, 4), -9.0)
+    for t, k in enumerate([3, 1, 1, 3, 1, 2, 2, 3]):
+        lp2[0, t, k] = 0.0
+    assert co.greedy_decode(lp2, [8]) == [[1, 1, 2]]
+    assert co.greedy_decode(lp2, [3]) == [[1]]
+    assert co.greedy_decode(lp2, [0]) == [[]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_ctc_head_matches_reference_golden(golden_dir, dtype):
+    from asr_amd import CTCDecoder
+
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    dev = torch.device("cuda:0")
+    g = _golden(golden_dir)
+    B, T, Hd = g["enc"].shape
+    V = g["W"].shape[0]
+    head = CTCDecoder(Hd, V)
+    with torch.no_grad():
+        head.ctc_projection.weight.copy_(torch.from_numpy(g["W"]))
+        head.ctc_projection.bias.copy_(torch.from_numpy(g["b"]))
+    head = head.to(dev)
+    enc = torch.from_numpy(g["enc"]).to(dev).to(dtype)
+    lengths = torch.from_numpy(g["lengths"]).to(dev)
+    want = _lists(g["tokens"], g["counts"])
+    if dtype == torch.float32:
+        lp = head(enc).cpu().numpy()
+        np.testing.assert_allclose(lp, g["log_probs"], rtol=1e-4, atol=2e-5)
+        assert head.decode(enc, lengths) == want  # token-identical
+        tokens, counts = head.greedy(enc, lengths)
+        assert (tokens.cpu().numpy() == g["tokens"]).all() and (counts.cpu().numpy() == g["counts"]).all()
+    else:
+        # bf16 encoder output: identical to the oracle run on the same rounded input
+        enc_r = enc.float().cpu().numpy()
+        ref = co.greedy_decode(co.log_probs(enc_r, g["W"], g["b"]), g["lengths"])
+        assert head.decode(enc, lengths) == ref
+
+
+@pytest.mark.gpu
+def test_ctc_head_full_batch_and_edges():
+    """Batch 256 x 400 frames (the inference config): every utterance against the oracle."""
+    from asr_amd import CTCDecoder
+
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    B, T, Hd, V = 256, 400, 384, 34
+    head = CTCDecoder(Hd, V).to(dev)
+    torch.nn.init.xavier_uniform_(head.ctc_projection.weight, gain=4.0)
+    base = torch.randn(B, T // 5 + 1, Hd).repeat_interleave(5, dim=1)[:, :T]
+    enc = (base + 0.2 * torch.randn(B, T, Hd)).to(dev)
+    lengths = torch.randint(0, T + 1, (B,))
+    lengths[0], lengths[1] = T, 0
+    got = head.decode(enc, lengths.to(dev))
+    lp = co.log_probs(enc.cpu().numpy(), head.ctc_projection.weight.detach().cpu().numpy(),
+                      head.ctc_projection.bias.detach().cpu().numpy())
+    assert got == co.greedy_decode(lp, lengths.numpy())
+    assert got[1] == []
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        head(enc.cpu())
+    with pytest.raises(RuntimeError, match="one entry per lane"):
+        CTCDecoder(Hd, 100).to(dev)(enc)
