@@ -1,0 +1,122 @@
+"""Minimal end-to-end harness around the HIP path: the reference's encoder stack with this
+package's LMUFFT layers and CTC head, so that a reference checkpoint can be evaluated on the GPU
+and greedy decodes can be compared token by token.
+
+Only the LMUFFT layers, the mel frontend and the CTC head are HIP kernels of this package; input
+/ output projections, self-attention and layer norms are plain torch ops (rocBLAS) -- they are
+outside the hot path and exist here so that the path can be exercised in place.  Module and
+parameter names follow the reference so that its state_dict loads unchanged:
+  encoder.input_projection, encoder.attention_layers.{i}.attention.{w_q,w_k,w_v,w_o,layer_norm},
+  encoder.lmu_layers.{i}, encoder.layer_norms.{i}, encoder.output_projection,
+  decoder.ctc_projection
+(reference: src/models/lmu_encoder.py:23-47, 183-229; src/models/asr_model.py:69-102).
+Inference only: dropout is the identity.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from .ctc import CTCDecoder
+from .lmu import LMUFFT
+
+
+class _MultiHeadAttention(nn.Module):
+    """softmax(Q K^T / sqrt(d_k), masked) V, output projection, residual, layer norm
+    (reference: src/models/lmu_encoder.py:48-99)."""
+
+    def __init__(self, d_model: int, num_heads: int):
+        super().__init__()
+        if d_model % num_heads:
+            raise ValueError("d_model must be a multiple of num_heads")
+        self.num_heads, self.d_k = num_heads, d_model // num_heads
+        self.w_q = nn.Linear(d_model, d_model)
+        self.w_k = nn.Linear(d_model, d_model)
+        self.w_v = nn.Linear(d_model, d_model)
+        self.w_o = nn.Linear(d_model, d_model)
+        self.layer_norm = nn.LayerNorm(d_model)
+
+    def forward(self, x: torch.Tensor, lengths: Optional[torch.Tensor]) -> torch.Tensor:
+        B, T, C = x.shape
+        split = lambda t: t.view(B, T, self.num_heads, self.d_k).transpose(1, 2)  # noqa: E731
+        q, k, v = split(self.w_q(x)), split(self.w_k(x)), split(self.w_v(x))
+        scores = q @ k.transpose(-2, -1) / math.sqrt(self.d_k)
+        if lengths is not None:
+            # mask[b, i, j] = (i < len_b) and (j < len_b); masked scores are SET to -1e9, so a fully
+            # masked row (i >= len_b) becomes a uniform distribution, exactly as in the reference
+            valid = torch.arange(T, device=x.device)[None, :] < lengths.to(x.device)[:, None]
+            mask = valid[:, :, None] & valid[:, None, :]
+            scores = scores.masked_fill(~mask[:, None], -1e9)
+        ctx = (torch.softmax(scores, dim=-1) @ v).transpose(1, 2).reshape(B, T, C)
+        return self.layer_norm(self.w_o(ctx) + x)
+
+
+class _SelfAttention(nn.Module):
+    def __init__(self, d_model: int, num_heads: int):
+        super().__init__()
+        self.attention = _MultiHeadAttention(d_model, num_heads)
+
+    def forward(self, x, lengths):
+        return self.attention(x, lengths)
+
+
+class LMUEncoder(nn.Module):
+    """Constructor arguments as the reference's LMUEncoder (src/models/lmu_encoder.py:141-151);
+    `use_fft_lmu` must be True."""
+
+    def __init__(self, input_size=80, hidden_size=512, memory_size=256, num_lmu_layers=4, theta=128, dropout=0.1,
+                 use_fft_lmu=True, seq_len=None, use_attention=True, num_attention_heads=8):
+        super().__init__()
+        if not use_fft_lmu:
+            raise NotImplementedError("only the FFT-LMU encoder is implemented (use_fft_lmu=True)")
+        if seq_len is None:
+            raise ValueError("seq_len must be specified when using FFT-based LMU")
+        self.hidden_size, self.use_attention = hidden_size, use_attention
+        self.input_projection = nn.Linear(input_size, hidden_size)
+        self.attention_layers = nn.ModuleList(
+            [_SelfAttention(hidden_size, num_attention_heads) if use_attention else nn.Identity()
+             for _ in range(num_lmu_layers)])
+        self.lmu_layers = nn.ModuleList(
+            [LMUFFT(hidden_size, hidden_size, memory_size, seq_len, theta) for _ in range(num_lmu_layers)])
+        self.layer_norms = nn.ModuleList([nn.LayerNorm(hidden_size) for _ in range(num_lmu_layers)])
+        self.output_projection = nn.Linear(hidden_size, hidden_size)
+
+    def forward(self, x: torch.Tensor, lengths: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, list]:
+        x = self.input_projection(x)
+        states = []
+        for att, lmu, ln in zip(self.attention_layers, self.lmu_layers, self.layer_norms):
+            if self.use_attention:
+                x = att(x, lengths)
+            x, h_n = lmu(x)
+            states.append(h_n)
+            x = ln(x)
+        return self.output_projection(x), states
+
+    def get_output_dim(self) -> int:
+        return self.hidden_size
+
+
+class LMUASRModel(nn.Module):
+    """Encoder + CTC head with the reference model's state_dict layout (src/models/asr_model.py:53-128)."""
+
+    def __init__(self, input_size, hidden_size, memory_size, num_lmu_layers, theta, seq_len, vocab_size,
+                 num_attention_heads=8, use_attention=True):
+        super().__init__()
+        self.encoder = LMUEncoder(input_size, hidden_size, memory_size, num_lmu_layers, theta, 0.0, True, seq_len,
+                                  use_attention, num_attention_heads)
+        self.decoder = CTCDecoder(hidden_size, vocab_size)
+        self.vocab_size = vocab_size
+
+    @torch.no_grad()
+    def forward(self, spectrograms: torch.Tensor, input_lengths: Optional[torch.Tensor] = None):
+        encoded, states = self.encoder(spectrograms, input_lengths)
+        return self.decoder(encoded), states
+
+    @torch.no_grad()
+    def transcribe(self, spectrograms: torch.Tensor, input_lengths: Optional[torch.Tensor] = None) -> List[List[int]]:
+        """Greedy CTC token lists (the reference's decode(log_probs, input_lengths, beam_width=1))."""
+        encoded, _ = self.encoder(spectrograms, input_lengths)
+        return self.decoder.decode(encoded, input_lengths)
