@@ -165,10 +165,14 @@ __global__ __launch_bounds__(kThreads) void k_conv_fwd_bf16(const float* __restr
   gemm_loop_kc<TL>(oa, ob, acc, 0, kend, w);
 
   bf16_t* mb = m + (long)b * T * M;
-  tileb_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
-    const int t = t0 + mm, n = n0 + nn;
-    if (t < T && n < M) mb[(long)t * M + n] = (bf16_t)v;
-  });
+  if (M % 8 == 0) {  // rows of m are 16-byte aligned: whole row segments through LDS (free after the loop)
+    store_tile_bf16<TL>(acc, w, smem, mb, M, t0, n0, T, M, [](int, int, int, int, int, float v) { return v; });
+  } else {
+    tileb_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
+      const int t = t0 + mm, n = n0 + nn;
+      if (t < T && n < M) mb[(long)t * M + n] = (bf16_t)v;
+    });
+  }
 }
 
 // ---------------------------------------------------------------------------
