@@ -76,6 +76,8 @@ def _load():
     lib.lmufft_ctc_workspace_bytes.argtypes = [i32, i32]
     lib.lmufft_ctc_greedy.restype = ci
     lib.lmufft_ctc_greedy.argtypes = [vp, ci, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]
+    lib.lmufft_attention_fwd.restype = ci
+    lib.lmufft_attention_fwd.argtypes = [vp, vp, vp, ci, vp, i32, i32, i32, i32, vp, vp]
     lib.lmufft_fftprep_bytes.restype = sz
     lib.lmufft_fftprep_bytes.argtypes = [sp]
     lib.lmufft_fftprep_f32.restype = ci
@@ -126,6 +128,7 @@ EXPORTS = (
     "lmufft_melprep",
     "lmufft_mel_frames",
     "lmufft_mel_forward_f32",
+    "lmufft_attention_fwd",
     "lmufft_ctc_workspace_bytes",
     "lmufft_ctc_greedy",
     "lmufft_hprep_bytes",

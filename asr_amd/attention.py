@@ -1,0 +1,46 @@
+"""Masked self-attention core on the GPU (HIP kernel k_attention_fwd; inference, no autograd).
+
+Mirrors the score / softmax / context part of the reference's MultiHeadAttention.forward
+(src/models/lmu_encoder.py:68-91) with the length mask of LMUEncoder.forward (:247-252), on the
+[batch, frames, heads * d_k] tensors that its Linear layers produce and consume.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+_DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
+SUPPORTED_HEAD_WIDTHS = (32, 64, 128)
+
+
+def masked_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int,
+                     lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """softmax(q k^T / sqrt(d_k), masked by lengths) v per head; q, k, v, result: [B, T, heads * d_k]."""
+    for name, t in (("q", q), ("k", k), ("v", v)):
+        if not t.is_cuda:
+            raise RuntimeError(f"masked_attention: `{name}` lives on {t.device}; the kernel runs only on a GPU "
+                               "(there is no CPU fallback)")
+    if q.dim() != 3 or q.shape != k.shape or q.shape != v.shape:
+        raise RuntimeError(f"masked_attention: q, k, v must share one [batch, frames, channels] shape, got "
+                           f"{tuple(q.shape)}, {tuple(k.shape)}, {tuple(v.shape)}")
+    if q.dtype not in _DTYPES or k.dtype != q.dtype or v.dtype != q.dtype:
+        raise RuntimeError(f"masked_attention: dtypes {q.dtype}, {k.dtype}, {v.dtype}; supported: all float32 or "
+                           "all bfloat16")
+    B, T, C = q.shape
+    if C % num_heads:
+        raise RuntimeError(f"masked_attention: {C} channels do not split into {num_heads} heads")
+    dk = C // num_heads
+    q, k, v = q.detach().contiguous(), k.detach().contiguous(), v.detach().contiguous()
+    if lengths is not None:
+        lengths = lengths.to(device=q.device, dtype=torch.int32).contiguous()
+    ctx = torch.empty_like(q)
+    p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    with torch.cuda.device(q.device):
+        rc = _lib.lib.lmufft_attention_fwd(p(q), p(k), p(v), _DTYPES[q.dtype], p(lengths), B, T, num_heads, dk, p(ctx),
+                                           ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream))
+    _lib.check(rc, "lmufft_attention_fwd")
+    return ctx

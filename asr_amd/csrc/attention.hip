@@ -1,0 +1,216 @@
+// Masked multi-head self-attention core for inference on gfx950:
+//   ctx[b, i, h*dk + d] = sum_j softmax_j( q_i . k_j / sqrt(dk), masked )[j] * v[b, j, h*dk + d]
+// without materialising the [B, H, T, T] score and weight tensors.
+//
+// Reference arithmetic: MultiHeadAttention.forward, src/models/lmu_encoder.py:68-91 (scores =
+// Q K^T / sqrt(d_k); scores.masked_fill(mask == 0, -1e9) with mask[b, i, j] = (i < len_b) and
+// (j < len_b), built at src/models/lmu_encoder.py:247-252; softmax over j; dropout (identity in
+// eval mode); context = weights V, heads concatenated).  Masked scores are SET to -1e9, so a query
+// row past the utterance's end attends uniformly to all T positions -- reproduced here.
+//
+// fp32 arithmetic on the exact-fp32 MFMA (v_mfma_f32_32x32x2f32).  One wave owns 32 queries and
+// walks the keys in tiles of 32.  It computes the TRANSPOSED score tile S^T[key][query] = K Q^T:
+// in the MFMA output layout a lane then holds one query's scores (16 registers x 2 lane halves),
+// so the online-softmax row statistics cost one cross-half shuffle, and the probability
+// registers are, as they stand, the B operand of O^T[d][query] += V^T[d][key] P^T[key][query].
+// Nothing goes through LDS between the two contractions.  K and V tiles are staged in LDS once
+// per workgroup (4 waves = 128 queries of one head), next tile prefetched into registers.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "lmufft.h"
+#include "lmufft_internal.h"
+
+namespace lmufft {
+
+typedef float attn_f16v __attribute__((ext_vector_type(16)));
+typedef float attn_f4 __attribute__((ext_vector_type(4)));
+typedef __bf16 attn_bf16;
+
+constexpr int kAttnThreads = 256;
+constexpr int kAttnKeys = 32;       // keys per tile
+constexpr int kAttnQBlock = 128;    // queries per workgroup
+
+template <class T>
+__device__ __forceinline__ float attn_ld(const T* p) { return (float)*p; }
+
+template <int DK, class TIO>
+__global__ __launch_bounds__(kAttnThreads) void k_attention_fwd(const TIO* __restrict__ q, const TIO* __restrict__ k,
+                                                                const TIO* __restrict__ v,
+                                                                const int* __restrict__ lengths,
+                                                                TIO* __restrict__ ctx, int T, int H, float scale) {
+  static_assert(DK % 32 == 0 && DK <= 128, "head width: 32, 64, 96 or 128");
+  constexpr int KP = DK + 1;   // K tile pitch: lane = key, banks (key + d) distinct
+  constexpr int VP = DK + 8;   // V tile pitch: lane = d, the two lane halves 4 rows apart land 32 banks apart
+  constexpr int DT = DK / 32;  // 32-row tiles of O^T
+  constexpr int NS = DK / 2;   // MFMA steps of the score contraction (2 values of d per step)
+  __shared__ float Ks[kAttnKeys * KP];
+  __shared__ float Vs[kAttnKeys * VP];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int C = H * DK;
+  const int len = lengths ? min(max(lengths[b], 0), T) : T;
+  const long base = (long)b * T * C + (long)h * DK;
+  const int qi = blockIdx.x * kAttnQBlock + wave * 32 + r;  // this lane's query
+  const bool q_in = qi < T, q_valid = qi < len;
+
+  // Q[qi][d] for d = s + hh*NS, pre-scaled by 1/sqrt(dk): the B operand of every score step
+  float qreg[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) qreg[s] = q_in ? attn_ld(q + base + (long)qi * C + s + hh * NS) * scale : 0.f;
+
+  attn_f16v o[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // staging: thread -> (row, 4-float chunk) of the K and V tiles
+  constexpr int CH = DK / 4;                       // chunks per row
+  constexpr int NV = kAttnKeys * CH / kAttnThreads;  // chunks per thread and tensor (DK = 64: 2)
+  static_assert(kAttnKeys * CH % kAttnThreads == 0, "whole chunks per thread");
+  attn_f4 kst[NV], vst[NV];
+  auto fetch = [&](int j0) {
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const int idx = tid + n * kAttnThreads, row = idx / CH, c = (idx % CH) * 4;
+      const int j = min(j0 + row, T - 1);  // rows past T are masked below; keep the address valid
+      const TIO* kp = k + base + (long)j * C + c;
+      const TIO* vp = v + base + (long)j * C + c;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        kst[n][e] = attn_ld(kp + e);
+        vst[n][e] = attn_ld(vp + e);
+      }
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const int idx = tid + n * kAttnThreads, row = idx / CH, c = (idx % CH) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        Ks[row * KP + c + e] = kst[n][e];
+        Vs[row * VP + c + e] = vst[n][e];
+      }
+    }
+  };
+
+  fetch(0);
+  for (int j0 = 0; j0 < T; j0 += kAttnKeys) {
+    __syncthreads();  // everybody has finished with the previous tile
+    stage();
+    __syncthreads();
+    if (j0 + kAttnKeys < T) fetch(j0 + kAttnKeys);
+
+    // S^T[key r'][query] : lane supplies K[key = r][d = s + hh*NS] and its own Q value
+    attn_f16v st;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+      st = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[r * KP + s + hh * NS], qreg[s], st, 0, 0, 0);
+
+    // register i of this lane: key j0 + rho_i + 4*hh, query qi
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int j = j0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+      float sv = (q_valid && j < len) ? st[i] : -1e9f;
+      sv = j < T ? sv : -INFINITY;
+      st[i] = sv;
+      mx = fmaxf(mx, sv);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);           // finite: every tile holds at least one key < T
+    const float alpha = __expf(m_run - m_new);      // 0 on the first tile (m_run = -inf)
+    float psum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      st[i] = __expf(st[i] - m_new);
+      psum += st[i];
+    }
+    psum += __shfl_xor(psum, 32);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[t][i] *= alpha;
+    // O^T[d][query] += V^T[d][key] P^T[key][query]: A = V[key rho_i + 4hh][d = 32t + r], B = st[i]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+        o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[row * VP + 32 * t + r], st[i], o[t], 0, 0, 0);
+    }
+  }
+
+  // O^T / l -> ctx rows (through LDS: lanes hold queries, rows of ctx want lanes along d)
+  __syncthreads();
+  const float inv = 1.0f / l_run;
+  // each wave owns a strip of 8 queries x KP floats of the (now free) K tile and empties its 32
+  // queries in four passes
+  constexpr int STRIP = 8 * KP;  // 4 waves x 8 x KP = the K tile
+  float* ws = Ks + wave * STRIP;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    // queries 8*pass .. 8*pass+7 of this wave
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int d = 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        if ((r >> 3) == pass) ws[(r & 7) * KP + d] = o[t][i] * inv;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private strip: program order suffices
+    for (int idx = lane; idx < 8 * DK; idx += 64) {
+      const int ql = idx / DK, d = idx % DK;
+      const int qq = blockIdx.x * kAttnQBlock + wave * 32 + pass * 8 + ql;
+      if (qq < T) ctx[base + (long)qq * C + d] = (TIO)ws[ql * KP + d];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+}  // namespace lmufft
+
+using namespace lmufft;
+
+extern "C" {
+
+int lmufft_attention_fwd(const void* q, const void* k, const void* v, int dtype, const int32_t* lengths, int32_t B,
+                         int32_t T, int32_t H, int32_t DK, void* ctx, void* stream) {
+  if (B <= 0 || T <= 0 || H <= 0) return set_error("attention: bad shape (B=%d T=%d H=%d)", B, T, H);
+  if (DK != 32 && DK != 64 && DK != 128) return set_error("attention: head width %d; supported: 32, 64, 128", DK);
+  if (dtype != LMUFFT_F32 && dtype != LMUFFT_BF16) return set_error("attention: unknown dtype %d", dtype);
+  if (!q || !k || !v || !ctx) return set_error("attention: NULL pointer");
+  if (H > 65535 || B > 65535) return set_error("attention: H and B must fit a grid dimension");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((T + kAttnQBlock - 1) / kAttnQBlock, H, B);
+  const float scale = 1.0f / sqrtf((float)DK);
+#define ATTN_LAUNCH(DKV, TY)                                                                                   \
+  hipLaunchKernelGGL((k_attention_fwd<DKV, TY>), grid, dim3(kAttnThreads), 0, st, (const TY*)q, (const TY*)k,  \
+                     (const TY*)v, lengths, (TY*)ctx, T, H, scale)
+  {
+    ProfScope ps("k_attention_fwd", st);
+    if (dtype == LMUFFT_F32) {
+      if (DK == 32) ATTN_LAUNCH(32, float);
+      else if (DK == 64) ATTN_LAUNCH(64, float);
+      else ATTN_LAUNCH(128, float);
+    } else {
+      if (DK == 32) ATTN_LAUNCH(32, attn_bf16);
+      else if (DK == 64) ATTN_LAUNCH(64, attn_bf16);
+      else ATTN_LAUNCH(128, attn_bf16);
+    }
+  }
+#undef ATTN_LAUNCH
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error("launch of k_attention_fwd failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
+}  // extern "C"

@@ -2,8 +2,8 @@
 package's LMUFFT layers and CTC head, so that a reference checkpoint can be evaluated on the GPU
 and greedy decodes can be compared token by token.
 
-Only the LMUFFT layers, the mel frontend and the CTC head are HIP kernels of this package; input
-/ output projections, self-attention and layer norms are plain torch ops (rocBLAS) -- they are
+The LMUFFT layers, the attention core, the mel frontend and the CTC head are HIP kernels of this
+package; input / output / attention projections and layer norms are plain torch ops (rocBLAS) -- they are
 outside the hot path and exist here so that the path can be exercised in place.  Module and
 parameter names follow the reference so that its state_dict loads unchanged:
   encoder.input_projection, encoder.attention_layers.{i}.attention.{w_q,w_k,w_v,w_o,layer_norm},
@@ -20,6 +20,7 @@ from typing import List, Optional, Tuple
 import torch
 from torch import nn
 
+from .attention import SUPPORTED_HEAD_WIDTHS, masked_attention
 from .ctc import CTCDecoder
 from .lmu import LMUFFT
 
@@ -41,6 +42,10 @@ class _MultiHeadAttention(nn.Module):
 
     def forward(self, x: torch.Tensor, lengths: Optional[torch.Tensor]) -> torch.Tensor:
         B, T, C = x.shape
+        if x.is_cuda and self.d_k in SUPPORTED_HEAD_WIDTHS and not torch.is_grad_enabled():
+            # HIP kernel: no [B, heads, T, T] score tensor, no per-utterance mask loop
+            ctx = masked_attention(self.w_q(x), self.w_k(x), self.w_v(x), self.num_heads, lengths)
+            return self.layer_norm(self.w_o(ctx) + x)
         split = lambda t: t.view(B, T, self.num_heads, self.d_k).transpose(1, 2)  # noqa: E731
         q, k, v = split(self.w_q(x)), split(self.w_k(x)), split(self.w_v(x))
         scores = q @ k.transpose(-2, -1) / math.sqrt(self.d_k)

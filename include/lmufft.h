@@ -199,6 +199,21 @@ int lmufft_ctc_greedy(const void* enc, int dtype, const float* W, const float* b
                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Masked self-attention core for inference.  Replaces the score / softmax /
+ * context part of MultiHeadAttention.forward, src/models/lmu_encoder.py:68-91
+ * (scores = Q K^T / sqrt(d_k); masked_fill(mask == 0, -1e9) with mask[b,i,j] =
+ * i < len_b and j < len_b, src/models/lmu_encoder.py:247-252; softmax;
+ * weights V; heads concatenated), without the [B,H,T,T] tensors.
+ *   q, k, v, ctx: [B][T][H*DK], f32 or bf16 (dtype), head h in columns
+ *   h*DK .. (h+1)*DK-1 (the layout the reference's Linear layers produce and
+ *   its output projection consumes); lengths [B] or NULL (no mask);
+ *   DK in {32, 64, 128}.  fp32 arithmetic.  Dropout is not applied (eval).
+ * ---------------------------------------------------------------------- */
+int lmufft_attention_fwd(const void* q, const void* k, const void* v, int dtype,
+                         const int32_t* lengths, int32_t B, int32_t T, int32_t H,
+                         int32_t DK, void* ctx, void* stream);
+
+/* ------------------------------------------------------------------------
  * Per-kernel timing with HIP events on the caller's stream (no counterpart in
  * the reference, which has no profiling hooks).  While enabled, every kernel
  * launch made by this library is bracketed by two events; the totals are read
