@@ -8,7 +8,8 @@
 // eval mode); context = weights V, heads concatenated).  Masked scores are SET to -1e9, so a query
 // row past the utterance's end attends uniformly to all T positions -- reproduced here.
 //
-// fp32 arithmetic on the exact-fp32 MFMA (v_mfma_f32_32x32x2f32).  One wave owns 32 queries and
+// fp32 tensors: fp32 arithmetic on the exact-fp32 MFMA (v_mfma_f32_32x32x2f32); bf16 tensors: the
+// bf16 MFMA variant further down.  One wave owns 32 queries and
 // walks the keys in tiles of 32.  It computes the TRANSPOSED score tile S^T[key][query] = K Q^T:
 // in the MFMA output layout a lane then holds one query's scores (16 registers x 2 lane halves),
 // so the online-softmax row statistics cost one cross-half shuffle, and the probability
@@ -176,6 +177,154 @@ __global__ __launch_bounds__(kAttnThreads) void k_attention_fwd(const TIO* __res
   }
 }
 
+// ---------------------------------------------------------------------------
+// bf16 inputs/outputs: the same structure on v_mfma_f32_32x32x16_bf16 (fp32 scores, softmax
+// statistics and accumulation; probabilities rounded to bf16 for the value contraction).
+// A probability register i of lane half hh is key 16*(i>>3) + 4*hh + (i&3) + 8*((i>>2)&1) of the
+// tile; the eight registers 8*half .. 8*half+7 of a lane form one B fragment as they stand, if the
+// A fragment V^T[d][.] lists the keys in that order -- so V is staged TRANSPOSED, its keys
+// permuted: position 16*half + 8*hh + j of a row holds that key, and a fragment is one ds_read_b128.
+// ---------------------------------------------------------------------------
+typedef __bf16 attn_bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int DK>
+__global__ __launch_bounds__(kAttnThreads) void k_attention_fwd_bf16(const attn_bf16* __restrict__ q,
+                                                                     const attn_bf16* __restrict__ k,
+                                                                     const attn_bf16* __restrict__ v,
+                                                                     const int* __restrict__ lengths,
+                                                                     attn_bf16* __restrict__ ctx, int T, int H,
+                                                                     float scale) {
+  static_assert(DK % 32 == 0 && DK <= 128, "head width: 32, 64, 96 or 128");
+  constexpr int KP = DK + 8;          // K tile [key][d], 16-byte padded rows: conflict-free b128 fragments
+  constexpr int VTP = kAttnKeys + 8;  // V^T tile [d][key slot], 80-byte rows
+  constexpr int DT = DK / 32, NS = DK / 16;
+  constexpr int OP = DK + 1;          // fp32 output strip pitch
+  __shared__ __attribute__((aligned(16))) attn_bf16 Ks[kAttnKeys * KP];
+  __shared__ __attribute__((aligned(16))) attn_bf16 Vt[DK * VTP];
+  __shared__ float Os[4 * 8 * OP];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int C = H * DK;
+  const int len = lengths ? min(max(lengths[b], 0), T) : T;
+  const long base = (long)b * T * C + (long)h * DK;
+  const int qi = blockIdx.x * kAttnQBlock + wave * 32 + r;
+  const bool q_valid = qi < len;
+  const int qc = min(qi, T - 1);
+
+  attn_bf16x8 qf[NS];  // B fragments of the score contraction: Q[query r][16s + 8hh .. +7]
+#pragma unroll
+  for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const attn_bf16x8*>(q + base + (long)qc * C + 16 * s + 8 * hh);
+
+  attn_f16v o[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  constexpr int CH = DK / 8;                         // 16-byte chunks per key row
+  constexpr int NV = (kAttnKeys * CH + kAttnThreads - 1) / kAttnThreads;
+  attn_bf16x8 kst[NV], vst[NV];
+  auto fetch = [&](int j0) {
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const int idx = tid + n * kAttnThreads;
+      if (idx < kAttnKeys * CH) {
+        const int row = idx / CH, c = (idx % CH) * 8;
+        const int j = min(j0 + row, T - 1);
+        kst[n] = *reinterpret_cast<const attn_bf16x8*>(k + base + (long)j * C + c);
+        vst[n] = *reinterpret_cast<const attn_bf16x8*>(v + base + (long)j * C + c);
+      }
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const int idx = tid + n * kAttnThreads;
+      if (idx < kAttnKeys * CH) {
+        const int row = idx / CH, c = (idx % CH) * 8;
+        *reinterpret_cast<attn_bf16x8*>(&Ks[row * KP + c]) = kst[n];
+        // key `row` -> slot of the permuted key order
+        const int k16 = row & 15, rem = k16 & 7;
+        const int slot = 16 * (row >> 4) + 8 * (rem >> 2) + (rem & 3) + 4 * (k16 >> 3);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Vt[(c + e) * VTP + slot] = vst[n][e];
+      }
+    }
+  };
+
+  fetch(0);
+  for (int j0 = 0; j0 < T; j0 += kAttnKeys) {
+    __syncthreads();
+    stage();
+    __syncthreads();
+    if (j0 + kAttnKeys < T) fetch(j0 + kAttnKeys);
+
+    attn_f16v st;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const attn_bf16x8 kf = *reinterpret_cast<const attn_bf16x8*>(&Ks[r * KP + 16 * s + 8 * hh]);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st, 0, 0, 0);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int j = j0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+      float sv = (q_valid && j < len) ? st[i] * scale : -1e9f;
+      sv = j < T ? sv : -INFINITY;
+      st[i] = sv;
+      mx = fmaxf(mx, sv);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);
+    float psum = 0.f;
+    attn_bf16x8 pf[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float pv = __expf(st[i] - m_new);
+      psum += pv;
+      pf[i >> 3][i & 7] = (attn_bf16)pv;
+    }
+    psum += __shfl_xor(psum, 32);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[t][i] *= alpha;
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const attn_bf16x8 vf = *reinterpret_cast<const attn_bf16x8*>(&Vt[(32 * t + r) * VTP + 16 * half + 8 * hh]);
+        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[half], o[t], 0, 0, 0);
+      }
+  }
+
+  const float inv = 1.0f / l_run;
+  float* ws = Os + wave * 8 * OP;  // wave-private strip of 8 queries
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int d = 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        if ((r >> 3) == pass) ws[(r & 7) * OP + d] = o[t][i] * inv;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int idx = lane; idx < 8 * DK; idx += 64) {
+      const int ql = idx / DK, d = idx % DK;
+      const int qq = blockIdx.x * kAttnQBlock + wave * 32 + pass * 8 + ql;
+      if (qq < T) ctx[base + (long)qq * C + d] = (attn_bf16)ws[ql * OP + d];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
 }  // namespace lmufft
 
 using namespace lmufft;
@@ -189,6 +338,9 @@ int lmufft_attention_fwd(const void* q, const void* k, const void* v, int dtype,
   if (dtype != LMUFFT_F32 && dtype != LMUFFT_BF16) return set_error("attention: unknown dtype %d", dtype);
   if (!q || !k || !v || !ctx) return set_error("attention: NULL pointer");
   if (H > 65535 || B > 65535) return set_error("attention: H and B must fit a grid dimension");
+  // the bf16 kernel loads 16 bytes at a time (a head's columns start on multiples of 64 bytes)
+  if (dtype == LMUFFT_BF16 && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) != 0)
+    return set_error("attention: bf16 tensors must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((T + kAttnQBlock - 1) / kAttnQBlock, H, B);
   const float scale = 1.0f / sqrtf((float)DK);
@@ -202,9 +354,13 @@ int lmufft_attention_fwd(const void* q, const void* k, const void* v, int dtype,
       else if (DK == 64) ATTN_LAUNCH(64, float);
       else ATTN_LAUNCH(128, float);
     } else {
-      if (DK == 32) ATTN_LAUNCH(32, attn_bf16);
-      else if (DK == 64) ATTN_LAUNCH(64, attn_bf16);
-      else ATTN_LAUNCH(128, attn_bf16);
+#define ATTN_LAUNCH_B(DKV)                                                                                       \
+  hipLaunchKernelGGL((k_attention_fwd_bf16<DKV>), grid, dim3(kAttnThreads), 0, st, (const attn_bf16*)q,          \
+                     (const attn_bf16*)k, (const attn_bf16*)v, lengths, (attn_bf16*)ctx, T, H, scale)
+      if (DK == 32) ATTN_LAUNCH_B(32);
+      else if (DK == 64) ATTN_LAUNCH_B(64);
+      else ATTN_LAUNCH_B(128);
+#undef ATTN_LAUNCH_B
     }
   }
 #undef ATTN_LAUNCH

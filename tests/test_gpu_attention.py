@@ -63,6 +63,22 @@ def test_attention_bf16_and_long_sequence():
     assert np.abs(got[:, sl] - ref).max() <= 2 ** -8 * np.abs(ref).max() + 1e-3
 
 
+@pytest.mark.parametrize("B,T,H,dk,lengths", CASES)
+def test_attention_bf16_matches_oracle(B, T, H, dk, lengths):
+    """bf16 tensors (bf16 MFMA, probabilities rounded to bf16): the oracle on the rounded inputs;
+    errors of a convex combination of v's stay within a few bf16 ulps of max|v|."""
+    from asr_amd.attention import masked_attention
+
+    dev = _dev()
+    rng = np.random.default_rng(B * 100 + T + 1)
+    q, k, v = (torch.from_numpy(rng.standard_normal((B, T, H * dk)).astype(np.float32)).bfloat16() for _ in range(3))
+    ln = None if lengths is None else torch.tensor(lengths)
+    got = masked_attention(q.to(dev), k.to(dev), v.to(dev), H, ln).float().cpu().numpy()
+    ref = ao.attention_core(q.float().numpy(), k.float().numpy(), v.float().numpy(), lengths, H)
+    assert np.abs(got - ref).max() <= 2 ** -7 * np.abs(v.float().numpy()).max()
+    assert np.sqrt(((got - ref) ** 2).mean()) <= 2 ** -8 * np.sqrt((ref ** 2).mean()) + 1e-3
+
+
 def test_attention_errors():
     from asr_amd.attention import masked_attention
 
