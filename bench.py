@@ -5,8 +5,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = forward + backward through the encoder's stack of three LMUFFT
-layers (hidden 384, memory 192, theta 1000, 400 frames; BASELINE config 2's
-layer shape) on one synthetic batch of 64 utterances per GPU, including the
+layers (hidden 384, memory 192, theta 1000, 400 frames: the layer shape the
+training-throughput metric is quoted on) on one synthetic batch of 64 utterances per GPU, including the
 data-parallel gradient exchange.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
@@ -263,7 +263,7 @@ def main():
                 "workload": f"{args.layers} stacked LMUFFT layers (input {D}, hidden {Hd}, memory {M}, theta "
                             f"{args.theta:g}, seq_len {T}) fwd+bwd, batch {B} per GPU, {args.dtype} activations with fp32 "
                             f"accumulation and fp32 parameters, conv={args.conv}; "
-                            "BASELINE config 2 layer shape",
+                            "training-throughput layer shape",
                 "batch_per_gpu": B, "frames": T, "layers": args.layers, "parallelism": f"dp{world}",
                 "launch": "eager" if args.no_graph else "hip graph replay",
             },

@@ -1,4 +1,4 @@
-"""CPU port of the reference's LMUFFT arithmetic with torch ops -- TEST / BASELINE
+"""CPU port of the reference's LMUFFT arithmetic with torch ops -- TEST / CPU-BASELINE
 INFRASTRUCTURE, NOT A PRODUCT PATH.
 
 It exists for one purpose: to be *timed* on the host cores as the

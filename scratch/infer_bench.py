@@ -1,4 +1,4 @@
-"""BASELINE's inference configuration: raw 16 kHz audio (batch 256 x 4 s) -> mel frontend -> 3-layer encoder
+"""The inference benchmark configuration: raw 16 kHz audio (batch 256 x 4 s) -> mel frontend -> 3-layer encoder
 (384/192, 6 heads) -> greedy CTC, everything on the GPU; per-stage and end-to-end times."""
 import json, sys, time, torch
 from asr_amd import MelFrontend, _lib

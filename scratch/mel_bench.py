@@ -1,4 +1,4 @@
-"""Times the mel frontend at BASELINE's inference shape (256 x 4 s) and a 30 s batch."""
+"""Times the mel frontend at the inference benchmark shape (256 x 4 s) and a 30 s batch."""
 import torch
 from asr_amd import MelFrontend, _lib
 

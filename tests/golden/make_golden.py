@@ -77,7 +77,7 @@ def main():
     run_case("tiny_f32", 12, 10, 6, 16, 8, 2, 11, torch.float32, 0.3)
     # the shape the reference's own smoke script drives (pytorch-test-setup.py:55-64)
     run_case("smoke100_f32", 80, 256, 128, 100, 1000, 4, 21, torch.float32, 0.1)
-    # BASELINE config 1: 80-mel input, 400 frames / in-encoder 384 input, 200 frames
+    # CPU-runnable reference case: 80-mel input, 400 frames / in-encoder 384 input, 200 frames
     layer = run_case("cfg1a_f32", 80, 384, 192, 400, 1000, 2, 31, torch.float32, 0.0)
     run_case("cfg1c_f32", 384, 384, 192, 200, 1000, 2, 41, torch.float32, 0.0, use_hn=False)
 

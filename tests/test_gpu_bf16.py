@@ -1,5 +1,5 @@
 """GPU parity of the bf16 kernels.  The reference cannot run this path in bf16
-on a GPU (torch.fft rejects bf16), so the bar is the one BASELINE states: the
+on a GPU (torch.fft rejects bf16), so the bar is the stated bf16 one: the
 fp32 reference arithmetic (here: the fp64 oracle) evaluated on the SAME
 bf16-rounded inputs and weights, rtol 2e-2 -- taken relative to |value| plus
 the norm of the terms of the sum that produces the value (see _close), since an
@@ -92,8 +92,8 @@ SHAPES = [
     (1, 1, 8, 8, 8, 8),
     (2, 100, 80, 128, 256, 100),  # reference smoke shape
     (2, 65, 80, 192, 384, 100),
-    (3, 200, 384, 192, 384, 200),  # BASELINE config 1c
-    (2, 400, 80, 192, 384, 400),   # BASELINE config 1a
+    (3, 200, 384, 192, 384, 200),  # in-encoder layer after 2x downsampling
+    (2, 400, 80, 192, 384, 400),   # first layer: 80 mel bins, 400 frames
     (1, 1200, 24, 192, 64, 1200),  # long utterance: many k-parts in both convolution kernels
 ]
 
@@ -172,7 +172,7 @@ def test_bf16_module_autocast_and_golden(golden_dir):
 
 
 def test_bf16_full_size_properties():
-    """BASELINE config 2 layer shape in bf16: a slice against the oracle, plus exact structural properties."""
+    """Benchmark layer shape (B=64, T=400, 384/192) in bf16: a slice against the oracle, plus exact structural properties."""
     from asr_amd import LMUFFT
 
     dev = _dev()

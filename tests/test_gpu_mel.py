@@ -86,7 +86,7 @@ def test_mel_tone_silence_and_long_utterance():
     _check(got[near], ref[near], atol=2e-3, name="tone, bins within 60 dB of the peak")
     assert np.abs(got - ref)[~near].max() < 1.0
     assert got[0, 100].argmax() == ref[0, 100].argmax()
-    # 30 s utterance (3000 frames), BASELINE's long-utterance shape
+    # 30 s utterance (3000 frames), the long-utterance benchmark shape
     rng = np.random.default_rng(3)
     w = _noise(rng, 1, 479840)
     mel, frames = fe(torch.from_numpy(w).to(dev))
@@ -95,7 +95,7 @@ def test_mel_tone_silence_and_long_utterance():
 
 
 def test_mel_full_batch_properties():
-    """Batch 256 x 4 s (BASELINE's inference config): a few utterances against the oracle,
+    """Batch 256 x 4 s (the inference benchmark shape): a few utterances against the oracle,
     zero mean / unit unbiased std per utterance and bin for all."""
     from asr_amd import MelFrontend
 

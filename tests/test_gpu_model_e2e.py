@@ -53,7 +53,7 @@ def test_full_model_matches_reference(golden_dir):
 
 def test_audio_to_tokens_pipeline():
     """Raw 16 kHz audio in HBM -> mel frontend -> encoder -> greedy CTC, nothing touching the host
-    until the token lists (BASELINE's inference configuration at a small batch); bf16 and fp32 runs
+    until the token lists (the inference benchmark pipeline at a small batch); bf16 and fp32 runs
     of the same model agree on most tokens."""
     from asr_amd import MelFrontend
     from asr_amd.harness import LMUASRModel

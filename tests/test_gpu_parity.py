@@ -59,8 +59,8 @@ CONV_SHAPES = [
     (2, 16, 6, 16),      # tiny, scalar paths
     (3, 37, 5, 41),      # nothing divisible by 4, T < ldH
     (2, 100, 128, 100),  # reference smoke shape
-    (2, 200, 192, 200),  # BASELINE config 1 after 2x downsampling
-    (2, 400, 192, 400),  # BASELINE config 1
+    (2, 200, 192, 200),  # 4 s utterance after 2x downsampling
+    (2, 400, 192, 400),  # 4 s utterance, 400 frames
     (1, 130, 200, 400),  # M > one 192-wide tile, T < ldH
 ]
 
@@ -90,7 +90,7 @@ def test_conv_backward_matches_oracle(B, T, M, ldH):
 
 
 def test_conv_long_utterance_3000_frames():
-    """BASELINE's long-utterance shape (T = 3000, memory 192) on the Toeplitz kernels, against
+    """The long-utterance shape (30 s audio: T = 3000, memory 192) on the Toeplitz kernels, against
     the oracle's FFT evaluation of the same sums (the direct double sum is O(T^2) on the CPU)."""
     from asr_amd import causal_conv, causal_conv_adjoint
 
@@ -111,7 +111,7 @@ def test_conv_long_utterance_3000_frames():
 
 
 def test_conv_known_answers_full_size(golden_dir):
-    """Size-independent properties at BASELINE's full size (B=64, T=400, M=192)."""
+    """Size-independent properties at the benchmark's full size (B=64, T=400, M=192)."""
     from asr_amd import causal_conv, causal_conv_adjoint
 
     dev = _dev()
@@ -260,7 +260,7 @@ def test_module_state_dict_roundtrip_and_forward(golden_dir):
 
 
 def test_full_size_layer_properties(golden_dir):
-    """BASELINE config 2 layer shape (B=64, T=400, 384/192): oracle on a slice,
+    """Benchmark layer shape (B=64, T=400, 384/192): oracle on a slice,
     gradient identity on the whole."""
     from asr_amd import LMUFFT
 
