@@ -10,6 +10,7 @@
 // this path in bf16 on a GPU (torch.fft rejects bf16), so parity is defined
 // against the fp32 reference on bf16-rounded inputs, rtol 2e-2.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include <stdlib.h>
@@ -600,6 +601,21 @@ __global__ __launch_bounds__(kThreads) void k_conv_bwd2_bf16(const bf16_t* __res
 //   gb_u    = sum_rows ga[row]
 // The slabs are summed afterwards in a fixed order.
 // ---------------------------------------------------------------------------
+#ifdef LMUFFT_STAMPS
+// Debug build only: per-workgroup timestamps of the weight-gradient kernel (100 MHz wall clock in
+// slots 0..3, shader-clock sums in slots 4..7), read back through lmufft_debug_stamps().
+__device__ long long g_stamps[8 * 4096];
+#define LMUFFT_STAMP(i) \
+  if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 8 + (i)] = wall_clock64()
+#define LMUFFT_STAMP_ADD(i, v) \
+  if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 8 + (i)] += (v)
+#define LMUFFT_CLOCK() clock64()
+#else
+#define LMUFFT_STAMP(i)
+#define LMUFFT_STAMP_ADD(i, v)
+#define LMUFFT_CLOCK() 0
+#endif
+
 using WgradTileB = TileB<128, 192, 64, 2, 2>;
 static_assert(WgradTileB::BK <= 64, "one wave stages the ga slice of a k tile");
 
@@ -613,6 +629,10 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
   const int MD = M + D;
+  LMUFFT_STAMP(0);
+  LMUFFT_STAMP_ADD(4, -g_stamps[blockIdx.x * 8 + 4]);
+  LMUFFT_STAMP_ADD(5, -g_stamps[blockIdx.x * 8 + 5]);
+  LMUFFT_STAMP_ADD(6, -g_stamps[blockIdx.x * 8 + 6]);
   // all output tiles of one row range share its slices of gz and [m;x]: same XCD
   const int tiles_j = (MD + TL::BN - 1) / TL::BN, tiles_n = (Hd + TL::BM - 1) / TL::BM;
   const XcdSlot slot = xcd_slot(tiles_j * tiles_n);
@@ -667,7 +687,7 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
   const int RB = tiles_j * TL::WGN, RU = tiles_n * TL::WGM;
   const int slot_b = tile_j * TL::WGN + w.wn0 / TL::WN, slot_u = tile_n * TL::WGM + w.wm0 / TL::WM;
   int cnt_b = slot_b, cnt_u = slot_u;  // k-steps until this wave's next turn
-  f32x16 accb[TL::TM], accu[TL::TN][2];
+  f32x16 accb[TL::TM], accu[TL::TN];
 #pragma unroll
   for (int t = 0; t < TL::TM; ++t)
 #pragma unroll
@@ -675,31 +695,96 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
 #pragma unroll
   for (int t = 0; t < TL::TN; ++t)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) accu[t][0][i] = accu[t][1][i] = 0.f;
+    for (int i = 0; i < 16; ++i) accu[t][i] = 0.f;
   bf16x8 ones;
 #pragma unroll
   for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.f;
-  // Pipeline over k-tiles: tile i is multiplied out of LDS stage i & 1 while tile i + 1 waits in
-  // registers and is then written to the other stage, and the loads of tile i + 2 start: one
-  // barrier per k-tile, and a wave's LDS writes overlap the other waves' MFMAs.
+  // Pipeline over k-tiles: two LDS stages and two register sets.  In the round of tile i the wave
+  // writes tile i + 1 from one register set to the other stage, refills that set with the global
+  // loads of tile i + 3, then multiplies tile i -- so the loads of two k-tiles (80 KB per
+  // workgroup) are in flight during every round and each has two rounds to land; with one tile in
+  // flight the loop ran at the pace of one memory round trip per k-tile.  (Spreading the loads
+  // between the k-steps' MFMAs does not help: a wave that waits for the vector-memory queue to
+  // take its load cannot issue MFMAs either, so the issue time is paid wherever the loads stand.)  The loop is unrolled by
+  // two so that the register sets are named statically.  One barrier per k-tile.
+  // With VEC the staging addresses are kept as running pointers (a thread's vectors keep their
+  // columns from tile to tile; only the row advances), so a round spends a handful of VALU
+  // instructions per vector on addressing instead of re-deriving rows and panels.
   constexpr int kStageElems = OpA::ELEMS + OpB::ELEMS + 2 * TL::BK;  // + the ga slice (BK floats)
   auto stage_A = [&](int st) { return smem + st * kStageElems; };
   auto stage_B = [&](int st) { return smem + st * kStageElems + OpA::ELEMS; };
   auto stage_ga = [&](int st) { return reinterpret_cast<float*>(smem + st * kStageElems + OpA::ELEMS + OpB::ELEMS); };
-  float ga_reg = 0.f, gbu = 0.f;
-  auto fetch = [&](int k0) {
-    oa.fetch(k0);
-    ob.fetch(k0);
-    if (tid < TL::BK) ga_reg = (k0 + tid < kend) ? ga[k0 + tid] : 0.f;
+  bf16x8 ra[2][OpA::NV], rb[2][OpB::NV];
+  float ga_reg[2] = {0.f, 0.f}, gbu = 0.f;
+  const bf16_t* const zero_line = reinterpret_cast<const bf16_t*>(kZeroBytes);
+  const bf16_t* pa[OpA::NV];
+  const bf16_t* pb[OpB::NV];
+  int inc_b[OpB::NV];
+  unsigned col_ok = 0;  // bit i: A vector i inside Hd; bit 8 + i: B vector i inside M + D
+  if (VEC) {
+#pragma unroll
+    for (int i = 0; i < OpA::NV; ++i) {
+      const int idx = tid + i * kThreads;
+      const int c = n0 + (idx % (TL::BM / 8)) * 8, kr = idx / (TL::BM / 8);
+      pa[i] = gz + (long)(kbeg + kr) * Hd + c;
+      col_ok |= (c < Hd ? 1u : 0u) << i;
+    }
+#pragma unroll
+    for (int i = 0; i < OpB::NV; ++i) {
+      const int idx = tid + i * kThreads;
+      const int j = j0 + (idx % (TL::BN / 8)) * 8, kr = idx / (TL::BN / 8);
+      pb[i] = j < M ? m + (long)(kbeg + kr) * M + j : x + (long)(kbeg + kr) * D + (j - M);
+      inc_b[i] = TL::BK * (j < M ? M : D);
+      col_ok |= (j < MD ? 1u : 0u) << (8 + i);
+    }
+  }
+  // tiles are fetched in order (with VEC the pointers stand at tile k0); rows at or beyond kend
+  // come from the zero line, so rounds always store and fetch and the staging has no branches
+  auto fetch = [&](auto set_c, int k0) __attribute__((always_inline)) {
+    constexpr int set = decltype(set_c)::value;
+#pragma unroll
+    for (int i = 0; i < OpA::NV; ++i) {
+      const int idx = tid + i * kThreads;
+      const int kr = idx / (TL::BM / 8);
+      if (VEC) {
+        const bf16_t* p = (((col_ok >> i) & 1u) && k0 + kr < kend) ? pa[i] : zero_line;
+        ra[set][i] = *reinterpret_cast<const bf16x8*>(p);
+        pa[i] += (long)TL::BK * Hd;
+      } else {
+        ra[set][i] = la.fetch((idx % (TL::BM / 8)) * 8, k0 + kr);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < OpB::NV; ++i) {
+      const int idx = tid + i * kThreads;
+      const int kr = idx / (TL::BN / 8);
+      if (VEC) {
+        const bf16_t* p = (((col_ok >> (8 + i)) & 1u) && k0 + kr < kend) ? pb[i] : zero_line;
+        rb[set][i] = *reinterpret_cast<const bf16x8*>(p);
+        pb[i] += inc_b[i];
+      } else {
+        rb[set][i] = lb.fetch((idx % (TL::BN / 8)) * 8, k0 + kr);
+      }
+    }
+    if (tid < TL::BK) ga_reg[set] = (k0 + tid < kend) ? ga[k0 + tid] : 0.f;
   };
-  auto store = [&](int st) {
-    oa.S = stage_A(st);
-    ob.S = stage_B(st);
-    oa.store();
-    ob.store();
+  auto store = [&](auto set_c, int st) __attribute__((always_inline)) {
+    constexpr int set = decltype(set_c)::value;
+    bf16_t* sa = stage_A(st);
+    bf16_t* sb = stage_B(st);
+#pragma unroll
+    for (int i = 0; i < OpA::NV; ++i) {
+      const int idx = tid + i * kThreads;
+      *reinterpret_cast<bf16x8*>(&sa[(idx / (TL::BM / 8)) * OpA::LD + (idx % (TL::BM / 8)) * 8]) = ra[set][i];
+    }
+#pragma unroll
+    for (int i = 0; i < OpB::NV; ++i) {
+      const int idx = tid + i * kThreads;
+      *reinterpret_cast<bf16x8*>(&sb[(idx / (TL::BN / 8)) * OpB::LD + (idx % (TL::BN / 8)) * 8]) = rb[set][i];
+    }
     if (tid < TL::BK) {
-      stage_ga(st)[tid] = ga_reg;
-      gbu += ga_reg;
+      stage_ga(st)[tid] = ga_reg[set];
+      gbu += ga_reg[set];
     }
   };
   auto read_frags = [&](bf16x8 (&af)[TL::TM], bf16x8 (&bfr)[TL::TN], int kl) {
@@ -708,19 +793,18 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
 #pragma unroll
     for (int tn = 0; tn < TL::TN; ++tn) bfr[tn] = ob.frag32(w.wn0 + tn * 32, kl);
   };
-  if (kbeg < kend) {
-    fetch(kbeg);
-    store(0);
-    if (kbeg + TL::BK < kend) fetch(kbeg + TL::BK);
-  }
-  __syncthreads();
-  int st = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += TL::BK, st ^= 1) {
+  // round of the tile at k0, which sits in stage st; the tile at k0 + BK waits in register set
+  // `set_c` and that set is refilled with the tile at k0 + 3 BK
+  auto round = [&](auto set_c, int k0, int st) __attribute__((always_inline)) {
+    [[maybe_unused]] const long long c0 = LMUFFT_CLOCK();
+    store(set_c, st ^ 1);  // that stage was last read before the previous barrier
     oa.S = stage_A(st);
     ob.S = stage_B(st);
     const float* gaS = stage_ga(st);
     bf16x8 fa[2][TL::TM], fb[2][TL::TN];
     read_frags(fa[0], fb[0], 0);
+    fetch(set_c, k0 + 3 * TL::BK);
+    [[maybe_unused]] const long long c1 = LMUFFT_CLOCK();
 #pragma unroll
     for (int ks = 0; ks < TL::BK / 16; ++ks) {
       const int kl = ks * 16;
@@ -752,18 +836,37 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
         }
 #pragma unroll
         for (int tn = 0; tn < TL::TN; ++tn) {
-          accu[tn][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ghi, bfr[tn], accu[tn][0], 0, 0, 0);
-          accu[tn][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(glo, bfr[tn], accu[tn][1], 0, 0, 0);
+          accu[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ghi, bfr[tn], accu[tn], 0, 0, 0);
+        }
+#pragma unroll
+        for (int tn = 0; tn < TL::TN; ++tn) {
+          accu[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(glo, bfr[tn], accu[tn], 0, 0, 0);
         }
       }
       --cnt_u;
     }
-    if (k0 + TL::BK < kend) {
-      store(st ^ 1);
-      if (k0 + 2 * TL::BK < kend) fetch(k0 + 2 * TL::BK);
-    }
+    [[maybe_unused]] const long long c2 = LMUFFT_CLOCK();
     __syncthreads();
+    [[maybe_unused]] const long long c3 = LMUFFT_CLOCK();
+    LMUFFT_STAMP_ADD(4, c2 - c1);
+    LMUFFT_STAMP_ADD(5, c1 - c0);
+    LMUFFT_STAMP_ADD(6, c3 - c2);
+  };
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
+  fetch(Set0{}, kbeg);
+  fetch(Set1{}, kbeg + TL::BK);
+  store(Set0{}, 0);
+  fetch(Set0{}, kbeg + 2 * TL::BK);
+  __syncthreads();
+  LMUFFT_STAMP(1);
+  int k0 = kbeg;
+  for (; k0 + TL::BK < kend; k0 += 2 * TL::BK) {
+    round(Set1{}, k0, 0);
+    round(Set0{}, k0 + TL::BK, 1);
   }
+  if (k0 < kend) round(Set1{}, k0, 0);  // odd number of tiles
+  LMUFFT_STAMP(2);
 
   // gW_h tile -> slab through LDS: 16-byte stores of whole row segments (the operand area is free
   // after the loop's last barrier; the launch reserves BM * (BN + 4) floats)
@@ -803,7 +906,7 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
 #pragma unroll
     for (int tn = 0; tn < TL::TN; ++tn) {
       const int j = j0 + w.wn0 + tn * 32 + w.r;
-      if (j >= M && j < MD) dst[j - M] = accu[tn][0][0] + accu[tn][1][0];
+      if (j >= M && j < MD) dst[j - M] = accu[tn][0];
     }
   }
   if (tile_n == 0 && tile_j == 0 && tid < 64) {  // gb_u = sum of ga over the row range
@@ -812,7 +915,14 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     if (tid == 0) slab[off_gbu] = v;
   }
+  LMUFFT_STAMP(3);
 }
+
+#ifdef LMUFFT_STAMPS
+extern "C" int lmufft_debug_stamps(long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(long long) * std::min(n, 8 * 4096));
+}
+#endif
 
 
 struct HprepLayout {
