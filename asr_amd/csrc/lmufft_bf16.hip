@@ -30,6 +30,25 @@ static inline int up8(int v) { return (v + 7) & ~7; }
 static inline size_t align256b(size_t v) { return (v + 255) & ~size_t(255); }
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+#ifdef LMUFFT_STAMPS
+// Debug build only (-DLMUFFT_STAMPS=<kernel id>: 1 weight gradient, 2 forward convolution):
+// per-workgroup timestamps (100 MHz wall clock in slots 0..3, shader-clock sums in slots 4..7),
+// read back through lmufft_debug_stamps().
+__device__ long long g_stamps[8 * 4096];
+__device__ __forceinline__ int stamp_block() {
+  return blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+}
+#define LMUFFT_STAMP(id, i) \
+  if (LMUFFT_STAMPS == (id) && threadIdx.x == 0 && stamp_block() < 4096) g_stamps[stamp_block() * 8 + (i)] = wall_clock64()
+#define LMUFFT_STAMP_ADD(id, i, v) \
+  if (LMUFFT_STAMPS == (id) && threadIdx.x == 0 && stamp_block() < 4096) g_stamps[stamp_block() * 8 + (i)] += (v)
+#define LMUFFT_CLOCK() clock64()
+#else
+#define LMUFFT_STAMP(id, i)
+#define LMUFFT_STAMP_ADD(id, i, v)
+#define LMUFFT_CLOCK() 0
+#endif
+
 // ---------------------------------------------------------------------------
 // operand preparation
 // ---------------------------------------------------------------------------
@@ -142,10 +161,16 @@ __global__ __launch_bounds__(kThreads) void k_conv_fwd_bf16(const float* __restr
   OpB ob(smem, lb);
   bf16_t* U8 = smem + OpB::ELEMS;
 
-  // time-reversed u around this tile: position p <-> frame s = (t0 + BM - 1) - p
+  // time-reversed u around this tile: position p <-> frame s = (t0 + BM - 1) - p.  The frames
+  // come into LDS with one coalesced load per thread (one memory round trip), and the eight
+  // shifted copies are cut from there.
   const float* ub = u + (long)b * T;
   const int smax = t0 + TL::BM - 1;
   const int nchunks = (kend_pad / 8 + 8) * 8;
+  float* uf = reinterpret_cast<float*>(U8 + nchunks * 8);  // u[0 .. kend) of this batch item
+  for (int s = threadIdx.x; s < kend; s += kThreads) uf[s] = ub[s];
+  LMUFFT_STAMP(2, 0);
+  __syncthreads();
   for (int ch = threadIdx.x; ch < nchunks; ch += kThreads) {
     const int Q = ch >> 3, c = ch & 7;
     bf16x8 v;
@@ -153,10 +178,11 @@ __global__ __launch_bounds__(kThreads) void k_conv_fwd_bf16(const float* __restr
     for (int j = 0; j < 8; ++j) {
       const int p = 8 * Q + j - c;
       const int s = smax - p;
-      v[j] = (bf16_t)((p >= 0 && s >= 0 && s < T) ? ub[s] : 0.f);
+      v[j] = (bf16_t)((p >= 0 && s >= 0 && s < kend) ? uf[s] : 0.f);
     }
     *reinterpret_cast<bf16x8*>(&U8[ch * 8]) = v;
   }
+  LMUFFT_STAMP(2, 1);
   // (the first barrier inside gemm_loop_kc orders the fill against the reads)
 
   ToeplitzOperand<TL> oa{U8};
@@ -165,6 +191,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_fwd_bf16(const float* __restr
   tileb_zero<TL>(acc);
   gemm_loop_kc<TL>(oa, ob, acc, 0, kend, w);
 
+  LMUFFT_STAMP(2, 2);
   bf16_t* mb = m + (long)b * T * M;
   if (M % 8 == 0) {  // rows of m are 16-byte aligned: whole row segments through LDS (free after the loop)
     store_tile_bf16<TL>(acc, w, smem, mb, M, t0, n0, T, M, [](int, int, int, int, int, float v) { return v; });
@@ -174,6 +201,8 @@ __global__ __launch_bounds__(kThreads) void k_conv_fwd_bf16(const float* __restr
       if (t < T && n < M) mb[(long)t * M + n] = (bf16_t)v;
     });
   }
+  LMUFFT_STAMP(2, 3);
+  LMUFFT_STAMP_ADD(2, 4, kend - g_stamps[stamp_block() * 8 + 4]);
 }
 
 // ---------------------------------------------------------------------------
@@ -601,21 +630,6 @@ __global__ __launch_bounds__(kThreads) void k_conv_bwd2_bf16(const bf16_t* __res
 //   gb_u    = sum_rows ga[row]
 // The slabs are summed afterwards in a fixed order.
 // ---------------------------------------------------------------------------
-#ifdef LMUFFT_STAMPS
-// Debug build only: per-workgroup timestamps of the weight-gradient kernel (100 MHz wall clock in
-// slots 0..3, shader-clock sums in slots 4..7), read back through lmufft_debug_stamps().
-__device__ long long g_stamps[8 * 4096];
-#define LMUFFT_STAMP(i) \
-  if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 8 + (i)] = wall_clock64()
-#define LMUFFT_STAMP_ADD(i, v) \
-  if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 8 + (i)] += (v)
-#define LMUFFT_CLOCK() clock64()
-#else
-#define LMUFFT_STAMP(i)
-#define LMUFFT_STAMP_ADD(i, v)
-#define LMUFFT_CLOCK() 0
-#endif
-
 using WgradTileB = TileB<128, 192, 64, 2, 2>;
 static_assert(WgradTileB::BK <= 64, "one wave stages the ga slice of a k tile");
 
@@ -629,10 +643,10 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
   const int MD = M + D;
-  LMUFFT_STAMP(0);
-  LMUFFT_STAMP_ADD(4, -g_stamps[blockIdx.x * 8 + 4]);
-  LMUFFT_STAMP_ADD(5, -g_stamps[blockIdx.x * 8 + 5]);
-  LMUFFT_STAMP_ADD(6, -g_stamps[blockIdx.x * 8 + 6]);
+  LMUFFT_STAMP(1, 0);
+  LMUFFT_STAMP_ADD(1, 4, -g_stamps[stamp_block() * 8 + 4]);
+  LMUFFT_STAMP_ADD(1, 5, -g_stamps[stamp_block() * 8 + 5]);
+  LMUFFT_STAMP_ADD(1, 6, -g_stamps[stamp_block() * 8 + 6]);
   // all output tiles of one row range share its slices of gz and [m;x]: same XCD
   const int tiles_j = (MD + TL::BN - 1) / TL::BN, tiles_n = (Hd + TL::BM - 1) / TL::BM;
   const XcdSlot slot = xcd_slot(tiles_j * tiles_n);
@@ -848,9 +862,9 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
     [[maybe_unused]] const long long c2 = LMUFFT_CLOCK();
     __syncthreads();
     [[maybe_unused]] const long long c3 = LMUFFT_CLOCK();
-    LMUFFT_STAMP_ADD(4, c2 - c1);
-    LMUFFT_STAMP_ADD(5, c1 - c0);
-    LMUFFT_STAMP_ADD(6, c3 - c2);
+    LMUFFT_STAMP_ADD(1, 4, c2 - c1);
+    LMUFFT_STAMP_ADD(1, 5, c1 - c0);
+    LMUFFT_STAMP_ADD(1, 6, c3 - c2);
   };
   using Set0 = std::integral_constant<int, 0>;
   using Set1 = std::integral_constant<int, 1>;
@@ -859,14 +873,14 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
   store(Set0{}, 0);
   fetch(Set0{}, kbeg + 2 * TL::BK);
   __syncthreads();
-  LMUFFT_STAMP(1);
+  LMUFFT_STAMP(1, 1);
   int k0 = kbeg;
   for (; k0 + TL::BK < kend; k0 += 2 * TL::BK) {
     round(Set1{}, k0, 0);
     round(Set0{}, k0 + TL::BK, 1);
   }
   if (k0 < kend) round(Set1{}, k0, 0);  // odd number of tiles
-  LMUFFT_STAMP(2);
+  LMUFFT_STAMP(1, 2);
 
   // gW_h tile -> slab through LDS: 16-byte stores of whole row segments (the operand area is free
   // after the loop's last barrier; the launch reserves BM * (BN + 4) floats)
@@ -915,7 +929,7 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     if (tid == 0) slab[off_gbu] = v;
   }
-  LMUFFT_STAMP(3);
+  LMUFFT_STAMP(1, 3);
 }
 
 #ifdef LMUFFT_STAMPS
@@ -1111,7 +1125,8 @@ int lmufft_forward_bf16(const lmufft_shape* s, const void* x_, const float* w_u,
     using TL = ConvFwdTileB;
     const dim3 grid(cdivb(s->M, TL::BN), s->B, cdivb(s->T, TL::BM));
     const int kpad = cdivb(s->T, TL::BK) * TL::BK;
-    const size_t lds = sizeof(bf16_t) * ((size_t)TL::BN * (TL::BK + 8) + (size_t)(kpad / 8 + 8) * 64);
+    const size_t lds = sizeof(bf16_t) * ((size_t)TL::BN * (TL::BK + 8) + (size_t)(kpad / 8 + 8) * 64) +
+                       sizeof(float) * (size_t)kpad;
     if (lds > 160 * 1024) return set_error("sequence too long for the Toeplitz forward kernel (T=%d)", s->T);
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void*)k_conv_fwd_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=

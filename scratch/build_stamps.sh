@@ -1,4 +1,4 @@
 #!/bin/sh
 # Debug build of the library with in-kernel timestamps (see scratch/stamps.py).
-cd "$(dirname "$0")/.." && hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -DLMUFFT_STAMPS \
+cd "$(dirname "$0")/.." && hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -DLMUFFT_STAMPS=${1:-1} \
   -Iinclude -Iasr_amd/csrc -Wno-unused-function -fno-gpu-rdc -o scratch/liblmufft_stamps.so asr_amd/csrc/*.hip
