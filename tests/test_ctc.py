@@ -89,3 +89,34 @@ def test_ctc_head_full_batch_and_edges():
         head(enc.cpu())
     with pytest.raises(RuntimeError, match="one entry per lane"):
         CTCDecoder(Hd, 100).to(dev)(enc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,Hd,V", [
+    (3, 37, 64, 20),    # matrix-pipe kernel, one vocabulary tile, ragged last frame tile
+    (2, 50, 384, 34),   # matrix-pipe kernel, two vocabulary tiles
+    (1, 1, 96, 64),     # a single frame, full 64-entry vocabulary
+    (5, 33, 1024, 29),  # widest encoder the head accepts
+    (2, 45, 100, 34),   # width not a multiple of 32: lane-per-entry kernel
+])
+def test_ctc_head_kernel_routes(B, T, Hd, V, dtype):
+    """Both logits kernels against the oracle: log-probabilities to 1e-4, tokens identical."""
+    from asr_amd import CTCDecoder
+
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(B * 1000 + Hd + V)
+    head = CTCDecoder(Hd, V).to(dev)
+    torch.nn.init.xavier_uniform_(head.ctc_projection.weight, gain=3.0)
+    torch.nn.init.normal_(head.ctc_projection.bias, std=0.5)
+    enc = torch.randn(B, T, Hd).to(dev).to(dtype)
+    lengths = torch.randint(0, T + 1, (B,))
+    lengths[0] = T
+    W = head.ctc_projection.weight.detach().cpu().numpy()
+    b = head.ctc_projection.bias.detach().cpu().numpy()
+    ref_lp = co.log_probs(enc.float().cpu().numpy(), W, b)
+    lp = head(enc).cpu().numpy()
+    np.testing.assert_allclose(lp, ref_lp, rtol=1e-4, atol=5e-5)
+    assert head.decode(enc, lengths.to(dev)) == co.greedy_decode(ref_lp, lengths.numpy())
