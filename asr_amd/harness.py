@@ -21,8 +21,19 @@ import torch
 from torch import nn
 
 from .attention import SUPPORTED_HEAD_WIDTHS, masked_attention
+from .layernorm import MAX_WIDTH as _LN_MAX_WIDTH, add_layer_norm
 from .ctc import CTCDecoder
 from .lmu import LMUFFT
+
+
+def _layer_norm(ln: nn.LayerNorm, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """ln(x + residual): the one-pass HIP kernel for inference on the GPU, torch otherwise."""
+    C = x.shape[-1]
+    if (x.is_cuda and not torch.is_grad_enabled() and ln.elementwise_affine and ln.bias is not None
+            and C % 4 == 0 and C <= _LN_MAX_WIDTH and x.dtype in (torch.float32, torch.bfloat16)
+            and (residual is None or residual.dtype in (torch.float32, torch.bfloat16))):
+        return add_layer_norm(x, residual, ln.weight, ln.bias, ln.eps)
+    return ln(x if residual is None else x + residual)
 
 
 class _MultiHeadAttention(nn.Module):
@@ -45,7 +56,7 @@ class _MultiHeadAttention(nn.Module):
         if x.is_cuda and self.d_k in SUPPORTED_HEAD_WIDTHS and not torch.is_grad_enabled():
             # HIP kernel: no [B, heads, T, T] score tensor, no per-utterance mask loop
             ctx = masked_attention(self.w_q(x), self.w_k(x), self.w_v(x), self.num_heads, lengths)
-            return self.layer_norm(self.w_o(ctx) + x)
+            return _layer_norm(self.layer_norm, self.w_o(ctx), x)
         split = lambda t: t.view(B, T, self.num_heads, self.d_k).transpose(1, 2)  # noqa: E731
         q, k, v = split(self.w_q(x)), split(self.w_k(x)), split(self.w_v(x))
         scores = q @ k.transpose(-2, -1) / math.sqrt(self.d_k)
@@ -97,7 +108,7 @@ class LMUEncoder(nn.Module):
                 x = att(x, lengths)
             x, h_n = lmu(x)
             states.append(h_n)
-            x = ln(x)
+            x = _layer_norm(ln, x)
         return self.output_projection(x), states
 
     def get_output_dim(self) -> int:

@@ -1,0 +1,59 @@
+"""Residual add + LayerNorm on the GPU in one pass (HIP kernel k_add_layernorm; inference, no autograd).
+
+Mirrors `self.layer_norm(output + residual)` of the reference's attention block
+(src/models/lmu_encoder.py:97) and the `x = layer_norm(x)` that follows every LMU layer
+(src/models/lmu_encoder.py:274); the dropout after each of them is the identity in eval mode.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+_DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
+MAX_WIDTH = 1024
+
+
+def add_layer_norm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor, bias: torch.Tensor,
+                   eps: float = 1e-5, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """LayerNorm over the last dimension of `x (+ residual)` with fp32 statistics.
+
+    x, residual: [..., C] float32 or bfloat16 (they may differ); weight, bias: [C].  The result has
+    `out_dtype`, by default float32 under autocast (where torch runs layer_norm in fp32) and the
+    promoted input dtype otherwise.
+    """
+    for name, t in (("x", x), ("residual", residual), ("weight", weight), ("bias", bias)):
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(f"add_layer_norm: `{name}` lives on {t.device}; the kernel runs only on a GPU "
+                               "(there is no CPU fallback)")
+    if residual is not None and residual.shape != x.shape:
+        raise RuntimeError(f"add_layer_norm: residual {tuple(residual.shape)} does not match x {tuple(x.shape)}")
+    C = x.shape[-1]
+    if weight.shape != (C,) or bias.shape != (C,):
+        raise RuntimeError(f"add_layer_norm: weight / bias must have shape ({C},)")
+    if x.dtype not in _DTYPES or (residual is not None and residual.dtype not in _DTYPES):
+        raise RuntimeError("add_layer_norm: supported dtypes are float32 and bfloat16")
+    if out_dtype is None:
+        if torch.is_autocast_enabled():
+            out_dtype = torch.float32
+        else:
+            out_dtype = x.dtype if residual is None else torch.promote_types(x.dtype, residual.dtype)
+    if out_dtype not in _DTYPES:
+        raise RuntimeError(f"add_layer_norm: output dtype {out_dtype} is not supported")
+    x = x.detach().contiguous()
+    residual = None if residual is None else residual.detach().contiguous()
+    weight = weight.detach().float().contiguous()
+    bias = bias.detach().float().contiguous()
+    out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    rows = x.numel() // C if C else 0
+    p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    with torch.cuda.device(x.device):
+        rc = _lib.lib.lmufft_add_layernorm(
+            p(x), _DTYPES[x.dtype], p(residual), _DTYPES[residual.dtype] if residual is not None else 0, p(weight),
+            p(bias), float(eps), rows, C, p(out), _DTYPES[out_dtype],
+            ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    _lib.check(rc, "lmufft_add_layernorm")
+    return out

@@ -214,6 +214,22 @@ int lmufft_attention_fwd(const void* q, const void* k, const void* v, int dtype,
                          int32_t DK, void* ctx, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Residual add + layer normalisation for inference, one pass over HBM.
+ * Replaces `self.layer_norm(output + residual)`, src/models/lmu_encoder.py:97
+ * (attention block), and `x = layer_norm(x)` after every LMU layer,
+ * src/models/lmu_encoder.py:274 (res = NULL); the dropout that follows each of
+ * them is the identity in eval mode.
+ *   out[r][:] = (v - mean(v)) / sqrt(var(v) + eps) * gamma + beta,  v = x[r][:] (+ res[r][:]),
+ *   biased variance, statistics and arithmetic in fp32 as torch.nn.LayerNorm.
+ *   x, res, out: [rows][C] contiguous, each f32 or bf16 (x_dtype, res_dtype,
+ *   out_dtype; res may be NULL); gamma, beta: f32 [C]; C % 4 == 0, C <= 1024;
+ *   out may alias x or res.
+ * ---------------------------------------------------------------------- */
+int lmufft_add_layernorm(const void* x, int x_dtype, const void* res, int res_dtype,
+                         const float* gamma, const float* beta, float eps, int64_t rows,
+                         int32_t C, void* out, int out_dtype, void* stream);
+
+/* ------------------------------------------------------------------------
  * Per-kernel timing with HIP events on the caller's stream (no counterpart in
  * the reference, which has no profiling hooks).  While enabled, every kernel
  * launch made by this library is bracketed by two events; the totals are read
