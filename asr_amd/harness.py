@@ -26,14 +26,16 @@ from .ctc import CTCDecoder
 from .lmu import LMUFFT
 
 
-def _layer_norm(ln: nn.LayerNorm, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+def _layer_norm(ln: nn.LayerNorm, x: torch.Tensor, residual: Optional[torch.Tensor] = None,
+                out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """ln(x + residual): the one-pass HIP kernel for inference on the GPU, torch otherwise."""
     C = x.shape[-1]
     if (x.is_cuda and not torch.is_grad_enabled() and ln.elementwise_affine and ln.bias is not None
             and C % 4 == 0 and C <= _LN_MAX_WIDTH and x.dtype in (torch.float32, torch.bfloat16)
             and (residual is None or residual.dtype in (torch.float32, torch.bfloat16))):
-        return add_layer_norm(x, residual, ln.weight, ln.bias, ln.eps)
-    return ln(x if residual is None else x + residual)
+        return add_layer_norm(x, residual, ln.weight, ln.bias, ln.eps, out_dtype=out_dtype)
+    y = ln(x if residual is None else x + residual)
+    return y if out_dtype is None else y.to(out_dtype)
 
 
 class _MultiHeadAttention(nn.Module):
@@ -51,12 +53,13 @@ class _MultiHeadAttention(nn.Module):
         self.w_o = nn.Linear(d_model, d_model)
         self.layer_norm = nn.LayerNorm(d_model)
 
-    def forward(self, x: torch.Tensor, lengths: Optional[torch.Tensor]) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, lengths: Optional[torch.Tensor],
+                out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
         B, T, C = x.shape
         if x.is_cuda and self.d_k in SUPPORTED_HEAD_WIDTHS and not torch.is_grad_enabled():
             # HIP kernel: no [B, heads, T, T] score tensor, no per-utterance mask loop
             ctx = masked_attention(self.w_q(x), self.w_k(x), self.w_v(x), self.num_heads, lengths)
-            return _layer_norm(self.layer_norm, self.w_o(ctx), x)
+            return _layer_norm(self.layer_norm, self.w_o(ctx), x, out_dtype)
         split = lambda t: t.view(B, T, self.num_heads, self.d_k).transpose(1, 2)  # noqa: E731
         q, k, v = split(self.w_q(x)), split(self.w_k(x)), split(self.w_v(x))
         scores = q @ k.transpose(-2, -1) / math.sqrt(self.d_k)
@@ -67,7 +70,7 @@ class _MultiHeadAttention(nn.Module):
             mask = valid[:, :, None] & valid[:, None, :]
             scores = scores.masked_fill(~mask[:, None], -1e9)
         ctx = (torch.softmax(scores, dim=-1) @ v).transpose(1, 2).reshape(B, T, C)
-        return self.layer_norm(self.w_o(ctx) + x)
+        return _layer_norm(self.layer_norm, self.w_o(ctx), x, out_dtype)
 
 
 class _SelfAttention(nn.Module):
@@ -75,8 +78,8 @@ class _SelfAttention(nn.Module):
         super().__init__()
         self.attention = _MultiHeadAttention(d_model, num_heads)
 
-    def forward(self, x, lengths):
-        return self.attention(x, lengths)
+    def forward(self, x, lengths, out_dtype=None):
+        return self.attention(x, lengths, out_dtype)
 
 
 class LMUEncoder(nn.Module):
@@ -99,16 +102,24 @@ class LMUEncoder(nn.Module):
             [LMUFFT(hidden_size, hidden_size, memory_size, seq_len, theta) for _ in range(num_lmu_layers)])
         self.layer_norms = nn.ModuleList([nn.LayerNorm(hidden_size) for _ in range(num_lmu_layers)])
         self.output_projection = nn.Linear(hidden_size, hidden_size)
+        # Under autocast torch's layer_norm returns fp32, and every consumer (three projections, the
+        # LMU layer) casts that tensor to bf16 again.  With bf16_stream the layer norms write bf16
+        # directly: the casts disappear and the residual is the bf16-rounded activation -- a
+        # deviation from the reference's autocast arithmetic of one bf16 rounding per block, inside
+        # the bf16 tolerance.  Off by default.
+        self.bf16_stream = False
 
     def forward(self, x: torch.Tensor, lengths: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, list]:
+        stream = torch.bfloat16 if (self.bf16_stream and x.is_cuda and torch.is_autocast_enabled()
+                                    and torch.get_autocast_dtype("cuda") == torch.bfloat16) else None
         x = self.input_projection(x)
         states = []
         for att, lmu, ln in zip(self.attention_layers, self.lmu_layers, self.layer_norms):
             if self.use_attention:
-                x = att(x, lengths)
+                x = att(x, lengths, stream)
             x, h_n = lmu(x)
             states.append(h_n)
-            x = _layer_norm(ln, x)
+            x = _layer_norm(ln, x, None, stream)
         return self.output_projection(x), states
 
     def get_output_dim(self) -> int:

@@ -11,7 +11,8 @@ fe = MelFrontend()
 wave = 0.1 * torch.randn(B, L, device=dev)
 samples = torch.full((B,), L, device=dev, dtype=torch.int32)
 out = {}
-for dt in (torch.float32, torch.bfloat16):
+for dt, stream in ((torch.float32, False), (torch.bfloat16, False), (torch.bfloat16, True)):
+    model.encoder.bf16_stream = stream
     def run():
         mel, frames = fe(wave, samples)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dt == torch.bfloat16):
@@ -27,7 +28,7 @@ for dt in (torch.float32, torch.bfloat16):
         torch.cuda.synchronize(); prof = _lib.profile_read(); _lib.profile_enable(False)
     kern = {k: round(v[0] / 5 * 1e3, 1) for k, v in prof.items() if v[1]}
     frames = B * 400
-    out[str(dt)[6:]] = {"ms_per_batch": ms, "frames_per_s": frames / ms * 1e3, "audio_seconds_per_s": B * 3.99 / ms * 1e3,
+    out[str(dt)[6:] + ("_stream" if stream else "")] = {"ms_per_batch": ms, "frames_per_s": frames / ms * 1e3, "audio_seconds_per_s": B * 3.99 / ms * 1e3,
                          "hip_kernel_us_per_batch": kern, "hip_kernels_ms": sum(kern.values()) / 1e3}
-    print(str(dt)[6:], f"{ms:.2f} ms per batch of {B} x 4 s = {frames / ms / 1e3:.1f} M frames/s; HIP kernels {sum(kern.values()) / 1e3:.2f} ms", kern, flush=True)
+    print(str(dt)[6:] + ("_stream" if stream else ""), f"{ms:.2f} ms per batch of {B} x 4 s = {frames / ms / 1e3:.1f} M frames/s; HIP kernels {sum(kern.values()) / 1e3:.2f} ms", kern, flush=True)
 json.dump(out, open(sys.argv[1], "w"), indent=1) if len(sys.argv) > 1 else None

@@ -71,3 +71,17 @@ def test_audio_to_tokens_pipeline():
     tokens = model.transcribe(mel, frames)
     assert len(tokens) == 8 and all(len(t) <= int(f) for t, f in zip(tokens, frames))
     assert all(0 <= k < 33 for t in tokens for k in t)
+    # bf16 autocast (the benchmark's dtype) against the fp32 run: log-probabilities within the bf16
+    # bar of their magnitude, with fp32 layer-norm outputs and with the bf16 activation stream
+    with torch.no_grad():
+        lp32 = model(mel, frames)[0].float()
+        valid = (torch.arange(400, device=dev)[None, :] < frames[:, None])
+        scale = float(lp32.abs().max())
+        for stream in (False, True):
+            model.encoder.bf16_stream = stream
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                lpb = model(mel, frames)[0].float()
+            err = float((lpb - lp32)[valid].abs().max())
+            assert err <= 2e-2 * max(1.0, scale) * 4, (stream, err, scale)
+            agree = float((lpb.argmax(-1) == lp32.argmax(-1))[valid].float().mean())
+            assert agree > 0.9, (stream, agree)
