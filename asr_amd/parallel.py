@@ -7,6 +7,8 @@ Here each bucket (by default one per layer, ~0.9 MB) is a flat fp32 buffer
 whose slices ARE the parameters' .grad tensors, so no pack/unpack copies are
 needed; a bucket's all-reduce is launched as soon as the last of its
 gradients has been accumulated, and overlaps the backward of earlier layers.
+The buckets are consecutive slices of one arena, so a graph-replayed step,
+whose backward runs no Python, exchanges all of them in ONE all-reduce.
 On MI355X `backend="nccl"` is RCCL over xGMI.  Constant buffers (A, B, H,
 fft_H) are never communicated.
 """
@@ -50,6 +52,7 @@ class GradBuckets:
         self._handles = []
         self._hooks = []
         self._sunk_modules = []
+        plan = []
         for grp in groups:
             module = grp if isinstance(grp, torch.nn.Module) else None
             params = [p for p in (module.parameters() if module is not None else grp) if p.requires_grad]
@@ -59,7 +62,22 @@ class GradBuckets:
             for p in params:
                 offs.append(n)
                 n += -(-p.numel() // _ALIGN) * _ALIGN
-            flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
+            plan.append((module, params, offs, n))
+        # All buckets are slices of ONE allocation when they agree on dtype and device: a step whose
+        # backward ran without Python (graph replay) then exchanges every gradient with a single
+        # all-reduce -- one collective latency instead of one per layer.
+        kinds = {(ps[0].dtype, ps[0].device) for _, ps, _, _ in plan}
+        self.arena = None
+        if len(kinds) == 1:
+            (dtype, device), = kinds
+            self.arena = torch.zeros(sum(n for _, _, _, n in plan), dtype=dtype, device=device)
+        start = 0
+        for module, params, offs, n in plan:
+            if self.arena is not None:
+                flat = self.arena[start : start + n]
+                start += n
+            else:
+                flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
             views = [flat[o : o + p.numel()].view_as(p) for o, p in zip(offs, params)]
             bi = len(self.buckets)
             self.buckets.append(flat)
@@ -122,17 +140,21 @@ class GradBuckets:
 
     def finish(self) -> None:
         """Wait for the outstanding all-reduces and turn sums into means."""
-        if not self.overlap:
-            for bi in range(len(self.buckets)):
-                self._launch(bi, force=True)
+        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        if not self.overlap and distributed:
+            if self.arena is not None:
+                self._handles.append(dist.all_reduce(self.arena, op=dist.ReduceOp.SUM, group=self.group,
+                                                     async_op=True))
+            else:
+                for bi in range(len(self.buckets)):
+                    self._launch(bi, force=True)
         for h in self._handles:
             h.wait()
         self._handles = []
-        if self.average and dist.is_available() and dist.is_initialized():
+        if self.average and distributed:
             ws = dist.get_world_size(self.group)
-            if ws > 1:
-                for flat in self.buckets:
-                    flat.div_(ws)
+            for flat in ([self.arena] if self.arena is not None else self.buckets):
+                flat.div_(ws)
 
     def capture_step(self, fn):
         """Capture fn() -- forward and backward of one step on static tensors -- into a HIP graph

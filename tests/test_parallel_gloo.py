@@ -70,6 +70,23 @@ def _worker(rank, world, port, ret):
             assert torch.allclose(head.weight.grad, torch.full_like(head.weight, 3 * want))
             assert torch.allclose(head.bias.grad, torch.full_like(head.bias, 3.0))
             assert lo <= head.weight.grad.data_ptr() < hi
+        # the form used by graph-replayed steps: nothing is launched during the backward, finish()
+        # exchanges the whole arena in one all-reduce
+        assert buckets.arena is not None and buckets.arena.numel() == sum(b.numel() for b in buckets.buckets)
+        assert all(b.data_ptr() >= buckets.arena.data_ptr() for b in buckets.buckets)
+        buckets.overlap = False
+        for step in range(2):
+            buckets.zero_grad()
+            head(torch.full((3, 10), float(rank + 1 + step))).sum().backward()
+            for l in reversed(layers):
+                _emulate_layer_backward(l, float(rank + 1 + step))
+            assert not buckets._handles
+            buckets.finish()
+            want = sum(r + 1 + step for r in range(world)) / world
+            for l in layers:
+                for p in l.parameters():
+                    assert torch.allclose(p.grad, torch.full_like(p, want)), (rank, step)
+            assert torch.allclose(head.weight.grad, torch.full_like(head.weight, 3 * want))
         buckets.remove()
         assert all(l.grad_sink is None for l in layers)
         ret[rank] = "ok"
