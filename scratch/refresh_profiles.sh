@@ -1,0 +1,17 @@
+#!/bin/bash
+# Runs on the GPU box (from the repo root): bench lines, rocprofv3 kernel statistics and PMC traffic
+# for both dtypes, written under gpurun_out/refresh/.  Every GPU step has its own time limit.
+set -e
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/refresh
+rm -rf $O && mkdir -p $O
+timeout -k 10 240 python3 bench.py > $O/bench_bf16.json 2> $O/bench_bf16.err
+timeout -k 10 240 python3 bench.py --dtype f32 > $O/bench_f32.json 2> $O/bench_f32.err
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_bf16 -o bf16 -- python3 bench.py --steps 30 > $O/stats_bf16.log 2>&1
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_f32 -o f32 -- python3 bench.py --dtype f32 --steps 30 > $O/stats_f32.log 2>&1
+for dt in bf16 f32; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout -s KILL 180 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$dt/$c -o p -- python3 bench.py --dtype $dt --steps 5 --warmup 1 --no-graph > $O/pmc_${dt}_$c.log 2>&1
+  done
+done
+echo done > $O/DONE
