@@ -422,16 +422,42 @@ __global__ __launch_bounds__(kThreads) void k_dgrad_bf16(const bf16_t* __restric
 }
 
 // LDS-DMA form; needs Hd % 8 == 0, ncols % 8 == 0 and 16-byte aligned rows
+// partial slabs of the adjoint convolution (second form): part[p][row], p < P <= kGaMaxParts
+constexpr int kGaMaxParts = 32;
+struct GaParts {
+  const float* part;  // NULL: ga comes as an array
+  const float* u;
+  float* ga_out;
+  long stride;
+  int P;
+};
+
 template <class TL>
 __global__ __launch_bounds__(TL::THREADS) void k_dgrad_glds_bf16(const bf16_t* __restrict__ gz,
                                                                  const bf16_t* __restrict__ WbT,
                                                                  bf16_t* __restrict__ out,
                                                                  const float* __restrict__ ga,
                                                                  const float* __restrict__ w_u, int rows, int Hd,
-                                                                 int ldWT, int j_begin, int ncols) {
+                                                                 int ldWT, int j_begin, int ncols, GaParts gp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int n0 = blockIdx.x * TL::BN;
   const long m0 = (long)blockIdx.y * TL::BM;
+
+  // Encoder-activation gradient from the adjoint convolution's partial slabs, for this tile's rows:
+  // ga[row] = (u[row] > 0) sum_p part[p][row].  The partial loads are issued here and summed after
+  // the GEMM loop, so their latency hides behind it; the column-tile-0 workgroup also writes ga
+  // for the weight-gradient kernel.  (Replaces a separate reduction kernel.)
+  constexpr int kGaGroups = TL::THREADS / TL::BM;
+  constexpr int kGaPer = (kGaMaxParts + kGaGroups - 1) / kGaGroups;
+  float ga_part[kGaPer];
+  const int ga_row = threadIdx.x % TL::BM, ga_grp = threadIdx.x / TL::BM;
+  if (gp.part) {
+#pragma unroll
+    for (int i = 0; i < kGaPer; ++i) {
+      const int p = ga_grp + i * kGaGroups;
+      ga_part[i] = (p < gp.P && m0 + ga_row < rows) ? gp.part[(long)p * gp.stride + m0 + ga_row] : 0.f;
+    }
+  }
 
   GldsOperand<TL::BM, TL::NW, false> oa(
       smem_raw,
@@ -458,8 +484,31 @@ __global__ __launch_bounds__(TL::THREADS) void k_dgrad_glds_bf16(const bf16_t* _
   gemm_loop_glds<TL>(oa, ob, acc, 0, Hd, w);
 
   float wcol[TL::TN], grow[TL::TM][16];
-  preload_cols<TL>(wcol, w, [&](int nn) { return (ga && n0 + nn < ncols) ? w_u[n0 + nn] : 0.f; });
-  preload_rows<TL>(grow, w, [&](int mm) { return (ga && m0 + mm < rows) ? ga[m0 + mm] : 0.f; });
+  if (gp.part) {  // (the loop ended with a barrier: the stages are free)
+    float* sc = reinterpret_cast<float*>(smem_raw);  // [kGaGroups][BM] partial sums, then [BM] ga
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kGaPer; ++i) s += ga_part[i];
+    sc[ga_grp * TL::BM + ga_row] = s;
+    __syncthreads();
+    float v = 0.f;
+    if (threadIdx.x < TL::BM) {
+#pragma unroll
+      for (int g = 0; g < kGaGroups; ++g) v += sc[g * TL::BM + ga_row];
+      const long row = m0 + ga_row;
+      v = (row < rows && gp.u[row] > 0.f) ? v : 0.f;
+      if (row < rows && n0 == 0) gp.ga_out[row] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < TL::BM) sc[ga_row] = v;
+    __syncthreads();
+    preload_cols<TL>(wcol, w, [&](int nn) { return n0 + nn < ncols ? w_u[n0 + nn] : 0.f; });
+    preload_rows<TL>(grow, w, [&](int mm) { return sc[mm]; });
+    __syncthreads();  // the epilogue reuses the same LDS
+  } else {
+    preload_cols<TL>(wcol, w, [&](int nn) { return (ga && n0 + nn < ncols) ? w_u[n0 + nn] : 0.f; });
+    preload_rows<TL>(grow, w, [&](int mm) { return (ga && m0 + mm < rows) ? ga[m0 + mm] : 0.f; });
+  }
   bf16_t* tile = reinterpret_cast<bf16_t*>(smem_raw);
   store_tile_bf16<TL>(acc, w, tile, out, ncols, m0, n0, rows, ncols,
                       [&](int tm, int tn, int i, int, int, float v) { return v + grow[tm][i] * wcol[tn]; });
@@ -1219,7 +1268,7 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
 
   // out = gz W_h[:, j_begin : j_begin + ncols] (+ ga w_u), LDS-DMA kernel when everything is 16-byte friendly
   auto dgrad = [&](auto glds_tag, auto fallback_tag, const char* name, bf16_t* out, int j_begin, int ncols,
-                   const float* ga_, const float* wu_) -> int {
+                   const float* ga_, const float* wu_, GaParts gparts) -> int {
     using TG = decltype(glds_tag);
     using TF = decltype(fallback_tag);
     const bool fast = (s->Hd % 8 == 0) && (ncols % 8 == 0) && al16(out);
@@ -1232,7 +1281,7 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
         return set_error("cannot reserve %zu bytes of LDS for k_dgrad_glds_bf16", lds);
       PROFB(name);
       hipLaunchKernelGGL(k_dgrad_glds_bf16<TG>, grid, dim3(TG::THREADS), lds, st, (const bf16_t*)gz, WbT, out, ga_,
-                         wu_, (int)rows, s->Hd, wl.ldWT, j_begin, ncols);
+                         wu_, (int)rows, s->Hd, wl.ldWT, j_begin, ncols, gparts);
     } else {
       const dim3 grid(cdivb(ncols, TF::BN), cdivb(rows, TF::BM));
       const size_t lds = sizeof(bf16_t) * (size_t)(TF::BM + TF::BN) * (TF::BK + 8);
@@ -1245,7 +1294,11 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
   };
 
   // gm = gz W_h[:, :M]
-  if (int rc = dgrad(DgradMTileB{}, DgradMTileB{}, "k_dgrad_m_bf16", gm, 0, s->M, nullptr, nullptr)) return rc;
+  const GaParts no_parts{nullptr, nullptr, nullptr, 0, 0};
+  if (int rc = dgrad(DgradMTileB{}, DgradMTileB{}, "k_dgrad_m_bf16", gm, 0, s->M, nullptr, nullptr, no_parts)) return rc;
+  // the input-gradient GEMM can sum the adjoint convolution's partial slabs itself (and write ga)
+  const bool dgrad_x_fast = gx && (s->Hd % 8 == 0) && (s->D % 8 == 0) && al16(gx);
+  GaParts ga_parts = no_parts;
   // ga = (adjoint conv of gm) * (u > 0)
   const int KS = cdivb(s->M, 16);
   if (s->M % 8 == 0 && al16(gm) && (KS == 2 || KS == 4 || KS == 8 || KS == 12 || KS == 16)) {
@@ -1273,7 +1326,11 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
     }
 #undef LAUNCH_CB2
     LAUNCH_CHECKB("k_conv_bwd_bf16");
-    if (int rc = launch_sum_slabs_masked(gupart, u, ga, rows, P, st)) return rc;
+    if (dgrad_x_fast && P <= kGaMaxParts) {
+      ga_parts = GaParts{gupart, u, ga, rows, P};
+    } else {
+      if (int rc = launch_sum_slabs_masked(gupart, u, ga, rows, P, st)) return rc;
+    }
   } else {
     using TL = ConvBwdTileB;
     const dim3 grid(1, s->B, p.ntt);
@@ -1298,7 +1355,8 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
   }
   // gx = gz W_h[:, M:] + ga w_u
   if (gx)
-    if (int rc = dgrad(DgradXGldsTile{}, DgradXTileB{}, "k_dgrad_x_bf16", gx, s->M, s->D, (const float*)ga, w_u)) return rc;
+    if (int rc = dgrad(DgradXGldsTile{}, DgradXTileB{}, "k_dgrad_x_bf16", gx, s->M, s->D, (const float*)ga, w_u, ga_parts))
+      return rc;
   {  // gW_h, gb_h, gw_u, gb_u
     using TL = WgradTileB;
     const bool vec = (s->Hd % 8 == 0) && (s->M % 8 == 0) && (s->D % 8 == 0) && al16(m) && al16(x);
