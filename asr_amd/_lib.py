@@ -18,7 +18,7 @@ BF16 = 1
 CONV_AUTO = 0
 CONV_TOEPLITZ = 1
 CONV_FFT = 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class Shape(ctypes.Structure):
@@ -93,7 +93,7 @@ def _load():
     lib.lmufft_wprep_bf16.restype = ci
     lib.lmufft_wprep_bf16.argtypes = [sp, vp, vp, vp]
     lib.lmufft_forward_bf16.restype = ci
-    lib.lmufft_forward_bf16.argtypes = [sp] + [vp] * 10 + [ci, vp, sz, vp]
+    lib.lmufft_forward_bf16.argtypes = [sp] + [vp] * 11 + [ci, vp, sz, vp]
     lib.lmufft_backward_bf16.restype = ci
     lib.lmufft_backward_bf16.argtypes = [sp] + [vp] * 15 + [ci, vp, sz, vp]
     lib.lmufft_profile_enable.restype = ci

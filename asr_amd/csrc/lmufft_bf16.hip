@@ -53,21 +53,31 @@ __device__ __forceinline__ int stamp_block() {
 // operand preparation
 // ---------------------------------------------------------------------------
 // Wb[n][k] (ld = ldW, zero padded) and WbT[j][n] (ld = ldWT, zero padded) from fp32 W[Hd][MD]
-__global__ __launch_bounds__(kThreads) void k_prep_weights(const float* __restrict__ W, bf16_t* __restrict__ Wb,
-                                                           bf16_t* __restrict__ WbT, int Hd, int MD, int ldW,
-                                                           int ldWT) {
+struct WeightPrep {
+  const float* W;  // NULL: nothing to prepare
+  bf16_t *Wb, *WbT;
+  int Hd, MD, ldW, ldWT;
+};
+__device__ __forceinline__ void prep_weights_blocks(const WeightPrep& q, int block, int nblocks) {
+  const float* __restrict__ W = q.W;
+  bf16_t* __restrict__ Wb = q.Wb;
+  bf16_t* __restrict__ WbT = q.WbT;
+  const int Hd = q.Hd, MD = q.MD, ldW = q.ldW, ldWT = q.ldWT;
   const long n1 = Wb ? (long)Hd * ldW : 0;
   const long n2 = WbT ? (long)MD * ldWT : 0;
-  for (long i = blockIdx.x * (long)kThreads + threadIdx.x; i < n1 + n2; i += (long)gridDim.x * kThreads) {
+  for (long i = block * (long)kThreads + threadIdx.x; i < n1 + n2; i += (long)nblocks * kThreads) {
     if (i < n1) {
       const int n = (int)(i / ldW), k = (int)(i % ldW);
       Wb[i] = (bf16_t)(k < MD ? W[(long)n * MD + k] : 0.f);
     } else {
-      const long q = i - n1;
-      const int j = (int)(q / ldWT), n = (int)(q % ldWT);
-      WbT[q] = (bf16_t)(n < Hd ? W[(long)n * MD + j] : 0.f);
+      const long r = i - n1;
+      const int j = (int)(r / ldWT), n = (int)(r % ldWT);
+      WbT[r] = (bf16_t)(n < Hd ? W[(long)n * MD + j] : 0.f);
     }
   }
+}
+__global__ __launch_bounds__(kThreads) void k_prep_weights(WeightPrep q) {
+  prep_weights_blocks(q, blockIdx.x, gridDim.x);
 }
 
 // Hb[k][tau] (ld = ldHb) and HbT[tau][k] (ld = ldHT, ldHb rows) from fp32 H[M][ldH]
@@ -94,10 +104,18 @@ template <bool VEC>
 __global__ __launch_bounds__(kThreads) void k_encode_fwd_bf16(const bf16_t* __restrict__ x,
                                                               const float* __restrict__ w_u,
                                                               const float* __restrict__ b_u,
-                                                              float* __restrict__ u, int rows, int D) {
+                                                              float* __restrict__ u, int rows, int D,
+                                                              WeightPrep prep, int prep_blocks) {
+  // the first prep_blocks workgroups convert W_h for the projection and the backward (independent
+  // work that would otherwise be a launch of its own); the others encode
+  if ((int)blockIdx.x < prep_blocks) {
+    prep_weights_blocks(prep, blockIdx.x, prep_blocks);
+    return;
+  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const float bias = b_u[0];
-  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+  const int eblock = blockIdx.x - prep_blocks, eblocks = gridDim.x - prep_blocks;
+  for (int row = eblock * 4 + wave; row < rows; row += eblocks * 4) {
     const bf16_t* xr = x + (long)row * D;
     float s = 0.f;
     if (VEC) {
@@ -1119,27 +1137,32 @@ size_t lmufft_wprep_bytes(const lmufft_shape* s) {
   return wprep_layout(*s).total;
 }
 
+static WeightPrep weight_prep(const lmufft_shape& s, const float* W_h, void* wprep, int* blocks) {
+  const WprepLayout l = wprep_layout(s);
+  const int MD = s.M + s.D;
+  const long n = (long)s.Hd * l.ldW + (long)MD * l.ldWT;
+  *blocks = min(cdivb(n, kThreads), 2048);
+  return WeightPrep{W_h, (bf16_t*)((char*)wprep + l.off_Wb), (bf16_t*)((char*)wprep + l.off_WbT), s.Hd, MD, l.ldW,
+                    l.ldWT};
+}
+
 int lmufft_wprep_bf16(const lmufft_shape* s, const float* W_h, void* wprep, void* stream) {
   if (int rc = check_shape_b(s)) return rc;
   if (!W_h || !wprep) return set_error("wprep: NULL pointer");
   if (!al16(wprep)) return set_error("wprep: buffer must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  const WprepLayout l = wprep_layout(*s);
-  const int MD = s->M + s->D;
-  bf16_t* Wb = (bf16_t*)((char*)wprep + l.off_Wb);
-  bf16_t* WbT = (bf16_t*)((char*)wprep + l.off_WbT);
-  const long n = (long)s->Hd * l.ldW + (long)MD * l.ldWT;
+  int blocks = 0;
+  const WeightPrep q = weight_prep(*s, W_h, wprep, &blocks);
   {
     PROFB("k_prep_weights");
-    hipLaunchKernelGGL(k_prep_weights, dim3(min(cdivb(n, kThreads), 2048)), dim3(kThreads), 0, st, W_h, Wb, WbT,
-                       s->Hd, MD, l.ldW, l.ldWT);
+    hipLaunchKernelGGL(k_prep_weights, dim3(blocks), dim3(kThreads), 0, st, q);
   }
   LAUNCH_CHECKB("k_prep_weights");
   return 0;
 }
 
 int lmufft_forward_bf16(const lmufft_shape* s, const void* x_, const float* w_u, const float* b_u,
-                        const void* wprep, const float* b_h, const void* hprep, float* u, void* m_, void* h_,
+                        void* wprep, const float* W_h, const float* b_h, const void* hprep, float* u, void* m_, void* h_,
                         void* h_n_, int conv_algo, void* workspace, size_t workspace_bytes, void* stream) {
   (void)workspace;
   (void)workspace_bytes;
@@ -1162,12 +1185,17 @@ int lmufft_forward_bf16(const lmufft_shape* s, const void* x_, const float* w_u,
   const bf16_t* Hb = (const bf16_t*)((const char*)hprep + hl.off_Hb);
   {
     const bool vec = (s->D % 8 == 0) && al16(x) && al16(w_u);
-    const dim3 grid(min(cdivb(rows, 4), 4096));
+    int prep_blocks = 0;
+    WeightPrep prep{nullptr, nullptr, nullptr, 0, 0, 0, 0};
+    if (W_h) prep = weight_prep(*s, W_h, wprep, &prep_blocks);
+    const dim3 grid(prep_blocks + min(cdivb(rows, 4), 4096));
     PROFB("k_encode_fwd_bf16");
     if (vec)
-      hipLaunchKernelGGL(k_encode_fwd_bf16<true>, grid, dim3(kThreads), 0, st, x, w_u, b_u, u, (int)rows, s->D);
+      hipLaunchKernelGGL(k_encode_fwd_bf16<true>, grid, dim3(kThreads), 0, st, x, w_u, b_u, u, (int)rows, s->D, prep,
+                         prep_blocks);
     else
-      hipLaunchKernelGGL(k_encode_fwd_bf16<false>, grid, dim3(kThreads), 0, st, x, w_u, b_u, u, (int)rows, s->D);
+      hipLaunchKernelGGL(k_encode_fwd_bf16<false>, grid, dim3(kThreads), 0, st, x, w_u, b_u, u, (int)rows, s->D, prep,
+                         prep_blocks);
   }
   LAUNCH_CHECKB("k_encode_fwd_bf16");
   {

@@ -157,12 +157,11 @@ class _LMUFFTFunction(torch.autograd.Function):
             else:
                 if hprep is None:
                     hprep = prepare_impulse_bf16(H)
-                # bf16 copies of W_h (both orientations), made once and reused by the backward
+                # bf16 copies of W_h (both orientations), made by the forward's first launch and reused
+                # by the backward
                 wprep = _workspace(_lib.lib.lmufft_wprep_bytes(ctypes.byref(shp)), dev)
-                _lib.check(_lib.lib.lmufft_wprep_bf16(ctypes.byref(shp), _ptr(W_h), _ptr(wprep), _stream(dev)),
-                           "lmufft_wprep_bf16")
                 rc = _lib.lib.lmufft_forward_bf16(
-                    ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(b_u), _ptr(wprep), _ptr(b_h), _ptr(hprep),
+                    ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(b_u), _ptr(wprep), _ptr(W_h), _ptr(b_h), _ptr(hprep),
                     _ptr(u), _ptr(m), _ptr(h), _ptr(h_n), conv_algo, _ptr(ws), ws.numel(), _stream(dev))
                 what = "lmufft_forward_bf16"
         _lib.check(rc, what)

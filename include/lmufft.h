@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMUFFT_ABI_VERSION 2
+#define LMUFFT_ABI_VERSION 3
 
 /* element types of the activations (x, h, gh, gx, m) */
 #define LMUFFT_F32 0
@@ -143,8 +143,11 @@ int lmufft_hprep_bf16(const lmufft_shape* s, const float* H, void* hprep, void* 
 size_t lmufft_wprep_bytes(const lmufft_shape* s);
 int lmufft_wprep_bf16(const lmufft_shape* s, const float* W_h, void* wprep, void* stream);
 
+/* W_h: NULL, or the fp32 weights [Hd][M+D] -- the call then rebuilds `wprep` from them itself,
+ * in the same launch as the encoder kernel (one launch fewer per step than a separate
+ * lmufft_wprep_bf16 call; `wprep` is written in that case). */
 int lmufft_forward_bf16(const lmufft_shape* s, const void* x, const float* w_u,
-                        const float* b_u, const void* wprep, const float* b_h,
+                        const float* b_u, void* wprep, const float* W_h, const float* b_h,
                         const void* hprep, float* u, void* m, void* h, void* h_n,
                         int conv_algo, void* workspace, size_t workspace_bytes,
                         void* stream);
