@@ -31,7 +31,8 @@ static inline size_t align256b(size_t v) { return (v + 255) & ~size_t(255); }
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 #ifdef LMUFFT_STAMPS
-// Debug build only (-DLMUFFT_STAMPS=<kernel id>: 1 weight gradient, 2 forward convolution):
+// Debug build only (-DLMUFFT_STAMPS=<kernel id>: 1 weight gradient, 2 forward convolution,
+// 3 adjoint convolution):
 // per-workgroup timestamps (100 MHz wall clock in slots 0..3, shader-clock sums in slots 4..7),
 // read back through lmufft_debug_stamps().
 __device__ long long g_stamps[8 * 4096];
@@ -622,6 +623,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_bwd2_bf16(const bf16_t* __res
   float* red = reinterpret_cast<float*>(smem_raw + (size_t)(Lp + kCb2St - 1) * LDW * sizeof(bf16_t));  // [4][32][64]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
   const bf16_t* zero = reinterpret_cast<const bf16_t*>(kZeroBytes);
+  LMUFFT_STAMP(3, 0);
 
   const int tau_lo = ta - s0 - (kCb2St - 1);
   for (int idx = threadIdx.x; idx < nrows * (KP / 8); idx += kThreads) {
@@ -632,6 +634,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_bwd2_bf16(const bf16_t* __res
         *reinterpret_cast<const bf16x8*>(ok ? HbT + (long)tau * ldHT + c * 8 : zero);
   }
   __syncthreads();
+  LMUFFT_STAMP(3, 1);
 
   f32x16 acc[2];
 #pragma unroll
@@ -667,6 +670,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_bwd2_bf16(const bf16_t* __res
     }
   }
 
+  LMUFFT_STAMP(3, 2);
   // wave partials -> LDS -> ordered sum -> slab p
 #pragma unroll
   for (int tn = 0; tn < 2; ++tn)
@@ -684,6 +688,8 @@ __global__ __launch_bounds__(kThreads) void k_conv_bwd2_bf16(const bf16_t* __res
                     red[(3 * kCb2Bt + bl) * kCb2St + sl];
     if (b0 + bl < B && s0 + sl < T) slab[(long)(b0 + bl) * T + s0 + sl] = v;
   }
+  LMUFFT_STAMP(3, 3);
+  LMUFFT_STAMP_ADD(3, 4, s0 - g_stamps[stamp_block() * 8 + 4]);
 }
 
 // ---------------------------------------------------------------------------
