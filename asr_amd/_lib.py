@@ -18,7 +18,7 @@ BF16 = 1
 CONV_AUTO = 0
 CONV_TOEPLITZ = 1
 CONV_FFT = 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class Shape(ctypes.Structure):
@@ -94,6 +94,8 @@ def _load():
     lib.lmufft_wprep_bf16.argtypes = [sp, vp, vp, vp]
     lib.lmufft_forward_bf16.restype = ci
     lib.lmufft_forward_bf16.argtypes = [sp] + [vp] * 11 + [ci, vp, sz, vp]
+    lib.lmufft_forward_ln_bf16.restype = ci
+    lib.lmufft_forward_ln_bf16.argtypes = [sp] + [vp] * 13 + [ctypes.c_float, vp, ci, ci, vp, sz, vp]
     lib.lmufft_backward_bf16.restype = ci
     lib.lmufft_backward_bf16.argtypes = [sp] + [vp] * 15 + [ci, vp, sz, vp]
     lib.lmufft_profile_enable.restype = ci
@@ -139,6 +141,7 @@ EXPORTS = (
     "lmufft_wprep_bytes",
     "lmufft_wprep_bf16",
     "lmufft_forward_bf16",
+    "lmufft_forward_ln_bf16",
     "lmufft_backward_bf16",
     "lmufft_profile_enable",
     "lmufft_profile_reset",

@@ -297,12 +297,18 @@ __global__ __launch_bounds__(kThreads) void k_proj_fwd_bf16(const bf16_t* __rest
 // of [m;x] -- the operand that comes from HBM -- passes through a CU's load path
 // exactly once, and W_h (L2-resident) once per 128 rows.
 using ProjGldsTile = TileB<128, 384, 64, 2, 4>;
+struct LnEpilogue {  // y == NULL: none
+  const float *gamma, *beta;
+  float eps;
+  void* y;
+  int y_bf16;
+};
 constexpr int kProjStages = 2;
 
 __global__ __launch_bounds__(ProjGldsTile::THREADS) void k_proj_fwd_glds_bf16(
     const bf16_t* __restrict__ m, const bf16_t* __restrict__ x, const bf16_t* __restrict__ Wb,
     const float* __restrict__ bias, bf16_t* __restrict__ h, bf16_t* __restrict__ h_n, int rows, int T, int M, int D,
-    int Hd, int ldW) {
+    int Hd, int ldW, LnEpilogue ln) {
   using TL = ProjGldsTile;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int n0 = blockIdx.x * TL::BN;
@@ -351,6 +357,60 @@ __global__ __launch_bounds__(ProjGldsTile::THREADS) void k_proj_fwd_glds_bf16(
       const int col = n0 + c * 8;
       if (col < Hd)
         *reinterpret_cast<bf16x8*>(h_n + (rl / T) * Hd + col) = *reinterpret_cast<const bf16x8*>(&tile[ml * LDT + c * 8]);
+    }
+  }
+  // Layer norm of the rows of h that follows the layer in the encoder (src/models/lmu_encoder.py:274),
+  // taken from the bf16 tile still in LDS -- the same bf16-rounded h a separate layer-norm kernel
+  // would read back from HBM; the tile spans the whole row (the host checks Hd <= BN).  Four lanes
+  // share a row: fp32 mean, centred second moment, two shuffles each.
+  if (ln.y) {
+    const int rl = threadIdx.x >> 2, q = threadIdx.x & 3;
+    static_assert(TL::THREADS == 4 * TL::BM, "four lanes per tile row");
+    const long row = m0 + rl;
+    const int chunks = Hd / 8;
+    float s = 0.f;
+    for (int c = q; c < chunks; c += 4) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(&tile[rl * LDT + c * 8]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (float)v[j];
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    const float mean = s / (float)Hd;
+    float ss = 0.f;
+    for (int c = q; c < chunks; c += 4) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(&tile[rl * LDT + c * 8]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = (float)v[j] - mean;
+        ss += d * d;
+      }
+    }
+    ss += __shfl_xor(ss, 1);
+    ss += __shfl_xor(ss, 2);
+    const float rstd = rsqrtf(ss / (float)Hd + ln.eps);
+    if (row < rows) {
+      for (int c = q; c < chunks; c += 4) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(&tile[rl * LDT + c * 8]);
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(ln.gamma + c * 8);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(ln.gamma + c * 8 + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(ln.beta + c * 8);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(ln.beta + c * 8 + 4);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          o[j] = ((float)v[j] - mean) * rstd * (j < 4 ? g0[j] : g1[j - 4]) + (j < 4 ? b0[j] : b1[j - 4]);
+        if (ln.y_bf16) {
+          bf16x8 ob;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ob[j] = (bf16_t)o[j];
+          *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(ln.y) + row * Hd + c * 8) = ob;
+        } else {
+          float* yp = reinterpret_cast<float*>(ln.y) + row * Hd + c * 8;
+          *reinterpret_cast<f32x4*>(yp) = f32x4{o[0], o[1], o[2], o[3]};
+          *reinterpret_cast<f32x4*>(yp + 4) = f32x4{o[4], o[5], o[6], o[7]};
+        }
+      }
     }
   }
 }
@@ -1167,13 +1227,13 @@ int lmufft_wprep_bf16(const lmufft_shape* s, const float* W_h, void* wprep, void
   return 0;
 }
 
-int lmufft_forward_bf16(const lmufft_shape* s, const void* x_, const float* w_u, const float* b_u,
-                        void* wprep, const float* W_h, const float* b_h, const void* hprep, float* u, void* m_, void* h_,
-                        void* h_n_, int conv_algo, void* workspace, size_t workspace_bytes, void* stream) {
-  (void)workspace;
-  (void)workspace_bytes;
+}  // extern "C"
+
+static int forward_bf16_impl(const lmufft_shape* s, const void* x_, const float* w_u, const float* b_u, void* wprep,
+                             const float* W_h, const float* b_h, const void* hprep, float* u, void* m_, void* h_,
+                             void* h_n_, int conv_algo, void* stream, const LnEpilogue& ln) {
   if (int rc = check_shape_b(s)) return rc;
-  if (!x_ || !w_u || !b_u || !wprep || !b_h || !hprep || !u || !m_ || !h_ || !h_n_)
+  if (!x_ || !w_u || !b_u || !wprep || !b_h || !hprep || !u || !m_ || (!h_ && !ln.y) || !h_n_)
     return set_error("forward: NULL pointer");
   if (conv_algo != LMUFFT_CONV_AUTO && conv_algo != LMUFFT_CONV_TOEPLITZ)
     return set_error("conv algorithm %d is not available for bf16", conv_algo);
@@ -1224,7 +1284,11 @@ int lmufft_forward_bf16(const lmufft_shape* s, const void* x_, const float* w_u,
   {
     using TL = ProjTileB;
     const bool vec = (s->M % 8 == 0) && (s->D % 8 == 0) && (s->Hd % 8 == 0) && al16(m) && al16(x) && al16(h) &&
-                     al16(h_n);
+                     al16(h_n);  // (a NULL h counts as aligned)
+    if (ln.y && !(vec && s->Hd <= ProjGldsTile::BN && al16(ln.y) && al16(ln.gamma) && al16(ln.beta)))
+      return set_error("forward with layer norm: needs hidden_size <= %d, memory / input / hidden sizes that are "
+                       "multiples of 8 and 16-byte aligned tensors; use lmufft_add_layernorm after the layer",
+                       ProjGldsTile::BN);
     if (vec) {  // LDS-DMA staging
       using TG = ProjGldsTile;
       const dim3 grid(cdivb(s->Hd, TG::BN), cdivb(rows, TG::BM));
@@ -1236,7 +1300,7 @@ int lmufft_forward_bf16(const lmufft_shape* s, const void* x_, const float* w_u,
       {
         PROFB("k_proj_fwd_bf16");
         hipLaunchKernelGGL(k_proj_fwd_glds_bf16, grid, dim3(TG::THREADS), lds, st, m, x, Wb, b_h, h, h_n, (int)rows,
-                           s->T, s->M, s->D, s->Hd, ldW);
+                           s->T, s->M, s->D, s->Hd, ldW, ln);
       }
     } else {
       const dim3 grid(cdivb(s->Hd, TL::BN), cdivb(rows, TL::BM));
@@ -1248,6 +1312,30 @@ int lmufft_forward_bf16(const lmufft_shape* s, const void* x_, const float* w_u,
     LAUNCH_CHECKB("k_proj_fwd_bf16");
   }
   return 0;
+}
+
+extern "C" {
+
+int lmufft_forward_bf16(const lmufft_shape* s, const void* x, const float* w_u, const float* b_u, void* wprep,
+                        const float* W_h, const float* b_h, const void* hprep, float* u, void* m, void* h, void* h_n,
+                        int conv_algo, void* workspace, size_t workspace_bytes, void* stream) {
+  (void)workspace;
+  (void)workspace_bytes;
+  if (!h) return set_error("forward: NULL pointer");
+  return forward_bf16_impl(s, x, w_u, b_u, wprep, W_h, b_h, hprep, u, m, h, h_n, conv_algo, stream,
+                           LnEpilogue{nullptr, nullptr, 0.f, nullptr, 0});
+}
+
+int lmufft_forward_ln_bf16(const lmufft_shape* s, const void* x, const float* w_u, const float* b_u, void* wprep,
+                           const float* W_h, const float* b_h, const void* hprep, float* u, void* m, void* h,
+                           void* h_n, const float* gamma, const float* beta, float eps, void* y, int y_dtype,
+                           int conv_algo, void* workspace, size_t workspace_bytes, void* stream) {
+  (void)workspace;
+  (void)workspace_bytes;
+  if (!gamma || !beta || !y) return set_error("forward with layer norm: NULL pointer");
+  if (y_dtype != LMUFFT_F32 && y_dtype != LMUFFT_BF16) return set_error("forward with layer norm: unknown dtype");
+  return forward_bf16_impl(s, x, w_u, b_u, wprep, W_h, b_h, hprep, u, m, h, h_n, conv_algo, stream,
+                           LnEpilogue{gamma, beta, eps, y, y_dtype == LMUFFT_BF16});
 }
 
 int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u, const void* wprep,

@@ -232,6 +232,45 @@ def lmufft_layer(x, w_u, b_u, W_h, b_h, H, conv_algo="auto", hprep=None, fftprep
     return _LMUFFTFunction.apply(x, w_u, b_u, W_h, b_h, H, _ALGOS[conv_algo], hprep, fftprep, grad_sink)
 
 
+def lmufft_layer_norm_inference(x, w_u, b_u, W_h, b_h, H, ln_weight, ln_bias, eps=1e-5, out_dtype=torch.float32,
+                                hprep=None):
+    """(layer_norm(h), h_n) of the bf16 LMUFFT forward, the normalisation done in the projection
+    kernel's epilogue (no autograd; h itself is not written).  x bfloat16 [B, T, D]; needs
+    hidden_size <= 384 and memory / input / hidden sizes that are multiples of 8.
+    Reference: src/lmu.py:297-320 followed by src/models/lmu_encoder.py:274."""
+    _require_gpu(x, "x")
+    if x.dtype != torch.bfloat16 or x.dim() != 3:
+        raise RuntimeError("lmufft_layer_norm_inference: x must be a bfloat16 [batch, seq_len, input_size] tensor")
+    if out_dtype not in _DTYPES:
+        raise RuntimeError(f"lmufft_layer_norm_inference: output dtype {out_dtype} is not supported")
+    B, T, D = x.shape
+    M, ldH = H.shape
+    Hd = W_h.shape[0]
+    if w_u.shape != (1, D) or W_h.shape[1] != M + D or ln_weight.shape != (Hd,) or ln_bias.shape != (Hd,):
+        raise RuntimeError("lmufft_layer_norm_inference: parameter shapes do not match x")
+    if T > ldH:
+        raise RuntimeError(f"LMUFFT: sequence length {T} exceeds the layer's seq_len {ldH}")
+    dev = x.device
+    x = x.detach().contiguous()
+    f32 = lambda t: t.detach().contiguous().float()  # noqa: E731
+    w_u, b_u, W_h, b_h, H, g, b = f32(w_u), f32(b_u), f32(W_h), f32(b_h), f32(H), f32(ln_weight), f32(ln_bias)
+    if hprep is None:
+        hprep = prepare_impulse_bf16(H)
+    u = torch.empty((B, T), dtype=torch.float32, device=dev)
+    m = torch.empty((B, T, M), dtype=torch.bfloat16, device=dev)
+    h_n = torch.empty((B, Hd), dtype=torch.bfloat16, device=dev)
+    y = torch.empty((B, T, Hd), dtype=out_dtype, device=dev)
+    shp = _shape(B, T, D, M, Hd, ldH)
+    with torch.cuda.device(dev):
+        wprep = _workspace(_lib.lib.lmufft_wprep_bytes(ctypes.byref(shp)), dev)
+        rc = _lib.lib.lmufft_forward_ln_bf16(
+            ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(b_u), _ptr(wprep), _ptr(W_h), _ptr(b_h), _ptr(hprep), _ptr(u),
+            _ptr(m), None, _ptr(h_n), _ptr(g), _ptr(b), float(eps), _ptr(y), _DTYPES[out_dtype], _lib.CONV_AUTO, None, 0,
+            _stream(dev))
+    _lib.check(rc, "lmufft_forward_ln_bf16")
+    return y, h_n
+
+
 def _conv_fftprep(H, T, conv_algo, fftprep):
     if fftprep is None and conv_algo == "fft":
         fftprep = prepare_impulse_fft(H, T)

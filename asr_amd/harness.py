@@ -117,9 +117,14 @@ class LMUEncoder(nn.Module):
         for att, lmu, ln in zip(self.attention_layers, self.lmu_layers, self.layer_norms):
             if self.use_attention:
                 x = att(x, lengths, stream)
-            x, h_n = lmu(x)
+            if ln.elementwise_affine and ln.bias is not None and lmu.supports_fused_layer_norm(x):
+                # the layer norm rides on the projection kernel's epilogue: h never goes to HBM
+                x, h_n = lmu.forward_layer_norm(
+                    x, ln, stream or (torch.float32 if torch.is_autocast_enabled() else x.dtype))
+            else:
+                x, h_n = lmu(x)
+                x = _layer_norm(ln, x, None, stream)
             states.append(h_n)
-            x = _layer_norm(ln, x, None, stream)
         return self.output_projection(x), states
 
     def get_output_dim(self) -> int:

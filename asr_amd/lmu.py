@@ -139,6 +139,28 @@ class LMUFFT(nn.Module):
                             grad_sink=self.grad_sink)
 
 
+    # hidden sizes whose rows fit one projection tile: the layer norm can ride on the projection kernel
+    FUSED_LAYER_NORM_MAX_HIDDEN = 384
+
+    def supports_fused_layer_norm(self, x) -> bool:
+        """True when forward_layer_norm(x, ...) can run: inference on the bf16 path, shapes the
+        LDS-DMA projection kernel takes, the whole hidden row inside one tile."""
+        bf16 = x.dtype == torch.bfloat16 or (torch.is_autocast_enabled()
+                                             and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+        return (x.is_cuda and x.dim() == 3 and bf16 and not torch.is_grad_enabled()
+                and self.hidden_size <= self.FUSED_LAYER_NORM_MAX_HIDDEN and self.hidden_size % 8 == 0
+                and self.memory_size % 8 == 0 and x.shape[-1] % 8 == 0)
+
+    def forward_layer_norm(self, x, layer_norm: nn.LayerNorm, out_dtype=torch.float32):
+        """(layer_norm(h), h_n): the layer followed by the encoder's LayerNorm
+        (src/models/lmu_encoder.py:266-274) in one pass; see supports_fused_layer_norm."""
+        from .functional import lmufft_layer_norm_inference
+
+        return lmufft_layer_norm_inference(x.to(torch.bfloat16), self.W_u.weight, self.W_u.bias, self.W_h.weight,
+                                           self.W_h.bias, self.H, layer_norm.weight, layer_norm.bias, layer_norm.eps,
+                                           out_dtype, hprep=self._impulse_bf16())
+
+
 class LMU(nn.Module):
     """Name kept because the reference encoder imports it (src/models/lmu_encoder.py:9,15).
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMUFFT_ABI_VERSION 3
+#define LMUFFT_ABI_VERSION 4
 
 /* element types of the activations (x, h, gh, gx, m) */
 #define LMUFFT_F32 0
@@ -151,6 +151,19 @@ int lmufft_forward_bf16(const lmufft_shape* s, const void* x, const float* w_u,
                         const void* hprep, float* u, void* m, void* h, void* h_n,
                         int conv_algo, void* workspace, size_t workspace_bytes,
                         void* stream);
+
+/* The bf16 forward followed by the layer norm the encoder applies to the layer's output
+ * (`x = layer_norm(x)`, src/models/lmu_encoder.py:274; dropout is the identity in eval mode), with
+ * the normalisation done in the projection kernel's epilogue: y = LN(h) * gamma + beta (fp32
+ * statistics over the bf16 h, biased variance), y [B][T][Hd] f32 or bf16 (y_dtype).
+ * `h` may be NULL when only y and h_n are wanted (inference).  Needs Hd <= 384 and M, D, Hd
+ * multiples of 8; otherwise it fails and the caller runs lmufft_add_layernorm after the layer. */
+int lmufft_forward_ln_bf16(const lmufft_shape* s, const void* x, const float* w_u,
+                           const float* b_u, void* wprep, const float* W_h, const float* b_h,
+                           const void* hprep, float* u, void* m, void* h, void* h_n,
+                           const float* gamma, const float* beta, float eps, void* y,
+                           int y_dtype, int conv_algo, void* workspace,
+                           size_t workspace_bytes, void* stream);
 
 int lmufft_backward_bf16(const lmufft_shape* s, const void* x, const float* w_u,
                          const void* wprep, const void* hprep, const float* u,

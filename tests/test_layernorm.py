@@ -81,3 +81,40 @@ def test_kernel_in_place_and_errors():
         add_layer_norm(torch.zeros(3, 8), None, torch.ones(8), torch.zeros(8))
     assert add_layer_norm(torch.zeros(0, 8, device=dev), None, torch.ones(8, device=dev),
                           torch.zeros(8, device=dev)).shape == (0, 8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,D,M,Hd", [(3, 50, 80, 64, 128), (2, 400, 384, 192, 384), (5, 37, 24, 8, 40)])
+def test_layer_norm_in_projection_epilogue(B, T, D, M, Hd, out_dtype):
+    """LMUFFT layer + LayerNorm in one pass (lmufft_forward_ln_bf16) against the layer followed by the
+    oracle's layer norm of its bf16 output; h_n identical to the plain forward's."""
+    from asr_amd import LMUFFT
+
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(B * 100 + Hd)
+    layer = LMUFFT(D, Hd, M, T, 100.0).to(dev)
+    ln = torch.nn.LayerNorm(Hd).to(dev)
+    torch.nn.init.normal_(ln.weight, 1.0, 0.3)
+    torch.nn.init.normal_(ln.bias, 0.0, 0.3)
+    x = torch.randn(B, T, D, device=dev).bfloat16()
+    with torch.no_grad():
+        assert layer.supports_fused_layer_norm(x)
+        h, h_n = layer(x)
+        y, h_n2 = layer.forward_layer_norm(x, ln, out_dtype)
+    assert y.dtype == out_dtype and torch.equal(h_n, h_n2)
+    want = lo.add_layer_norm(h.float().cpu().numpy(), None, ln.weight.detach().cpu().numpy(),
+                             ln.bias.detach().cpu().numpy(), ln.eps)
+    got = y.float().cpu().numpy()
+    if out_dtype == torch.float32:
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-5)
+    else:
+        np.testing.assert_allclose(got, want, rtol=2e-2, atol=2e-2)
+    # shapes the epilogue cannot take are refused by the C ABI, and the module says so beforehand
+    wide = LMUFFT(D, 512, M, T, 100.0).to(dev)
+    with torch.no_grad():
+        assert not wide.supports_fused_layer_norm(x)
+        with pytest.raises(RuntimeError, match="lmufft_add_layernorm"):
+            wide.forward_layer_norm(x, torch.nn.LayerNorm(512).to(dev))
