@@ -109,6 +109,16 @@ def cpu_baseline(args, H, seconds):
         times.append(time.perf_counter() - t0)
     times.sort()
     med = times[len(times) // 2]
+    # one-thread figure on a bounded sample: three steps
+    torch.set_num_threads(1)
+    step()
+    one = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        step()
+        one.append(time.perf_counter() - t0)
+    one.sort()
+    torch.set_num_threads(threads)
     return {
         "value": args.batch * args.frames / med,
         "unit": "frames/s",
@@ -116,6 +126,7 @@ def cpu_baseline(args, H, seconds):
         "kind": "port",
         "sample": f"same workload (batch {args.batch} x {args.frames} frames x {args.layers} layers, fp32, "
                   f"torch.fft route + autograd), median of {len(times)} steps, {med * 1e3:.1f} ms/step",
+        "one_thread": {"value": args.batch * args.frames / one[1], "ms_per_step": one[1] * 1e3, "steps": 3},
     }
 
 
