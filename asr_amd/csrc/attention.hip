@@ -37,7 +37,7 @@ template <class T>
 __device__ __forceinline__ float attn_ld(const T* p) { return (float)*p; }
 
 template <int DK, class TIO>
-__global__ __launch_bounds__(kAttnThreads) void k_attention_fwd(const TIO* __restrict__ q, const TIO* __restrict__ k,
+__global__ __launch_bounds__(kAttnThreads, DK <= 64 ? 4 : 1) void k_attention_fwd(const TIO* __restrict__ q, const TIO* __restrict__ k,
                                                                 const TIO* __restrict__ v,
                                                                 const int* __restrict__ lengths,
                                                                 TIO* __restrict__ ctx, int T, int H, float scale) {
@@ -182,13 +182,16 @@ __global__ __launch_bounds__(kAttnThreads) void k_attention_fwd(const TIO* __res
 // statistics and accumulation; probabilities rounded to bf16 for the value contraction).
 // A probability register i of lane half hh is key 16*(i>>3) + 4*hh + (i&3) + 8*((i>>2)&1) of the
 // tile; the eight registers 8*half .. 8*half+7 of a lane form one B fragment as they stand, if the
-// A fragment V^T[d][.] lists the keys in that order -- so V is staged TRANSPOSED, its keys
-// permuted: position 16*half + 8*hh + j of a row holds that key, and a fragment is one ds_read_b128.
+// A fragment V^T[d][.] lists the keys in that order.  V is staged as it lies in HBM ([key][d], one
+// 16-byte LDS write per lane) and the fragment is gathered by two ds_read_b64_tr_b16, whose lanes
+// name the key rows they want (an earlier form scattered V^T into LDS with eight 2-byte writes per
+// lane between the two barriers of every round).
 // ---------------------------------------------------------------------------
 typedef __bf16 attn_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 attn_bf16x4 __attribute__((ext_vector_type(4)));
 
 template <int DK>
-__global__ __launch_bounds__(kAttnThreads) void k_attention_fwd_bf16(const attn_bf16* __restrict__ q,
+__global__ __launch_bounds__(kAttnThreads, DK <= 64 ? 4 : 1) void k_attention_fwd_bf16(const attn_bf16* __restrict__ q,
                                                                      const attn_bf16* __restrict__ k,
                                                                      const attn_bf16* __restrict__ v,
                                                                      const int* __restrict__ lengths,
@@ -199,11 +202,12 @@ __global__ __launch_bounds__(kAttnThreads) void k_attention_fwd_bf16(const attn_
   constexpr int NKT = 1;              // 32-key score tiles per round (2 was measured slower: 0.31 against 0.26 ms at
                                       // B=256, T=400 -- more registers and LDS per workgroup, fewer resident waves)
   constexpr int KEYS = 32 * NKT;
-  constexpr int VTP = KEYS + 8;       // V^T tile [d][key slot], 144-byte rows
+  constexpr int VP = DK <= 96 ? 96 : 160;  // V tile [key][d]; row pitch 192 or 320 bytes: the four key rows of a
+                                           // transposing read fall on distinct bank quarters
   constexpr int DT = DK / 32, NS = DK / 16;
   constexpr int OP = DK + 1;          // fp32 output strip pitch
   __shared__ __attribute__((aligned(16))) attn_bf16 Ks[KEYS * KP];
-  __shared__ __attribute__((aligned(16))) attn_bf16 Vt[DK * VTP];
+  __shared__ __attribute__((aligned(16))) attn_bf16 Vs[KEYS * VP];
   __shared__ float Os[4 * 8 * OP];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -227,6 +231,8 @@ __global__ __launch_bounds__(kAttnThreads) void k_attention_fwd_bf16(const attn_
   const float scale2 = scale * 1.4426950408889634f;
   constexpr float kMasked2 = -1e9f * 1.4426950408889634f;  // the reference's mask value, base-2 domain
   const bool all_q_valid = __all(q_valid);
+  // transposing-read addressing: in each 16-lane group lane 4q+p names key row q, d columns 4p..4p+3
+  const int tq = (lane & 15) >> 2, tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
 
   constexpr int CH = DK / 8;                         // 16-byte chunks per key row
   constexpr int NV = (KEYS * CH + kAttnThreads - 1) / kAttnThreads;
@@ -250,11 +256,7 @@ __global__ __launch_bounds__(kAttnThreads) void k_attention_fwd_bf16(const attn_
       if (idx < KEYS * CH) {
         const int row = idx / CH, c = (idx % CH) * 8;
         *reinterpret_cast<attn_bf16x8*>(&Ks[row * KP + c]) = kst[n];
-        // key `row` -> slot of the permuted key order
-        const int k16 = row & 15, rem = k16 & 7;
-        const int slot = 16 * (row >> 4) + 8 * (rem >> 2) + (rem & 3) + 4 * (k16 >> 3);  // (row >> 4 runs over all 16-key groups)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) Vt[(c + e) * VTP + slot] = vst[n][e];
+        *reinterpret_cast<attn_bf16x8*>(&Vs[row * VP + c]) = vst[n];
       }
     }
   };
@@ -329,8 +331,18 @@ __global__ __launch_bounds__(kAttnThreads) void k_attention_fwd_bf16(const attn_
       for (int half = 0; half < 2; ++half)
 #pragma unroll
         for (int t = 0; t < DT; ++t) {
-          const attn_bf16x8 vf =
-              *reinterpret_cast<const attn_bf16x8*>(&Vt[(32 * t + r) * VTP + 32 * kt + 16 * half + 8 * hh]);
+          // A fragment V^T[d = 32 t + r][.] in the key order of the probability registers: slots 0..3 are
+          // keys 16 half + 4 hh + (0..3), slots 4..7 the same keys + 8 -- two transposing reads
+          const int key0 = 32 * kt + 16 * half + 4 * hh + tq;
+          typedef attn_bf16x4 __attribute__((address_space(3))) * lds4;
+          const attn_bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)&Vs[key0 * VP + 32 * t + tcol]);
+          const attn_bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)&Vs[(key0 + 8) * VP + 32 * t + tcol]);
+          attn_bf16x8 vf;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            vf[j] = lo[j];
+            vf[4 + j] = hi[j];
+          }
           o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][half], o[t], 0, 0, 0);
         }
   }
