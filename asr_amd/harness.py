@@ -26,6 +26,27 @@ from .ctc import CTCDecoder
 from .lmu import LMUFFT
 
 
+_BF16_WEIGHTS: dict = {}
+
+
+def _linear(layer: nn.Linear, x: torch.Tensor) -> torch.Tensor:
+    """layer(x).  For inference under bf16 autocast the bf16 copies of weight and bias are kept
+    (keyed on the parameters' version counters) instead of being re-cast by autocast at every
+    call; three input projections share one cast of x when x is already bf16."""
+    if (x.is_cuda and not torch.is_grad_enabled() and torch.is_autocast_enabled()
+            and torch.get_autocast_dtype("cuda") == torch.bfloat16 and layer.weight.dtype == torch.float32):
+        key = id(layer)
+        ver = (layer.weight._version, layer.weight.data_ptr(),
+               None if layer.bias is None else (layer.bias._version, layer.bias.data_ptr()))
+        hit = _BF16_WEIGHTS.get(key)
+        if hit is None or hit[0] != ver:
+            hit = (ver, layer.weight.detach().to(torch.bfloat16),
+                   None if layer.bias is None else layer.bias.detach().to(torch.bfloat16))
+            _BF16_WEIGHTS[key] = hit
+        return torch.nn.functional.linear(x.to(torch.bfloat16), hit[1], hit[2])
+    return layer(x)
+
+
 def _layer_norm(ln: nn.LayerNorm, x: torch.Tensor, residual: Optional[torch.Tensor] = None,
                 out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """ln(x + residual): the one-pass HIP kernel for inference on the GPU, torch otherwise."""
@@ -58,8 +79,11 @@ class _MultiHeadAttention(nn.Module):
         B, T, C = x.shape
         if x.is_cuda and self.d_k in SUPPORTED_HEAD_WIDTHS and not torch.is_grad_enabled():
             # HIP kernel: no [B, heads, T, T] score tensor, no per-utterance mask loop
-            ctx = masked_attention(self.w_q(x), self.w_k(x), self.w_v(x), self.num_heads, lengths)
-            return _layer_norm(self.layer_norm, self.w_o(ctx), x, out_dtype)
+            bf16_cast = torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+            xb = x.to(torch.bfloat16) if bf16_cast else x  # one cast for the three projections
+            ctx = masked_attention(_linear(self.w_q, xb), _linear(self.w_k, xb), _linear(self.w_v, xb), self.num_heads,
+                                   lengths)
+            return _layer_norm(self.layer_norm, _linear(self.w_o, ctx), x, out_dtype)
         split = lambda t: t.view(B, T, self.num_heads, self.d_k).transpose(1, 2)  # noqa: E731
         q, k, v = split(self.w_q(x)), split(self.w_k(x)), split(self.w_v(x))
         scores = q @ k.transpose(-2, -1) / math.sqrt(self.d_k)
@@ -112,7 +136,7 @@ class LMUEncoder(nn.Module):
     def forward(self, x: torch.Tensor, lengths: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, list]:
         stream = torch.bfloat16 if (self.bf16_stream and x.is_cuda and torch.is_autocast_enabled()
                                     and torch.get_autocast_dtype("cuda") == torch.bfloat16) else None
-        x = self.input_projection(x)
+        x = _linear(self.input_projection, x)
         states = []
         for att, lmu, ln in zip(self.attention_layers, self.lmu_layers, self.layer_norms):
             if self.use_attention:
@@ -125,7 +149,7 @@ class LMUEncoder(nn.Module):
                 x, h_n = lmu(x)
                 x = _layer_norm(ln, x, None, stream)
             states.append(h_n)
-        return self.output_projection(x), states
+        return _linear(self.output_projection, x), states
 
     def get_output_dim(self) -> int:
         return self.hidden_size
