@@ -593,7 +593,7 @@ __global__ __launch_bounds__(TL::THREADS) void k_dgrad_glds_bf16(const bf16_t* _
                       [&](int tm, int tn, int i, int, int, float v) { return v + grow[tm][i] * wcol[tn]; });
 }
 
-using DgradMTileB = TileB<128, 192, 64, 2, 2>;   // memory columns (M = 192): one column tile
+using DgradMTileB = TileB<64, 192, 64, 2, 2>;    // memory columns (M = 192): one column tile
 using DgradXTileB = TileB<128, 128, 64, 2, 2>;   // register-staged fallback for the input columns
 using DgradXGldsTile = TileB<128, 384, 64, 2, 4>;  // input columns, LDS-DMA form, eight waves
 
