@@ -78,6 +78,8 @@ def _load():
     lib.lmufft_ctc_greedy.argtypes = [vp, ci, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]
     lib.lmufft_attention_fwd.restype = ci
     lib.lmufft_attention_fwd.argtypes = [vp, vp, vp, ci, vp, i32, i32, i32, i32, vp, vp]
+    lib.lmufft_attention_fwd_ld.restype = ci
+    lib.lmufft_attention_fwd_ld.argtypes = [vp, vp, vp, ci, ctypes.c_int64, vp, i32, i32, i32, i32, vp, vp]
     lib.lmufft_add_layernorm.restype = ci
     lib.lmufft_add_layernorm.argtypes = [vp, ci, vp, ci, vp, vp, ctypes.c_float, ctypes.c_int64, i32, vp, ci, vp]
     lib.lmufft_fftprep_bytes.restype = sz
@@ -133,6 +135,7 @@ EXPORTS = (
     "lmufft_mel_frames",
     "lmufft_mel_forward_f32",
     "lmufft_attention_fwd",
+    "lmufft_attention_fwd_ld",
     "lmufft_add_layernorm",
     "lmufft_ctc_workspace_bytes",
     "lmufft_ctc_greedy",

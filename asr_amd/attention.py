@@ -44,3 +44,32 @@ def masked_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_head
                                            ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream))
     _lib.check(rc, "lmufft_attention_fwd")
     return ctx
+
+
+def masked_attention_packed(qkv: torch.Tensor, num_heads: int, lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """masked_attention on the output [B, T, 3 * heads * d_k] of ONE projection whose weight is the
+    concatenation of w_q, w_k, w_v (rows in that order): q, k, v are read in place as column blocks."""
+    if not qkv.is_cuda:
+        raise RuntimeError(f"masked_attention_packed: `qkv` lives on {qkv.device}; the kernel runs only on a GPU "
+                           "(there is no CPU fallback)")
+    if qkv.dim() != 3 or qkv.shape[2] % (3 * num_heads):
+        raise RuntimeError(f"masked_attention_packed: expected [batch, frames, 3 * heads * d_k], got {tuple(qkv.shape)}")
+    if qkv.dtype not in _DTYPES:
+        raise RuntimeError(f"masked_attention_packed: dtype {qkv.dtype}; supported: float32, bfloat16")
+    B, T, C3 = qkv.shape
+    C = C3 // 3
+    dk = C // num_heads
+    qkv = qkv.detach().contiguous()
+    if lengths is not None:
+        lengths = lengths.to(device=qkv.device, dtype=torch.int32).contiguous()
+    ctx = torch.empty((B, T, C), dtype=qkv.dtype, device=qkv.device)
+    es = qkv.element_size()
+    base = qkv.data_ptr()
+    vp = ctypes.c_void_p
+    with torch.cuda.device(qkv.device):
+        rc = _lib.lib.lmufft_attention_fwd_ld(
+            vp(base), vp(base + C * es), vp(base + 2 * C * es), _DTYPES[qkv.dtype], C3,
+            None if lengths is None else vp(lengths.data_ptr()), B, T, num_heads, dk, vp(ctx.data_ptr()),
+            vp(torch.cuda.current_stream(qkv.device).cuda_stream))
+    _lib.check(rc, "lmufft_attention_fwd_ld")
+    return ctx

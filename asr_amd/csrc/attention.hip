@@ -40,7 +40,8 @@ template <int DK, class TIO>
 __global__ __launch_bounds__(kAttnThreads, DK <= 64 ? 4 : 1) void k_attention_fwd(const TIO* __restrict__ q, const TIO* __restrict__ k,
                                                                 const TIO* __restrict__ v,
                                                                 const int* __restrict__ lengths,
-                                                                TIO* __restrict__ ctx, int T, int H, float scale) {
+                                                                TIO* __restrict__ ctx, int T, int H, int ld,
+                                                                float scale) {
   static_assert(DK % 32 == 0 && DK <= 128, "head width: 32, 64, 96 or 128");
   constexpr int KP = DK + 1;   // K tile pitch: lane = key, banks (key + d) distinct
   constexpr int VP = DK + 8;   // V tile pitch: lane = d, the two lane halves 4 rows apart land 32 banks apart
@@ -52,14 +53,15 @@ __global__ __launch_bounds__(kAttnThreads, DK <= 64 ? 4 : 1) void k_attention_fw
   const int b = blockIdx.z, h = blockIdx.y;
   const int C = H * DK;
   const int len = lengths ? min(max(lengths[b], 0), T) : T;
-  const long base = (long)b * T * C + (long)h * DK;
+  const long base = (long)b * T * C + (long)h * DK;    // context rows are dense
+  const long ibase = (long)b * T * ld + (long)h * DK;  // q, k, v rows are ld elements apart
   const int qi = blockIdx.x * kAttnQBlock + wave * 32 + r;  // this lane's query
   const bool q_in = qi < T, q_valid = qi < len;
 
   // Q[qi][d] for d = s + hh*NS, pre-scaled by 1/sqrt(dk): the B operand of every score step
   float qreg[NS];
 #pragma unroll
-  for (int s = 0; s < NS; ++s) qreg[s] = q_in ? attn_ld(q + base + (long)qi * C + s + hh * NS) * scale : 0.f;
+  for (int s = 0; s < NS; ++s) qreg[s] = q_in ? attn_ld(q + ibase + (long)qi * ld + s + hh * NS) * scale : 0.f;
 
   attn_f16v o[DT];
 #pragma unroll
@@ -78,8 +80,8 @@ __global__ __launch_bounds__(kAttnThreads, DK <= 64 ? 4 : 1) void k_attention_fw
     for (int n = 0; n < NV; ++n) {
       const int idx = tid + n * kAttnThreads, row = idx / CH, c = (idx % CH) * 4;
       const int j = min(j0 + row, T - 1);  // rows past T are masked below; keep the address valid
-      const TIO* kp = k + base + (long)j * C + c;
-      const TIO* vp = v + base + (long)j * C + c;
+      const TIO* kp = k + ibase + (long)j * ld + c;
+      const TIO* vp = v + ibase + (long)j * ld + c;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         kst[n][e] = attn_ld(kp + e);
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(kAttnThreads, DK <= 64 ? 4 : 1) void k_attention_fw
                                                                      const attn_bf16* __restrict__ v,
                                                                      const int* __restrict__ lengths,
                                                                      attn_bf16* __restrict__ ctx, int T, int H,
-                                                                     float scale) {
+                                                                     int ld, float scale) {
   static_assert(DK % 32 == 0 && DK <= 128, "head width: 32, 64, 96 or 128");
   constexpr int KP = DK + 8;          // K tile [key][d], 16-byte padded rows: conflict-free b128 fragments
   constexpr int NKT = 1;              // 32-key score tiles per round (2 was measured slower: 0.31 against 0.26 ms at
@@ -213,14 +215,15 @@ __global__ __launch_bounds__(kAttnThreads, DK <= 64 ? 4 : 1) void k_attention_fw
   const int b = blockIdx.z, h = blockIdx.y;
   const int C = H * DK;
   const int len = lengths ? min(max(lengths[b], 0), T) : T;
-  const long base = (long)b * T * C + (long)h * DK;
+  const long base = (long)b * T * C + (long)h * DK;    // context rows are dense
+  const long ibase = (long)b * T * ld + (long)h * DK;  // q, k, v rows are ld elements apart
   const int qi = blockIdx.x * kAttnQBlock + wave * 32 + r;
   const bool q_valid = qi < len;
   const int qc = min(qi, T - 1);
 
   attn_bf16x8 qf[NS];  // B fragments of the score contraction: Q[query r][16s + 8hh .. +7]
 #pragma unroll
-  for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const attn_bf16x8*>(q + base + (long)qc * C + 16 * s + 8 * hh);
+  for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const attn_bf16x8*>(q + ibase + (long)qc * ld + 16 * s + 8 * hh);
 
   attn_f16v o[DT];
 #pragma unroll
@@ -244,8 +247,8 @@ __global__ __launch_bounds__(kAttnThreads, DK <= 64 ? 4 : 1) void k_attention_fw
       if (idx < KEYS * CH) {
         const int row = idx / CH, c = (idx % CH) * 8;
         const int j = min(j0 + row, T - 1);
-        kst[n] = *reinterpret_cast<const attn_bf16x8*>(k + base + (long)j * C + c);
-        vst[n] = *reinterpret_cast<const attn_bf16x8*>(v + base + (long)j * C + c);
+        kst[n] = *reinterpret_cast<const attn_bf16x8*>(k + ibase + (long)j * ld + c);
+        vst[n] = *reinterpret_cast<const attn_bf16x8*>(v + ibase + (long)j * ld + c);
       }
     }
   };
@@ -376,7 +379,14 @@ extern "C" {
 
 int lmufft_attention_fwd(const void* q, const void* k, const void* v, int dtype, const int32_t* lengths, int32_t B,
                          int32_t T, int32_t H, int32_t DK, void* ctx, void* stream) {
+  return lmufft_attention_fwd_ld(q, k, v, dtype, (int64_t)H * DK, lengths, B, T, H, DK, ctx, stream);
+}
+
+int lmufft_attention_fwd_ld(const void* q, const void* k, const void* v, int dtype, int64_t ld, const int32_t* lengths,
+                            int32_t B, int32_t T, int32_t H, int32_t DK, void* ctx, void* stream) {
   if (B <= 0 || T <= 0 || H <= 0) return set_error("attention: bad shape (B=%d T=%d H=%d)", B, T, H);
+  if (ld < (int64_t)H * DK || ld > 0x7fffffff) return set_error("attention: row stride %lld", (long long)ld);
+  if (dtype == LMUFFT_BF16 && ld % 8 != 0) return set_error("attention: bf16 row stride must be a multiple of 8");
   if (DK != 32 && DK != 64 && DK != 128) return set_error("attention: head width %d; supported: 32, 64, 128", DK);
   if (dtype != LMUFFT_F32 && dtype != LMUFFT_BF16) return set_error("attention: unknown dtype %d", dtype);
   if (!q || !k || !v || !ctx) return set_error("attention: NULL pointer");
@@ -389,7 +399,7 @@ int lmufft_attention_fwd(const void* q, const void* k, const void* v, int dtype,
   const float scale = 1.0f / sqrtf((float)DK);
 #define ATTN_LAUNCH(DKV, TY)                                                                                   \
   hipLaunchKernelGGL((k_attention_fwd<DKV, TY>), grid, dim3(kAttnThreads), 0, st, (const TY*)q, (const TY*)k,  \
-                     (const TY*)v, lengths, (TY*)ctx, T, H, scale)
+                     (const TY*)v, lengths, (TY*)ctx, T, H, (int)ld, scale)
   {
     ProfScope ps("k_attention_fwd", st);
     if (dtype == LMUFFT_F32) {
@@ -399,7 +409,7 @@ int lmufft_attention_fwd(const void* q, const void* k, const void* v, int dtype,
     } else {
 #define ATTN_LAUNCH_B(DKV)                                                                                       \
   hipLaunchKernelGGL((k_attention_fwd_bf16<DKV>), grid, dim3(kAttnThreads), 0, st, (const attn_bf16*)q,          \
-                     (const attn_bf16*)k, (const attn_bf16*)v, lengths, (attn_bf16*)ctx, T, H, scale)
+                     (const attn_bf16*)k, (const attn_bf16*)v, lengths, (attn_bf16*)ctx, T, H, (int)ld, scale)
       if (DK == 32) ATTN_LAUNCH_B(32);
       else if (DK == 64) ATTN_LAUNCH_B(64);
       else ATTN_LAUNCH_B(128);

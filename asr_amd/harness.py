@@ -20,7 +20,7 @@ from typing import List, Optional, Tuple
 import torch
 from torch import nn
 
-from .attention import SUPPORTED_HEAD_WIDTHS, masked_attention
+from .attention import SUPPORTED_HEAD_WIDTHS, masked_attention, masked_attention_packed
 from .layernorm import MAX_WIDTH as _LN_MAX_WIDTH, add_layer_norm
 from .ctc import CTCDecoder
 from .lmu import LMUFFT
@@ -45,6 +45,26 @@ def _linear(layer: nn.Linear, x: torch.Tensor) -> torch.Tensor:
             _BF16_WEIGHTS[key] = hit
         return torch.nn.functional.linear(x.to(torch.bfloat16), hit[1], hit[2])
     return layer(x)
+
+
+_QKV_WEIGHTS: dict = {}
+
+
+def _qkv_projection(wq: nn.Linear, wk: nn.Linear, wv: nn.Linear, x: torch.Tensor) -> torch.Tensor:
+    """[w_q(x) | w_k(x) | w_v(x)] as ONE GEMM over the concatenated weights (inference; the
+    concatenation, in bf16 under bf16 autocast, is cached on the parameters' version counters)."""
+    bf16 = torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+    dt = torch.bfloat16 if bf16 else x.dtype
+    layers = (wq, wk, wv)
+    ver = tuple((l.weight._version, l.weight.data_ptr(), l.bias._version, l.bias.data_ptr()) for l in layers) + (dt,)
+    key = id(wq)
+    hit = _QKV_WEIGHTS.get(key)
+    if hit is None or hit[0] != ver:
+        hit = (ver, torch.cat([l.weight.detach() for l in layers]).to(dt),
+               torch.cat([l.bias.detach() for l in layers]).to(dt))
+        _QKV_WEIGHTS[key] = hit
+    with torch.autocast("cuda", enabled=False):
+        return torch.nn.functional.linear(x.to(dt), hit[1], hit[2])
 
 
 def _layer_norm(ln: nn.LayerNorm, x: torch.Tensor, residual: Optional[torch.Tensor] = None,
@@ -79,10 +99,12 @@ class _MultiHeadAttention(nn.Module):
         B, T, C = x.shape
         if x.is_cuda and self.d_k in SUPPORTED_HEAD_WIDTHS and not torch.is_grad_enabled():
             # HIP kernel: no [B, heads, T, T] score tensor, no per-utterance mask loop
-            bf16_cast = torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
-            xb = x.to(torch.bfloat16) if bf16_cast else x  # one cast for the three projections
-            ctx = masked_attention(_linear(self.w_q, xb), _linear(self.w_k, xb), _linear(self.w_v, xb), self.num_heads,
-                                   lengths)
+            if all(l.bias is not None for l in (self.w_q, self.w_k, self.w_v)):
+                # one GEMM for the three projections; the kernel reads q, k, v as column blocks of its output
+                ctx = masked_attention_packed(_qkv_projection(self.w_q, self.w_k, self.w_v, x), self.num_heads, lengths)
+            else:
+                ctx = masked_attention(_linear(self.w_q, x), _linear(self.w_k, x), _linear(self.w_v, x),
+                                       self.num_heads, lengths)
             return _layer_norm(self.layer_norm, _linear(self.w_o, ctx), x, out_dtype)
         split = lambda t: t.view(B, T, self.num_heads, self.d_k).transpose(1, 2)  # noqa: E731
         q, k, v = split(self.w_q(x)), split(self.w_k(x)), split(self.w_v(x))

@@ -228,6 +228,13 @@ int lmufft_ctc_greedy(const void* enc, int dtype, const float* W, const float* b
 int lmufft_attention_fwd(const void* q, const void* k, const void* v, int dtype,
                          const int32_t* lengths, int32_t B, int32_t T, int32_t H,
                          int32_t DK, void* ctx, void* stream);
+/* The same with q, k, v rows `ld` elements apart (ld >= H*DK; ctx stays dense): the three tensors
+ * may be column blocks of ONE projection output [B][T][3*H*DK] (q = base, k = base + H*DK,
+ * v = base + 2*H*DK, ld = 3*H*DK), i.e. w_q, w_k, w_v of src/models/lmu_encoder.py:41-43,68-70
+ * applied as a single GEMM. */
+int lmufft_attention_fwd_ld(const void* q, const void* k, const void* v, int dtype, int64_t ld,
+                            const int32_t* lengths, int32_t B, int32_t T, int32_t H,
+                            int32_t DK, void* ctx, void* stream);
 
 /* ------------------------------------------------------------------------
  * Residual add + layer normalisation for inference, one pass over HBM.

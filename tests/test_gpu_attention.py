@@ -88,3 +88,22 @@ def test_attention_errors():
         masked_attention(x, x, x, 2)  # d_k = 24
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         masked_attention(x.cpu(), x.cpu(), x.cpu(), 1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_packed_qkv_matches_separate_tensors(dtype):
+    """q, k, v read in place from one [B, T, 3C] projection output (row stride 3C) give exactly the
+    context of three dense tensors."""
+    from asr_amd.attention import masked_attention, masked_attention_packed
+
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    B, T, H, dk = 3, 77, 6, 64
+    qkv = torch.randn(B, T, 3 * H * dk, device=dev).to(dtype)
+    lengths = torch.tensor([77, 40, 1], device=dev)
+    q, k, v = (t.contiguous() for t in qkv.split(H * dk, dim=-1))
+    assert torch.equal(masked_attention_packed(qkv, H, lengths), masked_attention(q, k, v, H, lengths))
+    with pytest.raises(RuntimeError, match="3 \\* heads"):
+        masked_attention_packed(qkv[..., :-1], H, lengths)
