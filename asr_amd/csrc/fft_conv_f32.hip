@@ -430,6 +430,241 @@ __global__ __launch_bounds__(64) void k_fft_gu(const float2* __restrict__ Sp, co
 }
 
 // ---------------------------------------------------------------------------
+// Long sequences (2T - 1 > 1024): uniformly partitioned convolution on the same one-wave
+// transforms.  N = kPartN points, L = N / 2 samples per block; the filter is cut into partitions
+// h_q = H[:, qL .. qL + L), the input into overlapping segments x_j = u[(j-1)L .. (j+1)L):
+//     m[jL .. jL + L) = last L samples of ifft( sum_{q <= j} fft(x_j-q) * fft(h_q) ) ,
+// and for the adjoint, with segments z_c = gm[cL .. cL + N) of a channel pair and the partitions
+// mirrored inside themselves, F_q = rev_L(h_2p,q) - i rev_L(h_2p+1,q):
+//     gu[jL .. jL + L) = Re ifft( sum_{c >= j} fft(z_c) * fft(F_c-j) )[L - 1 .. 2L - 1) .
+// The products are summed in the spectrum, so the number of inverse transforms stays one per
+// (batch item, channel pair, block); the spectra of u blocks, filter partitions and the partial
+// sums are L2-resident (a few MB).
+// ---------------------------------------------------------------------------
+constexpr int kPartN = 512;
+constexpr int kPartL = kPartN / 2;
+constexpr int kPartJB = 6;  // output blocks per adjoint workgroup (accumulators in registers)
+
+// spectra of the filter partitions: G[(adj * nb + q) * npairs + p][f]
+template <int N>
+__global__ __launch_bounds__(64) void k_fft_prep_part(const float* __restrict__ H, float2* __restrict__ G, int M, int T,
+                                                      int ldH, int npairs, int nb) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float2* tw = reinterpret_cast<float2*>(lds);
+  float2* buf = tw + N;
+  constexpr int L = N / 2;
+  const int p = blockIdx.x, adj = blockIdx.y, q = blockIdx.z;
+  fill_twiddles<N>(tw);
+  __syncthreads();
+  if (p == 0 && adj == 0 && q == 0)  // the twiddle table follows the spectra
+    for (int k = threadIdx.x; k < N; k += 64) G[(long)2 * nb * npairs * N + k] = tw[k];
+  const float* h0 = H + (long)(2 * p) * ldH;
+  const float* h1 = (2 * p + 1 < M) ? H + (long)(2 * p + 1) * ldH : nullptr;
+  float2* out = G + (((long)adj * nb + q) * npairs + p) * N;
+  const float scale = 1.0f / (float)N;
+  wave_fft<N, false>(
+      tw, buf,
+      [&](int i, int) {
+        const int tap = q * L + (adj ? L - 1 - i : i);
+        if (i >= L || tap >= T) return make_float2(0.f, 0.f);
+        const float a = h0[tap], b = h1 ? h1[tap] : 0.f;
+        return make_float2(a, adj ? -b : b);
+      },
+      [&](int i, float2 v, int) { out[i] = make_float2(v.x * scale, v.y * scale); });
+}
+
+// spectra of the overlapping input segments: U[b * nb + j][f] = fft(u[b][(j-1)L .. (j+1)L))
+template <int N>
+__global__ __launch_bounds__(64) void k_fft_u_part(const float* __restrict__ u, const float2* __restrict__ table,
+                                                   float2* __restrict__ U, int T, int nb) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float2* tw = reinterpret_cast<float2*>(lds);
+  float2* buf = tw + N;
+  constexpr int L = N / 2;
+  const int b = blockIdx.x, j = blockIdx.y;
+  load_twiddles<N>(tw, table);
+  __syncthreads();
+  const float* ub = u + (long)b * T;
+  float2* Ub = U + ((long)b * nb + j) * N;
+  const int s0 = (j - 1) * L;
+  wave_fft<N, false>(
+      tw, buf,
+      [&](int i, int) {
+        const int s = s0 + i;
+        const float v = ub[min(max(s, 0), T - 1)];
+        return make_float2((s >= 0 && s < T) ? v : 0.f, 0.f);
+      },
+      [&](int i, float2 v, int) { Ub[i] = v; });
+}
+
+// forward: m[b][jL .. jL + L)[k0 .. k0 + 31] for one batch item, block and 16 channel pairs
+template <int N>
+__global__ __launch_bounds__(kFftThreads) void k_conv_fwd_fft_part(const float2* __restrict__ U,
+                                                                   const float2* __restrict__ G,
+                                                                   const float2* __restrict__ table,
+                                                                   float* __restrict__ m, int T, int M, int npairs,
+                                                                   int nb) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  using Lds = FftLds<N>;
+  constexpr int L = N / 2;
+  float2* tw = reinterpret_cast<float2*>(lds + Lds::TW);
+  const int wave = threadIdx.x >> 6;
+  float2* buf = reinterpret_cast<float2*>(lds + Lds::WORK) + (size_t)wave * Lds::PADN;
+  float* tile = lds + Lds::TILE;
+  const int b = blockIdx.y, j = blockIdx.z, p0 = blockIdx.x * kFftPairs;
+  const float2* Ub = U + (long)b * nb * N;
+  const int rows = min(L, T - j * L);
+
+  load_twiddles<N>(tw, table);
+  __syncthreads();
+  for (int pl = wave; pl < kFftPairs; pl += kFftWaves) {
+    const int p = p0 + pl;
+    if (p >= npairs) break;
+    wave_fft<N, true>(
+        tw, buf,
+        [&](int i, int) {
+          float2 s = make_float2(0.f, 0.f);
+          for (int q = 0; q <= j; ++q) s = s + cmul(Ub[(long)(j - q) * N + i], G[((long)q * npairs + p) * N + i]);
+          return s;
+        },
+        [&](int i, float2 v, int) {
+          if (i >= L && i - L < rows) {
+            tile[(i - L) * kTileLd + 2 * pl] = v.x;
+            tile[(i - L) * kTileLd + 2 * pl + 1] = v.y;
+          }
+        });
+  }
+  __syncthreads();
+  const int k0 = 2 * p0;
+  float* mb = m + ((long)b * T + (long)j * L) * M;
+  for (int idx = threadIdx.x; idx < rows * kFftCols; idx += kFftThreads) {
+    const int t = idx / kFftCols, c = idx % kFftCols;
+    if (k0 + c < M) mb[(long)t * M + k0 + c] = tile[t * kTileLd + c];
+  }
+}
+
+// adjoint, first kernel: for one batch item, 32 channels and the output blocks j0 .. j0 + JB - 1,
+// Sp[((g * B + b) * nb + j)][f] = sum_{c >= j} sum_pairs fft(z_c)[f] * Gr_{c-j}[f]
+template <int N>
+__global__ __launch_bounds__(kFftThreads) void k_conv_bwd_fft_part(const float* __restrict__ gm,
+                                                                   const float2* __restrict__ Gr,
+                                                                   const float2* __restrict__ table,
+                                                                   float2* __restrict__ Sp, int B, int T, int M,
+                                                                   int npairs, int nb) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  using Lds = FftLds<N>;
+  constexpr int L = N / 2;
+  float2* tw = reinterpret_cast<float2*>(lds + Lds::TW);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float2* buf = reinterpret_cast<float2*>(lds + Lds::WORK) + (size_t)wave * Lds::PADN;
+  float* tile = lds + Lds::TILE;  // [N][kTileLd]: one segment of 32 channels
+  const int b = blockIdx.y, p0 = blockIdx.x * kFftPairs, k0 = 2 * p0;
+  const int j0 = blockIdx.z * kPartJB, j1 = min(nb, j0 + kPartJB);
+  const float* gmb = gm + (long)b * T * M;
+
+  constexpr int R3 = N / 256;
+  constexpr int RL = R3 == 1 ? 16 : R3;
+  constexpr int NSL = R3 == 1 ? 16 : 256;
+  constexpr int NBL = N / RL;
+  constexpr int PER = ((NBL + 63) / 64) * RL;
+  float2 acc[kPartJB][PER];
+#pragma unroll
+  for (int a = 0; a < kPartJB; ++a)
+#pragma unroll
+    for (int i = 0; i < PER; ++i) acc[a][i] = make_float2(0.f, 0.f);
+
+  load_twiddles<N>(tw, table);
+  for (int c = j0; c < nb; ++c) {
+    __syncthreads();  // the previous segment's transforms have read the tile
+    const int t0 = c * L;
+    for (int idx = threadIdx.x; idx < N * kFftCols; idx += kFftThreads) {
+      const int tl = idx / kFftCols, cc = idx % kFftCols;
+      const int tt = t0 + tl;
+      tile[tl * kTileLd + cc] = (tt < T && k0 + cc < M) ? gmb[(long)tt * M + k0 + cc] : 0.f;
+    }
+    __syncthreads();
+    for (int pl = wave; pl < kFftPairs; pl += kFftWaves) {
+      const int p = p0 + pl;
+      if (p >= npairs) break;
+      wave_fft<N, false>(
+          tw, buf,
+          [&](int i, int) {
+            const float* t2 = tile + i * kTileLd + 2 * pl;
+            return make_float2(t2[0], t2[1]);
+          },
+          [&](int i, float2 v, int slot) {
+#pragma unroll
+            for (int a = 0; a < kPartJB; ++a) {
+              const int j = j0 + a;
+              if (j < j1 && j <= c) acc[a][slot] = acc[a][slot] + cmul(v, Gr[((long)(c - j) * npairs + p) * N + i]);
+            }
+          });
+    }
+  }
+  // per output block: park the wave's sum in its buffer, add the waves in a fixed order -> Sp
+  const float2* w0 = reinterpret_cast<const float2*>(lds + Lds::WORK);
+#pragma unroll
+  for (int a = 0; a < kPartJB; ++a) {
+    const int j = j0 + a;
+    if (j >= j1) break;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < (NBL + 63) / 64; ++q) {
+      const int jj = lane + 64 * q;
+      if (NBL % 64 != 0 && jj >= NBL) break;
+      const int kk = jj & (NSL - 1);
+      const int jb = (jj / NSL) * (NSL * RL) + kk;
+#pragma unroll
+      for (int r = 0; r < RL; ++r) buf[fpad(jb + r * NSL)] = acc[a][q * RL + r];
+    }
+    __syncthreads();
+    float2* out = Sp + (((long)blockIdx.x * B + b) * nb + j) * N;
+    for (int i = threadIdx.x; i < N; i += kFftThreads) {
+      const int pi = fpad(i);
+      float2 s = w0[pi];
+#pragma unroll
+      for (int wv = 1; wv < kFftWaves; ++wv) s = s + w0[(size_t)wv * Lds::PADN + pi];
+      out[i] = s;
+    }
+  }
+}
+
+// adjoint, second kernel: gu[b][jL .. jL + L) = Re ifft(sum_groups Sp[g][b][j])[L - 1 .. 2L - 1), masked by u > 0
+template <int N>
+__global__ __launch_bounds__(64) void k_fft_gu_part(const float2* __restrict__ Sp, const float2* __restrict__ table,
+                                                    const float* __restrict__ u, float* __restrict__ gu, int B, int T,
+                                                    int groups, int nb) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float2* tw = reinterpret_cast<float2*>(lds);
+  float2* buf = tw + N;
+  float2* sum = buf + FftLds<N>::PADN;
+  constexpr int L = N / 2;
+  const int b = blockIdx.x, j = blockIdx.y, lane = threadIdx.x;
+  load_twiddles<N>(tw, table);
+  float2 s[N / 64];
+#pragma unroll
+  for (int q = 0; q < N / 64; ++q) s[q] = Sp[((long)b * nb + j) * N + lane + 64 * q];
+  for (int g = 1; g < groups; ++g) {
+    float2 t[N / 64];
+#pragma unroll
+    for (int q = 0; q < N / 64; ++q) t[q] = Sp[(((long)g * B + b) * nb + j) * N + lane + 64 * q];
+#pragma unroll
+    for (int q = 0; q < N / 64; ++q) s[q] = s[q] + t[q];
+  }
+#pragma unroll
+  for (int q = 0; q < N / 64; ++q) sum[fpad(lane + 64 * q)] = s[q];
+  __syncthreads();
+  const float* ub = u ? u + (long)b * T : nullptr;
+  float* out = gu + (long)b * T;
+  wave_fft<N, true>(
+      tw, buf, [&](int i, int) { return sum[fpad(i)]; },
+      [&](int i, float2 v, int) {
+        const int sidx = j * L + i - (L - 1);
+        if (i >= L - 1 && i < 2 * L - 1 && sidx < T) out[sidx] = (ub && !(ub[sidx] > 0.f)) ? 0.f : v.x;
+      });
+}
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 static inline int cdivf(long a, long b) { return (int)((a + b - 1) / b); }
@@ -437,13 +672,24 @@ static inline int cdivf(long a, long b) { return (int)((a + b - 1) / b); }
 int fft_length(int T) {
   for (int n = 256; n <= 1024; n <<= 1)
     if (n >= 2 * T - 1) return n;
-  return 0;  // not supported by the LDS-resident kernels
+  return 0;  // longer sequences take the partitioned kernels
 }
+
+// blocks of kPartL samples of a long sequence; 0 when T is outside the partitioned kernels' range
+static int part_blocks(int T) {
+  if (fft_length(T) || T <= 0) return 0;
+  const int nb = cdivf(T, kPartL);
+  return nb <= 64 ? nb : 0;
+}
+bool fft_route_available(int T) { return fft_length(T) != 0 || part_blocks(T) != 0; }
 
 size_t fftprep_bytes(int M, int T) {
   const int N = fft_length(T);
-  if (!N) return 0;
-  return sizeof(float2) * (2 * (size_t)((M + 1) / 2) + 1) * N;  // G | Gr | twiddle table
+  const size_t npairs = (size_t)((M + 1) / 2);
+  if (N) return sizeof(float2) * (2 * npairs + 1) * N;  // G | Gr | twiddle table
+  const int nb = part_blocks(T);
+  if (!nb) return 0;
+  return sizeof(float2) * (2 * (size_t)nb * npairs + 1) * kPartN;  // G[q][p] | Gr[q][p] | twiddle table
 }
 
 #define FFT_DISPATCH(N_, CALL)  \
@@ -468,10 +714,26 @@ static int reserve_lds(K kernel, size_t lds, const char* name) {
   return 0;
 }
 
+static int no_fft_route(int T) {
+  return set_error("the FFT convolution supports T <= %d (got %d)", 64 * kPartL, T);
+}
+
 int fft_prepare(const lmufft_shape& s, const float* H, void* prep, hipStream_t st) {
   const int N = fft_length(s.T);
-  if (!N) return set_error("the LDS-resident FFT convolution supports T <= 512 (got %d)", s.T);
   const int npairs = (s.M + 1) / 2;
+  if (!N) {
+    const int nb = part_blocks(s.T);
+    if (!nb) return no_fft_route(s.T);
+    const size_t lds = FftLds<kPartN>::bytes_single();
+    if (int rc = reserve_lds(k_fft_prep_part<kPartN>, lds, "k_fft_prep")) return rc;
+    {
+      ProfScope ps("k_fft_prep", st);
+      hipLaunchKernelGGL(k_fft_prep_part<kPartN>, dim3(npairs, 2, nb), dim3(64), lds, st, H, (float2*)prep, s.M, s.T,
+                         s.ldH, npairs, nb);
+    }
+    FFT_LAUNCH_CHECK("k_fft_prep");
+    return 0;
+  }
   const dim3 grid(npairs, 2);
   FFT_DISPATCH(N, {
     const size_t lds = FftLds<NN>::bytes_single();
@@ -488,15 +750,38 @@ int fft_conv_groups(int M) { return cdivf((M + 1) / 2, kFftPairs); }
 // scratch of the FFT route: spectra of u (forward) or per-group partial spectra (adjoint)
 size_t fft_conv_workspace_bytes(const lmufft_shape& s) {
   const int N = fft_length(s.T);
-  if (!N) return 0;
-  return sizeof(float2) * (size_t)std::max(1, fft_conv_groups(s.M)) * s.B * N;
+  if (N) return sizeof(float2) * (size_t)std::max(1, fft_conv_groups(s.M)) * s.B * N;
+  const int nb = part_blocks(s.T);
+  if (!nb) return 0;
+  return sizeof(float2) * (size_t)std::max(1, fft_conv_groups(s.M)) * s.B * nb * kPartN;
 }
 
 int fft_conv_forward(const lmufft_shape& s, const float* u, const void* prep, float* m, void* ws, hipStream_t st) {
   const int N = fft_length(s.T);
-  if (!N) return set_error("the LDS-resident FFT convolution supports T <= 512 (got %d)", s.T);
   const int npairs = (s.M + 1) / 2;
   float2* U = (float2*)ws;
+  if (!N) {
+    const int nb = part_blocks(s.T);
+    if (!nb) return no_fft_route(s.T);
+    constexpr int NN = kPartN;
+    const float2* table = (const float2*)prep + (size_t)2 * nb * npairs * NN;
+    const size_t lds1 = FftLds<NN>::bytes_single();
+    if (int rc = reserve_lds(k_fft_u_part<NN>, lds1, "k_fft_u")) return rc;
+    {
+      ProfScope ps("k_fft_u", st);
+      hipLaunchKernelGGL(k_fft_u_part<NN>, dim3(s.B, nb), dim3(64), lds1, st, u, table, U, s.T, nb);
+    }
+    FFT_LAUNCH_CHECK("k_fft_u");
+    const size_t lds = FftLds<NN>::bytes(kPartL);
+    if (int rc = reserve_lds(k_conv_fwd_fft_part<NN>, lds, "k_conv_fwd_fft")) return rc;
+    {
+      ProfScope ps("k_conv_fwd_fft", st);
+      hipLaunchKernelGGL(k_conv_fwd_fft_part<NN>, dim3(cdivf(npairs, kFftPairs), s.B, nb), dim3(kFftThreads), lds, st,
+                         (const float2*)U, (const float2*)prep, table, m, s.T, s.M, npairs, nb);
+    }
+    FFT_LAUNCH_CHECK("k_conv_fwd_fft");
+    return 0;
+  }
   const float2* table = (const float2*)prep + (size_t)2 * npairs * N;
   FFT_DISPATCH(N, {
     const size_t lds1 = FftLds<NN>::bytes_single();
@@ -519,11 +804,34 @@ int fft_conv_forward(const lmufft_shape& s, const float* u, const void* prep, fl
 int fft_conv_backward(const lmufft_shape& s, const float* gm, const void* prep, const float* u, float* gu, void* ws,
                       hipStream_t st) {
   const int N = fft_length(s.T);
-  if (!N) return set_error("the LDS-resident FFT convolution supports T <= 512 (got %d)", s.T);
   const int npairs = (s.M + 1) / 2;
   const int groups = fft_conv_groups(s.M);
-  const float2* Gr = (const float2*)prep + (size_t)npairs * N;
   float2* Sp = (float2*)ws;
+  if (!N) {
+    const int nb = part_blocks(s.T);
+    if (!nb) return no_fft_route(s.T);
+    constexpr int NN = kPartN;
+    const float2* Gr = (const float2*)prep + (size_t)nb * npairs * NN;
+    const float2* table = (const float2*)prep + (size_t)2 * nb * npairs * NN;
+    const size_t lds = FftLds<NN>::bytes(NN);
+    if (int rc = reserve_lds(k_conv_bwd_fft_part<NN>, lds, "k_conv_bwd_fft")) return rc;
+    {
+      ProfScope ps("k_conv_bwd_fft", st);
+      hipLaunchKernelGGL(k_conv_bwd_fft_part<NN>, dim3(groups, s.B, cdivf(nb, kPartJB)), dim3(kFftThreads), lds, st, gm,
+                         Gr, table, Sp, s.B, s.T, s.M, npairs, nb);
+    }
+    FFT_LAUNCH_CHECK("k_conv_bwd_fft");
+    const size_t lds1 = FftLds<NN>::bytes_single();
+    if (int rc = reserve_lds(k_fft_gu_part<NN>, lds1, "k_fft_gu")) return rc;
+    {
+      ProfScope ps("k_fft_gu", st);
+      hipLaunchKernelGGL(k_fft_gu_part<NN>, dim3(s.B, nb), dim3(64), lds1, st, (const float2*)Sp, table, u, gu, s.B,
+                         s.T, groups, nb);
+    }
+    FFT_LAUNCH_CHECK("k_fft_gu");
+    return 0;
+  }
+  const float2* Gr = (const float2*)prep + (size_t)npairs * N;
   const float2* table = (const float2*)prep + (size_t)2 * npairs * N;
   FFT_DISPATCH(N, {
     const size_t lds = FftLds<NN>::bytes(s.T);

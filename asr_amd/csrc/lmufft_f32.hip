@@ -707,14 +707,14 @@ int launch_sum_slabs_masked(const float* part, const float* u, float* out, long 
 static bool use_fft(const lmufft_shape& s, int conv_algo, const void* fftprep) {
   if (conv_algo == LMUFFT_CONV_TOEPLITZ) return false;
   if (conv_algo == LMUFFT_CONV_FFT) return true;
-  return fftprep != nullptr && fft_length(s.T) != 0;
+  return fftprep != nullptr && fft_route_available(s.T);
 }
 static int check_algo(const lmufft_shape& s, int conv_algo, const void* fftprep) {
   if (conv_algo != LMUFFT_CONV_AUTO && conv_algo != LMUFFT_CONV_TOEPLITZ && conv_algo != LMUFFT_CONV_FFT)
     return set_error("unknown convolution algorithm %d", conv_algo);
   if (conv_algo == LMUFFT_CONV_FFT) {
     if (!fftprep) return set_error("the FFT convolution needs the prepared spectra (lmufft_fftprep_f32)");
-    if (!fft_length(s.T)) return set_error("the LDS-resident FFT convolution supports T <= 512 (got %d)", s.T);
+    if (!fft_route_available(s.T)) return set_error("the FFT convolution does not support T = %d", s.T);
   }
   return 0;
 }

@@ -47,7 +47,8 @@ size_t forward_workspace_bf16(const lmufft_shape& s);
 size_t backward_workspace_bf16(const lmufft_shape& s);
 
 // FFT route of the causal convolution (defined in fft_conv_f32.hip)
-int fft_length(int T);                      // 0 when the LDS-resident kernels cannot take T
+int fft_length(int T);                      // 0 when one transform cannot hold the sequence (2T - 1 > 1024)
+bool fft_route_available(int T);            // one transform, or the partitioned kernels for long sequences
 size_t fftprep_bytes(int M, int T);
 int fft_prepare(const lmufft_shape& s, const float* H, void* prep, hipStream_t st);
 size_t fft_conv_workspace_bytes(const lmufft_shape& s);  // scratch of either direction

@@ -71,7 +71,7 @@ def prepare_impulse_fft(H: torch.Tensor, T: int) -> torch.Tensor:
     shp = _shape(1, T, 1, M, 1, ldH)
     nbytes = _lib.lib.lmufft_fftprep_bytes(ctypes.byref(shp))
     if nbytes == 0:
-        raise RuntimeError(f"LMUFFT: the FFT convolution kernels do not support seq_len {T} (limit 512)")
+        raise RuntimeError(f"LMUFFT: the FFT convolution kernels do not support seq_len {T} (limit 16384)")
     buf = _workspace(nbytes, H.device)
     with torch.cuda.device(H.device):
         rc = _lib.lib.lmufft_fftprep_f32(ctypes.byref(shp), _ptr(H), _ptr(buf), _stream(H.device))

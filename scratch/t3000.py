@@ -23,7 +23,8 @@ layer.zero_grad()
 hb, _ = layer(xb); (hb * gh.bfloat16()).sum().backward()
 print("bf16 h", rel(hb.detach().float().cpu().numpy(), ref["h"]), "gx", rel(xb.grad.float().cpu().numpy(), ref["gx"]),
       "gW_h", rel(layer.W_h.weight.grad.cpu().numpy(), ref["gW_h"]), flush=True)
-for dt in (torch.bfloat16, torch.float32):
+for dt, algo in ((torch.bfloat16, "auto"), (torch.float32, "toeplitz"), (torch.float32, "fft")):
+    layer.conv_algo = algo
     xx = torch.randn(32, T, D, device=dev).to(dt).requires_grad_(True)
     gg = torch.randn(32, T, Hd, device=dev).to(dt)
     for _ in range(2):
@@ -36,4 +37,4 @@ for dt in (torch.bfloat16, torch.float32):
     torch.cuda.synchronize()
     dtm = (time.perf_counter() - t0) / 3
     prof = _lib.profile_read(); _lib.profile_enable(False)
-    print(dt, f"{dtm*1e3:.2f} ms/step, {32*T/dtm/1e6:.1f} M frames/s", {k: round(v[0]/v[1]*1e3) for k, v in prof.items() if v[1]}, flush=True)
+    print(dt, algo, f"{dtm*1e3:.2f} ms/step, {32*T/dtm/1e6:.1f} M frames/s", {k: round(v[0]/v[1]*1e3) for k, v in prof.items() if v[1]}, flush=True)
