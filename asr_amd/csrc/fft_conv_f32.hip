@@ -431,7 +431,7 @@ __global__ __launch_bounds__(64) void k_fft_gu(const float2* __restrict__ Sp, co
 
 // ---------------------------------------------------------------------------
 // Long sequences (2T - 1 > 1024): uniformly partitioned convolution on the same one-wave
-// transforms.  N = kPartN points, L = N / 2 samples per block; the filter is cut into partitions
+// transforms.  N points, L = N / 2 samples per block; the filter is cut into partitions
 // h_q = H[:, qL .. qL + L), the input into overlapping segments x_j = u[(j-1)L .. (j+1)L):
 //     m[jL .. jL + L) = last L samples of ifft( sum_{q <= j} fft(x_j-q) * fft(h_q) ) ,
 // and for the adjoint, with segments z_c = gm[cL .. cL + N) of a channel pair and the partitions
@@ -441,26 +441,31 @@ __global__ __launch_bounds__(64) void k_fft_gu(const float2* __restrict__ Sp, co
 // (batch item, channel pair, block); the spectra of u blocks, filter partitions and the partial
 // sums are L2-resident (a few MB).
 // ---------------------------------------------------------------------------
-constexpr int kPartN = 512;
-constexpr int kPartL = kPartN / 2;
+// The forward takes 1024-point transforms (blocks of 512 samples: half as many partition products
+// as with 512 points, and the products' operands come from L2 for every batch item and channel
+// pair); the adjoint keeps 512 points, because a workgroup stages a whole N-frame segment of 32
+// channels in LDS.  The two directions therefore have their own partitions of the filter.
+constexpr int kPartNF = 1024;            // forward
+constexpr int kPartNA = 512;             // adjoint
 constexpr int kPartJB = 6;  // output blocks per adjoint workgroup (accumulators in registers)
 
-// spectra of the filter partitions: G[(adj * nb + q) * npairs + p][f]
+// spectra of the filter partitions of one direction: G[q * npairs + p][f]; `table` receives exp(-2 pi i k / N)
 template <int N>
-__global__ __launch_bounds__(64) void k_fft_prep_part(const float* __restrict__ H, float2* __restrict__ G, int M, int T,
-                                                      int ldH, int npairs, int nb) {
+__global__ __launch_bounds__(64) void k_fft_prep_part(const float* __restrict__ H, float2* __restrict__ G,
+                                                      float2* __restrict__ table, int M, int T, int ldH, int npairs,
+                                                      int adj) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float2* tw = reinterpret_cast<float2*>(lds);
   float2* buf = tw + N;
   constexpr int L = N / 2;
-  const int p = blockIdx.x, adj = blockIdx.y, q = blockIdx.z;
+  const int p = blockIdx.x, q = blockIdx.y;
   fill_twiddles<N>(tw);
   __syncthreads();
-  if (p == 0 && adj == 0 && q == 0)  // the twiddle table follows the spectra
-    for (int k = threadIdx.x; k < N; k += 64) G[(long)2 * nb * npairs * N + k] = tw[k];
+  if (p == 0 && q == 0)
+    for (int k = threadIdx.x; k < N; k += 64) table[k] = tw[k];
   const float* h0 = H + (long)(2 * p) * ldH;
   const float* h1 = (2 * p + 1 < M) ? H + (long)(2 * p + 1) * ldH : nullptr;
-  float2* out = G + (((long)adj * nb + q) * npairs + p) * N;
+  float2* out = G + ((long)q * npairs + p) * N;
   const float scale = 1.0f / (float)N;
   wave_fft<N, false>(
       tw, buf,
@@ -675,21 +680,31 @@ int fft_length(int T) {
   return 0;  // longer sequences take the partitioned kernels
 }
 
-// blocks of kPartL samples of a long sequence; 0 when T is outside the partitioned kernels' range
-static int part_blocks(int T) {
-  if (fft_length(T) || T <= 0) return 0;
-  const int nb = cdivf(T, kPartL);
-  return nb <= 64 ? nb : 0;
+// layout of the prepared buffer of a long sequence:
+//   G [nbF][npairs][kPartNF] | Gr [nbA][npairs][kPartNA] | twiddles of kPartNF | twiddles of kPartNA
+struct PartLayout {
+  int nbF, nbA;  // blocks of kPartNF / 2 and of kPartNA / 2 samples; 0: T is outside the range
+  size_t offGr, offTabF, offTabA, total;  // in float2
+};
+static PartLayout part_layout(int M, int T) {
+  PartLayout l{0, 0, 0, 0, 0, 0};
+  if (fft_length(T) || T <= 0 || T > 16384) return l;
+  const size_t npairs = (size_t)((M + 1) / 2);
+  l.nbF = cdivf(T, kPartNF / 2);
+  l.nbA = cdivf(T, kPartNA / 2);
+  l.offGr = (size_t)l.nbF * npairs * kPartNF;
+  l.offTabF = l.offGr + (size_t)l.nbA * npairs * kPartNA;
+  l.offTabA = l.offTabF + kPartNF;
+  l.total = l.offTabA + kPartNA;
+  return l;
 }
-bool fft_route_available(int T) { return fft_length(T) != 0 || part_blocks(T) != 0; }
+bool fft_route_available(int T) { return fft_length(T) != 0 || part_layout(2, T).nbF != 0; }
 
 size_t fftprep_bytes(int M, int T) {
   const int N = fft_length(T);
   const size_t npairs = (size_t)((M + 1) / 2);
   if (N) return sizeof(float2) * (2 * npairs + 1) * N;  // G | Gr | twiddle table
-  const int nb = part_blocks(T);
-  if (!nb) return 0;
-  return sizeof(float2) * (2 * (size_t)nb * npairs + 1) * kPartN;  // G[q][p] | Gr[q][p] | twiddle table
+  return sizeof(float2) * part_layout(M, T).total;
 }
 
 #define FFT_DISPATCH(N_, CALL)  \
@@ -714,22 +729,24 @@ static int reserve_lds(K kernel, size_t lds, const char* name) {
   return 0;
 }
 
-static int no_fft_route(int T) {
-  return set_error("the FFT convolution supports T <= %d (got %d)", 64 * kPartL, T);
-}
+static int no_fft_route(int T) { return set_error("the FFT convolution supports T <= 16384 (got %d)", T); }
 
 int fft_prepare(const lmufft_shape& s, const float* H, void* prep, hipStream_t st) {
   const int N = fft_length(s.T);
   const int npairs = (s.M + 1) / 2;
   if (!N) {
-    const int nb = part_blocks(s.T);
-    if (!nb) return no_fft_route(s.T);
-    const size_t lds = FftLds<kPartN>::bytes_single();
-    if (int rc = reserve_lds(k_fft_prep_part<kPartN>, lds, "k_fft_prep")) return rc;
+    const PartLayout l = part_layout(s.M, s.T);
+    if (!l.nbF) return no_fft_route(s.T);
+    float2* base = (float2*)prep;
+    const size_t ldsF = FftLds<kPartNF>::bytes_single(), ldsA = FftLds<kPartNA>::bytes_single();
+    if (int rc = reserve_lds(k_fft_prep_part<kPartNF>, ldsF, "k_fft_prep")) return rc;
+    if (int rc = reserve_lds(k_fft_prep_part<kPartNA>, ldsA, "k_fft_prep")) return rc;
     {
       ProfScope ps("k_fft_prep", st);
-      hipLaunchKernelGGL(k_fft_prep_part<kPartN>, dim3(npairs, 2, nb), dim3(64), lds, st, H, (float2*)prep, s.M, s.T,
-                         s.ldH, npairs, nb);
+      hipLaunchKernelGGL(k_fft_prep_part<kPartNF>, dim3(npairs, l.nbF), dim3(64), ldsF, st, H, base, base + l.offTabF,
+                         s.M, s.T, s.ldH, npairs, 0);
+      hipLaunchKernelGGL(k_fft_prep_part<kPartNA>, dim3(npairs, l.nbA), dim3(64), ldsA, st, H, base + l.offGr,
+                         base + l.offTabA, s.M, s.T, s.ldH, npairs, 1);
     }
     FFT_LAUNCH_CHECK("k_fft_prep");
     return 0;
@@ -751,9 +768,10 @@ int fft_conv_groups(int M) { return cdivf((M + 1) / 2, kFftPairs); }
 size_t fft_conv_workspace_bytes(const lmufft_shape& s) {
   const int N = fft_length(s.T);
   if (N) return sizeof(float2) * (size_t)std::max(1, fft_conv_groups(s.M)) * s.B * N;
-  const int nb = part_blocks(s.T);
-  if (!nb) return 0;
-  return sizeof(float2) * (size_t)std::max(1, fft_conv_groups(s.M)) * s.B * nb * kPartN;
+  const PartLayout l = part_layout(s.M, s.T);
+  if (!l.nbF) return 0;
+  return sizeof(float2) * std::max((size_t)s.B * l.nbF * kPartNF,  // forward: spectra of the u segments
+                                   (size_t)std::max(1, fft_conv_groups(s.M)) * s.B * l.nbA * kPartNA);
 }
 
 int fft_conv_forward(const lmufft_shape& s, const float* u, const void* prep, float* m, void* ws, hipStream_t st) {
@@ -761,10 +779,11 @@ int fft_conv_forward(const lmufft_shape& s, const float* u, const void* prep, fl
   const int npairs = (s.M + 1) / 2;
   float2* U = (float2*)ws;
   if (!N) {
-    const int nb = part_blocks(s.T);
-    if (!nb) return no_fft_route(s.T);
-    constexpr int NN = kPartN;
-    const float2* table = (const float2*)prep + (size_t)2 * nb * npairs * NN;
+    const PartLayout l = part_layout(s.M, s.T);
+    if (!l.nbF) return no_fft_route(s.T);
+    constexpr int NN = kPartNF;
+    const int nb = l.nbF;
+    const float2* table = (const float2*)prep + l.offTabF;
     const size_t lds1 = FftLds<NN>::bytes_single();
     if (int rc = reserve_lds(k_fft_u_part<NN>, lds1, "k_fft_u")) return rc;
     {
@@ -772,7 +791,7 @@ int fft_conv_forward(const lmufft_shape& s, const float* u, const void* prep, fl
       hipLaunchKernelGGL(k_fft_u_part<NN>, dim3(s.B, nb), dim3(64), lds1, st, u, table, U, s.T, nb);
     }
     FFT_LAUNCH_CHECK("k_fft_u");
-    const size_t lds = FftLds<NN>::bytes(kPartL);
+    const size_t lds = FftLds<NN>::bytes(NN / 2);
     if (int rc = reserve_lds(k_conv_fwd_fft_part<NN>, lds, "k_conv_fwd_fft")) return rc;
     {
       ProfScope ps("k_conv_fwd_fft", st);
@@ -808,11 +827,12 @@ int fft_conv_backward(const lmufft_shape& s, const float* gm, const void* prep, 
   const int groups = fft_conv_groups(s.M);
   float2* Sp = (float2*)ws;
   if (!N) {
-    const int nb = part_blocks(s.T);
-    if (!nb) return no_fft_route(s.T);
-    constexpr int NN = kPartN;
-    const float2* Gr = (const float2*)prep + (size_t)nb * npairs * NN;
-    const float2* table = (const float2*)prep + (size_t)2 * nb * npairs * NN;
+    const PartLayout l = part_layout(s.M, s.T);
+    if (!l.nbF) return no_fft_route(s.T);
+    constexpr int NN = kPartNA;
+    const int nb = l.nbA;
+    const float2* Gr = (const float2*)prep + l.offGr;
+    const float2* table = (const float2*)prep + l.offTabA;
     const size_t lds = FftLds<NN>::bytes(NN);
     if (int rc = reserve_lds(k_conv_bwd_fft_part<NN>, lds, "k_conv_bwd_fft")) return rc;
     {

@@ -60,8 +60,9 @@ def impulse_response(A: torch.Tensor, B: torch.Tensor, seq_len: int):
 def _AUTO_PREFERS_FFT(T, M):
     """Shape policy of conv_algo="auto" on the fp32 path, from kernel timings on MI355X
     (batch 64, 192 memory channels, forward + adjoint, all kernels of a route): T=100 Toeplitz
-    37 us / FFT 48 us, T=200 61 / 61, T=400 125 / 84, T=512 167 / 88.  The Toeplitz kernels' work
-    grows with T^2, the FFT's with the transform length (256 / 512 / 1024 points)."""
+    37 us / FFT 48 us, T=200 61 / 61, T=400 125 / 84, T=512 167 / 88; batch 32, T=3000 (partitioned
+    FFT) 1970 / 620.  The Toeplitz kernels' work grows with T^2, the FFT's with the transform length
+    (256 / 512 / 1024 points) and, beyond one transform, with the number of partition products."""
     return T >= 192
 
 
