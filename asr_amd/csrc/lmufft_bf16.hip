@@ -32,7 +32,7 @@ static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) 
 
 #ifdef LMUFFT_STAMPS
 // Debug build only (-DLMUFFT_STAMPS=<kernel id>: 1 weight gradient, 2 forward convolution,
-// 3 adjoint convolution):
+// 3 adjoint convolution, 4 projection):
 // per-workgroup timestamps (100 MHz wall clock in slots 0..3, shader-clock sums in slots 4..7),
 // read back through lmufft_debug_stamps().
 __device__ long long g_stamps[8 * 4096];
@@ -341,13 +341,16 @@ __global__ __launch_bounds__(ProjGldsTile::THREADS) void k_proj_fwd_glds_bf16(
   WavePos<TL> w;
   f32x16 acc[TL::TM][TL::TN];
   tileb_zero<TL>(acc);
+  LMUFFT_STAMP(4, 0);
   gemm_loop_glds<TL>(oa, ob, acc, 0, K, w);
+  LMUFFT_STAMP(4, 1);
 
   float bcol[TL::TN];
   preload_cols<TL>(bcol, w, [&](int nn) { return n0 + nn < Hd ? bias[n0 + nn] : 0.f; });
   bf16_t* tile = reinterpret_cast<bf16_t*>(smem_raw);
   store_tile_bf16<TL>(acc, w, tile, h, Hd, m0, n0, rows, Hd,
                       [&](int, int tn, int, int, int, float v) { return fmaxf(v + bcol[tn], 0.f); });
+  LMUFFT_STAMP(4, 2);
   // h_n: the last frame of every utterance that ends inside this row tile (tile still in LDS)
   const long tile_end = min((long)rows, m0 + TL::BM);
   constexpr int LDT = TL::BN + 8;
