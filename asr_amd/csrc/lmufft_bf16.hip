@@ -144,7 +144,7 @@ __global__ __launch_bounds__(kThreads) void k_encode_fwd_bf16(const bf16_t* __re
 // lane's eight consecutive tau are ONE aligned ds_read_b128 and the 16 lanes
 // that the LDS serves together hit 16 different 16-byte slots.
 // ---------------------------------------------------------------------------
-using ConvFwdTileB = TileB<64, 192, 64, 2, 2>;
+using ConvFwdTileB = TileB<128, 96, 64, 4, 1>;
 
 template <class TL>
 struct ToeplitzOperand {
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_fwd_bf16(const float* __restr
   // shifted copies are cut from there.
   const float* ub = u + (long)b * T;
   const int smax = t0 + TL::BM - 1;
-  const int nchunks = (kend_pad / 8 + 8) * 8;
+  const int nchunks = (kend_pad / 8 + TL::BM / 8) * 8;
   float* uf = reinterpret_cast<float*>(U8 + nchunks * 8);  // u[0 .. kend) of this batch item
   for (int s = threadIdx.x; s < kend; s += kThreads) uf[s] = ub[s];
   LMUFFT_STAMP(2, 0);
@@ -1271,8 +1271,9 @@ static int forward_bf16_impl(const lmufft_shape* s, const void* x_, const float*
     using TL = ConvFwdTileB;
     const dim3 grid(cdivb(s->M, TL::BN), s->B, cdivb(s->T, TL::BM));
     const int kpad = cdivb(s->T, TL::BK) * TL::BK;
-    const size_t lds = sizeof(bf16_t) * ((size_t)TL::BN * (TL::BK + 8) + (size_t)(kpad / 8 + 8) * 64) +
-                       sizeof(float) * (size_t)kpad;
+    const size_t lds = std::max(sizeof(bf16_t) * ((size_t)TL::BN * (TL::BK + 8) + (size_t)(kpad / 8 + TL::BM / 8) * 64) +
+                                    sizeof(float) * (size_t)kpad,
+                                sizeof(bf16_t) * (size_t)TL::BM * (TL::BN + 8));  // the epilogue's staging tile
     if (lds > 160 * 1024) return set_error("sequence too long for the Toeplitz forward kernel (T=%d)", s->T);
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void*)k_conv_fwd_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
