@@ -26,28 +26,21 @@ from .ctc import CTCDecoder
 from .lmu import LMUFFT
 
 
-_BF16_WEIGHTS: dict = {}
-
-
 def _linear(layer: nn.Linear, x: torch.Tensor) -> torch.Tensor:
     """layer(x).  For inference under bf16 autocast the bf16 copies of weight and bias are kept
     (keyed on the parameters' version counters) instead of being re-cast by autocast at every
     call; three input projections share one cast of x when x is already bf16."""
     if (x.is_cuda and not torch.is_grad_enabled() and torch.is_autocast_enabled()
             and torch.get_autocast_dtype("cuda") == torch.bfloat16 and layer.weight.dtype == torch.float32):
-        key = id(layer)
         ver = (layer.weight._version, layer.weight.data_ptr(),
                None if layer.bias is None else (layer.bias._version, layer.bias.data_ptr()))
-        hit = _BF16_WEIGHTS.get(key)
+        hit = layer.__dict__.get("_bf16_copy")  # kept on the layer itself: it dies with it
         if hit is None or hit[0] != ver:
             hit = (ver, layer.weight.detach().to(torch.bfloat16),
                    None if layer.bias is None else layer.bias.detach().to(torch.bfloat16))
-            _BF16_WEIGHTS[key] = hit
+            layer.__dict__["_bf16_copy"] = hit
         return torch.nn.functional.linear(x.to(torch.bfloat16), hit[1], hit[2])
     return layer(x)
-
-
-_QKV_WEIGHTS: dict = {}
 
 
 def _qkv_projection(wq: nn.Linear, wk: nn.Linear, wv: nn.Linear, x: torch.Tensor) -> torch.Tensor:
@@ -57,12 +50,11 @@ def _qkv_projection(wq: nn.Linear, wk: nn.Linear, wv: nn.Linear, x: torch.Tensor
     dt = torch.bfloat16 if bf16 else x.dtype
     layers = (wq, wk, wv)
     ver = tuple((l.weight._version, l.weight.data_ptr(), l.bias._version, l.bias.data_ptr()) for l in layers) + (dt,)
-    key = id(wq)
-    hit = _QKV_WEIGHTS.get(key)
+    hit = wq.__dict__.get("_qkv_copy")  # kept on the first layer itself: it dies with it
     if hit is None or hit[0] != ver:
         hit = (ver, torch.cat([l.weight.detach() for l in layers]).to(dt),
                torch.cat([l.bias.detach() for l in layers]).to(dt))
-        _QKV_WEIGHTS[key] = hit
+        wq.__dict__["_qkv_copy"] = hit
     with torch.autocast("cuda", enabled=False):
         return torch.nn.functional.linear(x.to(dt), hit[1], hit[2])
 

@@ -85,3 +85,34 @@ def test_audio_to_tokens_pipeline():
             assert err <= 2e-2 * max(1.0, scale) * 4, (stream, err, scale)
             agree = float((lpb.argmax(-1) == lp32.argmax(-1))[valid].float().mean())
             assert agree > 0.9, (stream, agree)
+
+
+def test_cached_bf16_weights_follow_parameter_updates():
+    """The harness keeps bf16 copies of its projection weights for inference under autocast; an
+    in-place update of a parameter (an optimiser step, a checkpoint load) must invalidate them."""
+    from asr_amd.harness import LMUEncoder
+
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(4)
+    enc = LMUEncoder(80, 128, 64, 1, 100.0, seq_len=64, num_attention_heads=4).to(dev).eval()
+    x = torch.randn(2, 64, 80, device=dev)
+    lengths = torch.tensor([64, 30], device=dev)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        y0 = enc(x, lengths)[0].float()
+        assert float(y0.abs().max()) > 0
+        enc.output_projection.weight.zero_()
+        enc.output_projection.bias.fill_(0.25)
+        y1 = enc(x, lengths)[0].float()
+        assert torch.allclose(y1, torch.full_like(y1, 0.25))
+        for p in enc.attention_layers[0].attention.w_v.parameters():
+            p.zero_()  # values all zero -> the attention context is zero -> the block output is LN(w_o.bias + x)
+        y2 = enc(x, lengths)[0].float()
+        assert torch.allclose(y2, torch.full_like(y2, 0.25))
+        enc.output_projection.weight.copy_(torch.eye(128, device=dev))
+        enc.output_projection.bias.zero_()
+        a = enc(x, lengths)[0].float()
+        enc.attention_layers[0].attention.w_q.weight.mul_(3.0)  # context is zero whatever the scores are
+        b = enc(x, lengths)[0].float()
+        assert torch.equal(a, b)
