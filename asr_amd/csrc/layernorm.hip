@@ -148,6 +148,9 @@ extern "C" int lmufft_add_layernorm(const void* x, int x_dtype, const void* res,
   if (!aligned(x, x_dtype) || !aligned(out, out_dtype) || (res && !aligned(res, res_dtype)) ||
       !aligned(gamma, LMUFFT_F32) || !aligned(beta, LMUFFT_F32))
     return set_error("layernorm: rows must start on 16-byte (f32) / 8-byte (bf16) boundaries");
+  // in place is fine when the element sizes agree (a lane overwrites exactly what it has read)
+  if ((out == x && out_dtype != x_dtype) || (res && out == res && out_dtype != res_dtype))
+    return set_error("layernorm: out may alias x or res only with the same dtype");
   hipStream_t st = (hipStream_t)stream;
   const int ng = (C / 4 + 31) / 32;
   const long blocks = (rows + kLnThreads / 32 - 1) / (kLnThreads / 32);

@@ -246,7 +246,7 @@ int lmufft_attention_fwd_ld(const void* q, const void* k, const void* v, int dty
  *   biased variance, statistics and arithmetic in fp32 as torch.nn.LayerNorm.
  *   x, res, out: [rows][C] contiguous, each f32 or bf16 (x_dtype, res_dtype,
  *   out_dtype; res may be NULL); gamma, beta: f32 [C]; C % 4 == 0, C <= 1024;
- *   out may alias x or res.
+ *   out may alias x or res when their dtypes agree.
  * ---------------------------------------------------------------------- */
 int lmufft_add_layernorm(const void* x, int x_dtype, const void* res, int res_dtype,
                          const float* gamma, const float* beta, float eps, int64_t rows,
