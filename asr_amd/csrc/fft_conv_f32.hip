@@ -286,7 +286,7 @@ __global__ __launch_bounds__(kFftThreads) void k_conv_fwd_fft(const float2* __re
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using L = FftLds<N>;
   float2* tw = reinterpret_cast<float2*>(lds + L::TW);
-  const int wave = threadIdx.x >> 6;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float2* buf = reinterpret_cast<float2*>(lds + L::WORK) + (size_t)wave * L::PADN;
   float* tile = lds + L::TILE;
   const int b = blockIdx.y, p0 = blockIdx.x * kFftPairs;
@@ -299,8 +299,13 @@ __global__ __launch_bounds__(kFftThreads) void k_conv_fwd_fft(const float2* __re
     const int p = p0 + pl;
     if (p >= npairs) break;
     const float2* Gp = G + (long)p * N;
+    // the product spectrum, formed with coalesced loads and parked in the wave's buffer, which
+    // the transform then works on in place
+#pragma unroll
+    for (int k = 0; k < N / 64; ++k) buf[fpad(lane + 64 * k)] = cmul(Ub[lane + 64 * k], Gp[lane + 64 * k]);
+    wave_lds_fence();
     wave_fft<N, true>(
-        tw, buf, [&](int i, int) { return cmul(Ub[i], Gp[i]); },
+        tw, buf, [&](int i, int) { return buf[fpad(i)]; },
         [&](int i, float2 v, int) {
           if (i < T) {
             tile[i * kTileLd + 2 * pl] = v.x;
@@ -344,13 +349,10 @@ __global__ __launch_bounds__(kFftThreads) void k_conv_bwd_fft(const float* __res
   }
   __syncthreads();
 
-  // every lane accumulates the spectrum elements that the last stage hands it:
-  // the (index -> lane, slot) map of a stage is the same for every transform
-  constexpr int R3 = N / 256;
-  constexpr int RL = R3 == 1 ? 16 : R3;                   // radix of the last stage
-  constexpr int NSL = R3 == 1 ? 16 : 256;
-  constexpr int NBL = N / RL;
-  constexpr int PER = ((NBL + 63) / 64) * RL;             // outputs of the last stage per lane
+  // a lane accumulates the spectrum elements lane, lane + 64, ...: every transform parks its
+  // result in the wave's buffer and the product with the mirrored-filter spectrum is formed from
+  // there with coalesced loads
+  constexpr int PER = N / 64;
   float2 acc[PER];
 #pragma unroll
   for (int i = 0; i < PER; ++i) acc[i] = make_float2(0.f, 0.f);
@@ -366,18 +368,17 @@ __global__ __launch_bounds__(kFftThreads) void k_conv_bwd_fft(const float* __res
           const float re = t2[0], im = t2[1];
           return make_float2(i < T ? re : 0.f, i < T ? im : 0.f);
         },
-        [&](int i, float2 v, int slot) { acc[slot] = acc[slot] + cmul(v, Gp[i]); });
-  }
-  // replay the last stage's index sequence: slot -> spectrum index; park the wave's sum in its buffer
+        [&](int i, float2 v, int) { buf[fpad(i)] = v; });
+    wave_lds_fence();
+    float2 gq[PER];
 #pragma unroll
-  for (int q = 0; q < (NBL + 63) / 64; ++q) {
-    const int j = lane + 64 * q;
-    if (NBL % 64 != 0 && j >= NBL) break;
-    const int kk = j & (NSL - 1);
-    const int j0 = (j / NSL) * (NSL * RL) + kk;
+    for (int q = 0; q < PER; ++q) gq[q] = Gp[lane + 64 * q];
 #pragma unroll
-    for (int r = 0; r < RL; ++r) buf[fpad(j0 + r * NSL)] = acc[q * RL + r];
+    for (int q = 0; q < PER; ++q) acc[q] = acc[q] + cmul(buf[fpad(lane + 64 * q)], gq[q]);
+    wave_lds_fence();  // the buffer is the next transform's workspace
   }
+#pragma unroll
+  for (int q = 0; q < PER; ++q) buf[fpad(lane + 64 * q)] = acc[q];
   __syncthreads();
   // the waves' spectra summed in a fixed order -> Sp, coalesced
   const float2* w0 = reinterpret_cast<const float2*>(lds + L::WORK);
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(kFftThreads) void k_conv_fwd_fft_part(const float2*
   using Lds = FftLds<N>;
   constexpr int L = N / 2;
   float2* tw = reinterpret_cast<float2*>(lds + Lds::TW);
-  const int wave = threadIdx.x >> 6;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float2* buf = reinterpret_cast<float2*>(lds + Lds::WORK) + (size_t)wave * Lds::PADN;
   float* tile = lds + Lds::TILE;
   const int b = blockIdx.y, j = blockIdx.z, p0 = blockIdx.x * kFftPairs;
@@ -525,13 +526,29 @@ __global__ __launch_bounds__(kFftThreads) void k_conv_fwd_fft_part(const float2*
   for (int pl = wave; pl < kFftPairs; pl += kFftWaves) {
     const int p = p0 + pl;
     if (p >= npairs) break;
+    // sum of the partition products, formed with coalesced loads (a lane owns elements lane,
+    // lane + 64, ...) and parked in the wave's buffer, which the transform then works on in place
+    constexpr int PER = N / 64;
+    float2 s[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) s[k] = make_float2(0.f, 0.f);
+    for (int q = 0; q <= j; ++q) {
+      const float2* Uq = Ub + (long)(j - q) * N + lane;
+      const float2* Gq = G + ((long)q * npairs + p) * N + lane;
+      float2 uq[PER], gq[PER];
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        uq[k] = Uq[64 * k];
+        gq[k] = Gq[64 * k];
+      }
+#pragma unroll
+      for (int k = 0; k < PER; ++k) s[k] = s[k] + cmul(uq[k], gq[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) buf[fpad(lane + 64 * k)] = s[k];
+    wave_lds_fence();
     wave_fft<N, true>(
-        tw, buf,
-        [&](int i, int) {
-          float2 s = make_float2(0.f, 0.f);
-          for (int q = 0; q <= j; ++q) s = s + cmul(Ub[(long)(j - q) * N + i], G[((long)q * npairs + p) * N + i]);
-          return s;
-        },
+        tw, buf, [&](int i, int) { return buf[fpad(i)]; },
         [&](int i, float2 v, int) {
           if (i >= L && i - L < rows) {
             tile[(i - L) * kTileLd + 2 * pl] = v.x;
@@ -567,11 +584,11 @@ __global__ __launch_bounds__(kFftThreads) void k_conv_bwd_fft_part(const float* 
   const int j0 = blockIdx.z * kPartJB, j1 = min(nb, j0 + kPartJB);
   const float* gmb = gm + (long)b * T * M;
 
-  constexpr int R3 = N / 256;
-  constexpr int RL = R3 == 1 ? 16 : R3;
-  constexpr int NSL = R3 == 1 ? 16 : 256;
-  constexpr int NBL = N / RL;
-  constexpr int PER = ((NBL + 63) / 64) * RL;
+  // a lane accumulates the spectrum elements lane, lane + 64, ...: the transform parks its result
+  // in the wave's buffer and the products with the mirrored-filter spectra are formed from there,
+  // with coalesced loads that are all in flight together (inside the last stage's sink they
+  // were issued one by one, in that stage's strided order)
+  constexpr int PER = N / 64;
   float2 acc[kPartJB][PER];
 #pragma unroll
   for (int a = 0; a < kPartJB; ++a)
@@ -597,13 +614,24 @@ __global__ __launch_bounds__(kFftThreads) void k_conv_bwd_fft_part(const float* 
             const float* t2 = tile + i * kTileLd + 2 * pl;
             return make_float2(t2[0], t2[1]);
           },
-          [&](int i, float2 v, int slot) {
+          [&](int i, float2 v, int) { buf[fpad(i)] = v; });
+      wave_lds_fence();
+      float2 z[PER];
 #pragma unroll
-            for (int a = 0; a < kPartJB; ++a) {
-              const int j = j0 + a;
-              if (j < j1 && j <= c) acc[a][slot] = acc[a][slot] + cmul(v, Gr[((long)(c - j) * npairs + p) * N + i]);
-            }
-          });
+      for (int q = 0; q < PER; ++q) z[q] = buf[fpad(lane + 64 * q)];
+#pragma unroll
+      for (int a = 0; a < kPartJB; ++a) {
+        const int j = j0 + a;
+        if (j < j1 && j <= c) {  // (wave-uniform)
+          const float2* Gq = Gr + ((long)(c - j) * npairs + p) * N + lane;
+          float2 gq[PER];
+#pragma unroll
+          for (int q = 0; q < PER; ++q) gq[q] = Gq[64 * q];
+#pragma unroll
+          for (int q = 0; q < PER; ++q) acc[a][q] = acc[a][q] + cmul(z[q], gq[q]);
+        }
+      }
+      wave_lds_fence();  // the buffer is the next transform's workspace
     }
   }
   // per output block: park the wave's sum in its buffer, add the waves in a fixed order -> Sp
@@ -614,14 +642,7 @@ __global__ __launch_bounds__(kFftThreads) void k_conv_bwd_fft_part(const float* 
     if (j >= j1) break;
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < (NBL + 63) / 64; ++q) {
-      const int jj = lane + 64 * q;
-      if (NBL % 64 != 0 && jj >= NBL) break;
-      const int kk = jj & (NSL - 1);
-      const int jb = (jj / NSL) * (NSL * RL) + kk;
-#pragma unroll
-      for (int r = 0; r < RL; ++r) buf[fpad(jb + r * NSL)] = acc[a][q * RL + r];
-    }
+    for (int q = 0; q < PER; ++q) buf[fpad(lane + 64 * q)] = acc[a][q];
     __syncthreads();
     float2* out = Sp + (((long)blockIdx.x * B + b) * nb + j) * N;
     for (int i = threadIdx.x; i < N; i += kFftThreads) {
