@@ -18,7 +18,7 @@ BF16 = 1
 CONV_AUTO = 0
 CONV_TOEPLITZ = 1
 CONV_FFT = 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class Shape(ctypes.Structure):
@@ -80,6 +80,11 @@ def _load():
     lib.lmufft_attention_fwd.argtypes = [vp, vp, vp, ci, vp, i32, i32, i32, i32, vp, vp]
     lib.lmufft_attention_fwd_ld.restype = ci
     lib.lmufft_attention_fwd_ld.argtypes = [vp, vp, vp, ci, ctypes.c_int64, vp, i32, i32, i32, i32, vp, vp]
+    lib.lmufft_linear_bf16.restype = ci
+    lib.lmufft_linear_bf16.argtypes = [vp, vp, vp, ctypes.c_int64, i32, i32, vp, vp]
+    lib.lmufft_linear_ln_bf16.restype = ci
+    lib.lmufft_linear_ln_bf16.argtypes = [vp, vp, vp, ctypes.c_int64, i32, i32, vp, vp, ci, vp, vp, ctypes.c_float,
+                                          vp, ci, vp]
     lib.lmufft_add_layernorm.restype = ci
     lib.lmufft_add_layernorm.argtypes = [vp, ci, vp, ci, vp, vp, ctypes.c_float, ctypes.c_int64, i32, vp, ci, vp]
     lib.lmufft_fftprep_bytes.restype = sz
@@ -137,6 +142,8 @@ EXPORTS = (
     "lmufft_attention_fwd",
     "lmufft_attention_fwd_ld",
     "lmufft_add_layernorm",
+    "lmufft_linear_bf16",
+    "lmufft_linear_ln_bf16",
     "lmufft_ctc_workspace_bytes",
     "lmufft_ctc_greedy",
     "lmufft_hprep_bytes",

@@ -1,0 +1,224 @@
+// Linear layers of the encoder for bf16 inference on gfx950, with the residual add + layer norm
+// that follows the attention block's output projection folded into the GEMM's epilogue.
+//
+// Reference arithmetic: torch.nn.Linear under bf16 autocast -- bf16 operands, fp32 accumulation,
+//   bias added in fp32, one rounding to bf16 (src/models/lmu_encoder.py:40-43 w_q/w_k/w_v/w_o,
+//   :184 input_projection, :229 output_projection; calls at :68-70, :94, :244, :278), and
+//   `self.layer_norm(output + residual)` (src/models/lmu_encoder.py:97): the bf16 projection plus
+//   the residual in fp32, torch.nn.LayerNorm statistics in fp32, biased variance.
+//
+// k_linear_glds_bf16: out[rows][N] = x[rows][K] W[N][K]^T + bias.  Both operands are plain
+//   k-contiguous rows, so they are staged by LDS-DMA (gemm_glds_bf16.h) with no transposition.
+//   Tile 128 rows x 384 columns on eight waves: for N <= 384 every row of x passes through a CU's
+//   load path once and W (L2-resident, N*K*2 bytes) once per 128 rows; wider outputs (the fused
+//   q|k|v projection, N = 3 d_model) take ceil(N/384) column tiles whose workgroups are adjacent
+//   in launch order, so the x rows they share are served by L2.
+//   Layer-norm epilogue (N <= 384, one column tile): four lanes share a tile row, read the
+//   bf16-rounded projection back from the LDS tile, add the residual, and keep the 96 sums of
+//   their share of the row in registers across the mean / variance / scale passes -- the
+//   projection's output and the sum never go to HBM.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm_glds_bf16.h"
+#include "lmufft.h"
+#include "lmufft_internal.h"
+
+namespace lmufft {
+
+using LinearTile = TileB<128, 384, 64, 2, 4>;
+
+struct LinearLn {  // y == NULL: none
+  const void* res;  // [rows][N], may be NULL
+  int res_bf16;
+  const float *gamma, *beta;
+  float eps;
+  void* y;
+  int y_bf16;
+};
+
+__global__ __launch_bounds__(LinearTile::THREADS) void k_linear_glds_bf16(const bf16_t* __restrict__ x,
+                                                                          const bf16_t* __restrict__ W,
+                                                                          const float* __restrict__ bias,
+                                                                          bf16_t* __restrict__ out, long rows, int K,
+                                                                          int N, LinearLn ln) {
+  using TL = LinearTile;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int n0 = blockIdx.x * TL::BN;
+  const long m0 = (long)blockIdx.y * TL::BM;
+
+  typedef GldsOperand<TL::BM, TL::NW, false> OpA;
+  typedef GldsOperand<TL::BN, TL::NW, false> OpB;
+  OpA oa(
+      smem_raw,
+      [&](int r, const bf16_t*& q0, const bf16_t*&) {
+        const long row = m0 + r;
+        if (row >= rows) return false;
+        q0 = x + row * K;
+        return true;
+      },
+      K, K);
+  OpB ob(
+      smem_raw + 2 * OpA::STAGE_BYTES,
+      [&](int r, const bf16_t*& q0, const bf16_t*&) {
+        const int n = n0 + r;
+        if (n >= N) return false;
+        q0 = W + (long)n * K;
+        return true;
+      },
+      K, K);
+
+  WavePos<TL> w;
+  f32x16 acc[TL::TM][TL::TN];
+  tileb_zero<TL>(acc);
+  gemm_loop_glds<TL>(oa, ob, acc, 0, K, w);
+
+  float bcol[TL::TN];
+  preload_cols<TL>(bcol, w, [&](int nn) { return (bias && n0 + nn < N) ? bias[n0 + nn] : 0.f; });
+  bf16_t* tile = reinterpret_cast<bf16_t*>(smem_raw);
+  store_tile_bf16<TL>(acc, w, tile, out, N, m0, n0, rows, N,
+                      [&](int, int tn, int, int, int, float v) { return v + bcol[tn]; });
+
+  if (ln.y) {  // the tile spans the whole row (the host checks N <= BN)
+    static_assert(TL::THREADS == 4 * TL::BM, "four lanes per tile row");
+    constexpr int LDT = TL::BN + 8;
+    constexpr int PER = TL::BN / 8 / 4;  // 16-byte chunks per lane
+    const int rl = threadIdx.x >> 2, q = threadIdx.x & 3;
+    const long row = m0 + rl;
+    const bool live = row < rows;
+    const int chunks = N / 8;
+    float v[PER][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int c = q + 4 * i;
+      const bool on = c < chunks;
+      const bf16x8 t = *reinterpret_cast<const bf16x8*>(&tile[rl * LDT + c * 8]);
+      float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (ln.res && on && live) {
+        if (ln.res_bf16) {
+          const bf16x8 rb = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(ln.res) + row * N + c * 8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) r[j] = (float)rb[j];
+        } else {
+          const float* rp = reinterpret_cast<const float*>(ln.res) + row * N + c * 8;
+          const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp);
+          const f32x4 r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            r[j] = r0[j];
+            r[j + 4] = r1[j];
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[i][j] = on ? (float)t[j] + r[j] : 0.f;
+        s += v[i][j];
+      }
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    const float mean = s / (float)N;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const bool on = q + 4 * i < chunks;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = on ? v[i][j] - mean : 0.f;
+        ss += d * d;
+      }
+    }
+    ss += __shfl_xor(ss, 1);
+    ss += __shfl_xor(ss, 2);
+    const float rstd = rsqrtf(ss / (float)N + ln.eps);
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int c = q + 4 * i;
+        if (c < chunks) {
+          const f32x4 g0 = *reinterpret_cast<const f32x4*>(ln.gamma + c * 8);
+          const f32x4 g1 = *reinterpret_cast<const f32x4*>(ln.gamma + c * 8 + 4);
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(ln.beta + c * 8);
+          const f32x4 b1 = *reinterpret_cast<const f32x4*>(ln.beta + c * 8 + 4);
+          float o[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            o[j] = (v[i][j] - mean) * rstd * (j < 4 ? g0[j] : g1[j - 4]) + (j < 4 ? b0[j] : b1[j - 4]);
+          if (ln.y_bf16) {
+            bf16x8 ob8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ob8[j] = (bf16_t)o[j];
+            *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(ln.y) + row * N + c * 8) = ob8;
+          } else {
+            float* yp = reinterpret_cast<float*>(ln.y) + row * N + c * 8;
+            *reinterpret_cast<f32x4*>(yp) = f32x4{o[0], o[1], o[2], o[3]};
+            *reinterpret_cast<f32x4*>(yp + 4) = f32x4{o[4], o[5], o[6], o[7]};
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace lmufft
+
+using namespace lmufft;
+
+namespace {
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int linear_impl(const void* x, const void* W, const float* bias, int64_t rows, int32_t K, int32_t N, void* out,
+                const LinearLn& ln, void* stream) {
+  using TL = LinearTile;
+  if (rows < 0 || K <= 0 || N <= 0) return set_error("linear: bad shape (rows=%lld K=%d N=%d)", (long long)rows, K, N);
+  if (K % 8 != 0 || N % 8 != 0) return set_error("linear: K=%d and N=%d must be multiples of 8", K, N);
+  if (rows == 0) return 0;
+  if (!x || !W || (!out && !ln.y)) return set_error("linear: NULL pointer");
+  if (!al16(x) || !al16(W) || !al16(out) || (bias && (reinterpret_cast<uintptr_t>(bias) & 3)))
+    return set_error("linear: x, W and out must be 16-byte aligned");
+  if (ln.y) {
+    if (N > TL::BN) return set_error("linear: the layer-norm epilogue needs N <= %d (got %d)", TL::BN, N);
+    if (!ln.gamma || !ln.beta) return set_error("linear: NULL layer-norm parameters");
+    if (!al16(ln.y) || !al16(ln.res) || !al16(ln.gamma) || !al16(ln.beta))
+      return set_error("linear: y, res, gamma and beta must be 16-byte aligned");
+  }
+  const long row_tiles = (rows + TL::BM - 1) / TL::BM;
+  if (row_tiles > 65535) return set_error("linear: %lld rows exceed the launch grid", (long long)rows);
+  const dim3 grid((N + TL::BN - 1) / TL::BN, (unsigned)row_tiles);
+  const size_t lds = 2 * (size_t)(TL::BM + TL::BN) * kGldsRowBytes;
+  static_assert(2 * (TL::BM + TL::BN) * kGldsRowBytes >= TL::BM * (TL::BN + 8) * 2, "epilogue tile fits");
+  if (hipFuncSetAttribute((const void*)k_linear_glds_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+      hipSuccess)
+    return set_error("cannot reserve %zu bytes of LDS for k_linear_glds_bf16", lds);
+  hipStream_t st = (hipStream_t)stream;
+  {
+    ProfScope ps("k_linear_glds_bf16", st);
+    hipLaunchKernelGGL(k_linear_glds_bf16, grid, dim3(TL::THREADS), lds, st, (const bf16_t*)x, (const bf16_t*)W, bias,
+                       (bf16_t*)out, (long)rows, K, N, ln);
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error("k_linear_glds_bf16: %s", hipGetErrorString(e));
+  return 0;
+}
+}  // namespace
+
+extern "C" int lmufft_linear_bf16(const void* x, const void* W, const float* bias, int64_t rows, int32_t K, int32_t N,
+                                  void* out, void* stream) {
+  if (rows > 0 && !out) return set_error("linear: NULL pointer");
+  const LinearLn none{nullptr, 0, nullptr, nullptr, 0.f, nullptr, 0};
+  return linear_impl(x, W, bias, rows, K, N, out, none, stream);
+}
+
+extern "C" int lmufft_linear_ln_bf16(const void* x, const void* W, const float* bias, int64_t rows, int32_t K,
+                                     int32_t N, void* out, const void* res, int res_dtype, const float* gamma,
+                                     const float* beta, float eps, void* y, int y_dtype, void* stream) {
+  auto known = [](int d) { return d == LMUFFT_F32 || d == LMUFFT_BF16; };
+  if (!known(y_dtype) || (res && !known(res_dtype))) return set_error("linear: unknown dtype");
+  if (rows > 0 && !y) return set_error("linear: NULL pointer");
+  if (y && (y == x || (res && y == res && y_dtype != res_dtype)))
+    return set_error("linear: y may alias res only with the same dtype, and never x");
+  const LinearLn ln{res, res_dtype == LMUFFT_BF16, gamma, beta, eps, y, y_dtype == LMUFFT_BF16};
+  return linear_impl(x, W, bias, rows, K, N, out, ln, stream);
+}

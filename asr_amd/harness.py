@@ -2,9 +2,9 @@
 package's LMUFFT layers and CTC head, so that a reference checkpoint can be evaluated on the GPU
 and greedy decodes can be compared token by token.
 
-The LMUFFT layers, the attention core, the mel frontend and the CTC head are HIP kernels of this
-package; input / output / attention projections and layer norms are plain torch ops (rocBLAS) -- they are
-outside the hot path and exist here so that the path can be exercised in place.  Module and
+The LMUFFT layers, the attention core, the layer norms, the mel frontend and the CTC head are HIP
+kernels of this package, and so are the input / output / attention projections for inference
+under bf16 autocast (fp32 projections are torch's linear).  Module and
 parameter names follow the reference so that its state_dict loads unchanged:
   encoder.input_projection, encoder.attention_layers.{i}.attention.{w_q,w_k,w_v,w_o,layer_norm},
   encoder.lmu_layers.{i}, encoder.layer_norms.{i}, encoder.output_projection,
@@ -22,25 +22,55 @@ from torch import nn
 
 from .attention import SUPPORTED_HEAD_WIDTHS, masked_attention, masked_attention_packed
 from .layernorm import MAX_WIDTH as _LN_MAX_WIDTH, add_layer_norm
+from .linear import (FUSED_LAYER_NORM_MAX_WIDTH as LINEAR_LN_MAX_WIDTH, linear_add_layer_norm_bf16, linear_bf16,
+                     supported as linear_supported)
 from .ctc import CTCDecoder
 from .lmu import LMUFFT
 
 
+def _bf16_inference() -> bool:
+    return (not torch.is_grad_enabled() and torch.is_autocast_enabled()
+            and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+
+
+def _bf16_params(layer: nn.Linear):
+    """(weight bf16, bias bf16, bias bf16-rounded as fp32) of a Linear, kept on the layer itself
+    (so the copies die with it) and rebuilt when the parameters' version counters move."""
+    ver = (layer.weight._version, layer.weight.data_ptr(),
+           None if layer.bias is None else (layer.bias._version, layer.bias.data_ptr()))
+    hit = layer.__dict__.get("_bf16_copy")
+    if hit is None or hit[0] != ver:
+        b16 = None if layer.bias is None else layer.bias.detach().to(torch.bfloat16)
+        hit = (ver, layer.weight.detach().to(torch.bfloat16), b16, None if b16 is None else b16.float())
+        layer.__dict__["_bf16_copy"] = hit
+    return hit[1], hit[2], hit[3]
+
+
 def _linear(layer: nn.Linear, x: torch.Tensor) -> torch.Tensor:
     """layer(x).  For inference under bf16 autocast the bf16 copies of weight and bias are kept
-    (keyed on the parameters' version counters) instead of being re-cast by autocast at every
-    call; three input projections share one cast of x when x is already bf16."""
-    if (x.is_cuda and not torch.is_grad_enabled() and torch.is_autocast_enabled()
-            and torch.get_autocast_dtype("cuda") == torch.bfloat16 and layer.weight.dtype == torch.float32):
-        ver = (layer.weight._version, layer.weight.data_ptr(),
-               None if layer.bias is None else (layer.bias._version, layer.bias.data_ptr()))
-        hit = layer.__dict__.get("_bf16_copy")  # kept on the layer itself: it dies with it
-        if hit is None or hit[0] != ver:
-            hit = (ver, layer.weight.detach().to(torch.bfloat16),
-                   None if layer.bias is None else layer.bias.detach().to(torch.bfloat16))
-            layer.__dict__["_bf16_copy"] = hit
-        return torch.nn.functional.linear(x.to(torch.bfloat16), hit[1], hit[2])
+    instead of being re-cast by autocast at every call, and the product runs in this package's
+    GEMM kernel (torch's linear when the widths are not multiples of 8)."""
+    if x.is_cuda and _bf16_inference() and layer.weight.dtype == torch.float32:
+        w16, b16, b32 = _bf16_params(layer)
+        xb = x.to(torch.bfloat16)
+        if linear_supported(xb, w16):
+            return linear_bf16(xb, w16, b32)
+        return torch.nn.functional.linear(xb, w16, b16)
     return layer(x)
+
+
+def _linear_layer_norm(layer: nn.Linear, x: torch.Tensor, ln: nn.LayerNorm, residual: torch.Tensor,
+                       out_dtype: Optional[torch.dtype]) -> torch.Tensor:
+    """ln(layer(x) + residual); one kernel for inference under bf16 autocast when the width allows."""
+    if (x.is_cuda and _bf16_inference() and layer.weight.dtype == torch.float32 and ln.elementwise_affine
+            and ln.bias is not None and layer.out_features <= LINEAR_LN_MAX_WIDTH
+            and residual.dtype in (torch.float32, torch.bfloat16)):
+        w16, _, b32 = _bf16_params(layer)
+        xb = x.to(torch.bfloat16)
+        if linear_supported(xb, w16):
+            return linear_add_layer_norm_bf16(xb, w16, b32, residual, ln.weight, ln.bias, ln.eps,
+                                              out_dtype=out_dtype or torch.float32)
+    return _layer_norm(ln, _linear(layer, x), residual, out_dtype)
 
 
 def _qkv_projection(wq: nn.Linear, wk: nn.Linear, wv: nn.Linear, x: torch.Tensor) -> torch.Tensor:
@@ -52,11 +82,14 @@ def _qkv_projection(wq: nn.Linear, wk: nn.Linear, wv: nn.Linear, x: torch.Tensor
     ver = tuple((l.weight._version, l.weight.data_ptr(), l.bias._version, l.bias.data_ptr()) for l in layers) + (dt,)
     hit = wq.__dict__.get("_qkv_copy")  # kept on the first layer itself: it dies with it
     if hit is None or hit[0] != ver:
-        hit = (ver, torch.cat([l.weight.detach() for l in layers]).to(dt),
-               torch.cat([l.bias.detach() for l in layers]).to(dt))
+        bias = torch.cat([l.bias.detach() for l in layers]).to(dt)
+        hit = (ver, torch.cat([l.weight.detach() for l in layers]).to(dt), bias, bias.float())
         wq.__dict__["_qkv_copy"] = hit
+    xd = x.to(dt)
+    if bf16 and linear_supported(xd, hit[1]):
+        return linear_bf16(xd, hit[1], hit[3])
     with torch.autocast("cuda", enabled=False):
-        return torch.nn.functional.linear(x.to(dt), hit[1], hit[2])
+        return torch.nn.functional.linear(xd, hit[1], hit[2])
 
 
 def _layer_norm(ln: nn.LayerNorm, x: torch.Tensor, residual: Optional[torch.Tensor] = None,
@@ -97,7 +130,7 @@ class _MultiHeadAttention(nn.Module):
             else:
                 ctx = masked_attention(_linear(self.w_q, x), _linear(self.w_k, x), _linear(self.w_v, x),
                                        self.num_heads, lengths)
-            return _layer_norm(self.layer_norm, _linear(self.w_o, ctx), x, out_dtype)
+            return _linear_layer_norm(self.w_o, ctx, self.layer_norm, x, out_dtype)
         split = lambda t: t.view(B, T, self.num_heads, self.d_k).transpose(1, 2)  # noqa: E731
         q, k, v = split(self.w_q(x)), split(self.w_k(x)), split(self.w_v(x))
         scores = q @ k.transpose(-2, -1) / math.sqrt(self.d_k)

@@ -1,0 +1,101 @@
+"""Linear layers of the encoder on the GPU for bf16 inference (HIP kernel k_linear_glds_bf16; no autograd).
+
+Mirrors torch.nn.Linear under bf16 autocast as the reference runs it -- input_projection /
+output_projection (src/models/lmu_encoder.py:184, 229) and the attention block's w_q, w_k, w_v,
+w_o (src/models/lmu_encoder.py:40-43) -- and, for w_o, the `self.layer_norm(output + residual)`
+that follows it (src/models/lmu_encoder.py:94-97) in the same kernel.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+_DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
+FUSED_LAYER_NORM_MAX_WIDTH = 384
+
+
+def supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """True when linear_bf16 can take this call: bf16 operands on a GPU, K and N multiples of 8."""
+    return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.dim() == 2
+            and x.shape[-1] == weight.shape[1] and weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0)
+
+
+def _check(x, weight, bias):
+    for name, t in (("x", x), ("weight", weight), ("bias", bias)):
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(f"linear_bf16: `{name}` lives on {t.device}; the kernel runs only on a GPU "
+                               "(there is no CPU fallback)")
+    if x.dtype != torch.bfloat16 or weight.dtype != torch.bfloat16:
+        raise RuntimeError("linear_bf16: x and weight must be bfloat16")
+    if weight.dim() != 2 or x.shape[-1] != weight.shape[1]:
+        raise RuntimeError(f"linear_bf16: weight {tuple(weight.shape)} does not match x {tuple(x.shape)}")
+    if bias is not None and (bias.dtype != torch.float32 or bias.shape != (weight.shape[0],)):
+        raise RuntimeError(f"linear_bf16: bias must be float32 of shape ({weight.shape[0]},)")
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [..., K] bf16, weight [N, K] bf16 (nn.Linear layout), bias [N] fp32 or None -> [..., N] bf16.
+
+    The bias is added in fp32 before the single rounding; pass the bf16-rounded bias widened to
+    fp32 to reproduce autocast's arithmetic exactly.
+    """
+    _check(x, weight, bias)
+    N, K = weight.shape
+    x = x.detach().contiguous()
+    weight = weight.detach().contiguous()
+    bias = None if bias is None else bias.detach().contiguous()
+    out = torch.empty(x.shape[:-1] + (N,), dtype=torch.bfloat16, device=x.device)
+    rows = x.numel() // K
+    with torch.cuda.device(x.device):
+        rc = _lib.lib.lmufft_linear_bf16(_ptr(x), _ptr(weight), _ptr(bias), rows, K, N, _ptr(out),
+                                         ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    _lib.check(rc, "lmufft_linear_bf16")
+    return out
+
+
+def linear_add_layer_norm_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                               residual: Optional[torch.Tensor], ln_weight: torch.Tensor, ln_bias: torch.Tensor,
+                               eps: float = 1e-5, out_dtype: torch.dtype = torch.float32,
+                               return_projection: bool = False):
+    """LayerNorm(bf16(x weight^T + bias) + residual) in one kernel; N <= 384.
+
+    residual: [..., N] float32 or bfloat16, or None; the result has `out_dtype` (float32 or bfloat16).
+    With `return_projection` the bf16 projection is written too and (y, projection) is returned.
+    """
+    _check(x, weight, bias)
+    N, K = weight.shape
+    if N > FUSED_LAYER_NORM_MAX_WIDTH:
+        raise RuntimeError(f"linear_add_layer_norm_bf16: width {N} exceeds {FUSED_LAYER_NORM_MAX_WIDTH}")
+    shape = x.shape[:-1] + (N,)
+    if residual is not None:
+        if not residual.is_cuda or residual.dtype not in _DTYPES or residual.shape != shape:
+            raise RuntimeError(f"linear_add_layer_norm_bf16: residual must be a float32 / bfloat16 GPU tensor of shape "
+                               f"{tuple(shape)}")
+        residual = residual.detach().contiguous()
+    if out_dtype not in _DTYPES:
+        raise RuntimeError(f"linear_add_layer_norm_bf16: output dtype {out_dtype} is not supported")
+    if ln_weight.shape != (N,) or ln_bias.shape != (N,) or not ln_weight.is_cuda or not ln_bias.is_cuda:
+        raise RuntimeError(f"linear_add_layer_norm_bf16: layer-norm weight / bias must be GPU tensors of shape ({N},)")
+    x = x.detach().contiguous()
+    weight = weight.detach().contiguous()
+    bias = None if bias is None else bias.detach().contiguous()
+    g = ln_weight.detach().float().contiguous()
+    b = ln_bias.detach().float().contiguous()
+    y = torch.empty(shape, dtype=out_dtype, device=x.device)
+    proj = torch.empty(shape, dtype=torch.bfloat16, device=x.device) if return_projection else None
+    rows = x.numel() // K
+    with torch.cuda.device(x.device):
+        rc = _lib.lib.lmufft_linear_ln_bf16(
+            _ptr(x), _ptr(weight), _ptr(bias), rows, K, N, _ptr(proj), _ptr(residual),
+            _DTYPES[residual.dtype] if residual is not None else 0, _ptr(g), _ptr(b), float(eps), _ptr(y),
+            _DTYPES[out_dtype], ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    _lib.check(rc, "lmufft_linear_ln_bf16")
+    return (y, proj) if return_projection else y

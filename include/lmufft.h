@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMUFFT_ABI_VERSION 4
+#define LMUFFT_ABI_VERSION 5
 
 /* element types of the activations (x, h, gh, gx, m) */
 #define LMUFFT_F32 0
@@ -251,6 +251,35 @@ int lmufft_attention_fwd_ld(const void* q, const void* k, const void* v, int dty
 int lmufft_add_layernorm(const void* x, int x_dtype, const void* res, int res_dtype,
                          const float* gamma, const float* beta, float eps, int64_t rows,
                          int32_t C, void* out, int out_dtype, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Linear layers of the encoder for bf16 inference: out = x W^T + bias with bf16
+ * operands, fp32 accumulation, the bias added in fp32 and one rounding to bf16 --
+ * the arithmetic of torch.nn.Linear under bf16 autocast.  Replaces
+ * input_projection / output_projection (src/models/lmu_encoder.py:184, 229;
+ * calls at :244, :278) and the attention block's w_q, w_k, w_v, w_o
+ * (src/models/lmu_encoder.py:40-43; calls at :68-70, :94); the three input
+ * projections run as one call over the row-concatenated weights.
+ *   x: bf16 [rows][K]; W: bf16 [N][K] (nn.Linear.weight layout); bias: f32 [N]
+ *   or NULL; out: bf16 [rows][N].  K % 8 == 0, N % 8 == 0, 16-byte aligned
+ *   x, W and out.
+ * ---------------------------------------------------------------------- */
+int lmufft_linear_bf16(const void* x, const void* W, const float* bias, int64_t rows,
+                       int32_t K, int32_t N, void* out, void* stream);
+
+/* The same GEMM followed, in its epilogue, by the residual add and layer norm of
+ * the attention block: y = LN(bf16(x W^T + bias) + res) * gamma + beta
+ * (`output = self.layer_norm(output + residual)`, src/models/lmu_encoder.py:94-97;
+ * the dropout between them is the identity in eval mode).  The sum and the
+ * statistics are fp32, the variance is biased.
+ *   res: [rows][N] f32 or bf16 (res_dtype), or NULL; gamma, beta: f32 [N];
+ *   y: [rows][N] f32 or bf16 (y_dtype); out: bf16 [rows][N], or NULL when the
+ *   projection itself is not wanted.  Needs N <= 384; y may alias res when
+ *   their dtypes agree. */
+int lmufft_linear_ln_bf16(const void* x, const void* W, const float* bias, int64_t rows,
+                          int32_t K, int32_t N, void* out, const void* res, int res_dtype,
+                          const float* gamma, const float* beta, float eps, void* y,
+                          int y_dtype, void* stream);
 
 /* ------------------------------------------------------------------------
  * Per-kernel timing with HIP events on the caller's stream (no counterpart in

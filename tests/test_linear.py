@@ -1,0 +1,168 @@
+"""Linear layers of the encoder (bf16 inference): the oracle against torch's linear on the CPU,
+and the HIP kernel (through the C ABI) against the oracle, with and without the fused
+residual + layer-norm epilogue."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from oracle import layernorm_oracle as lno  # noqa: E402
+from oracle import linear_oracle as lo  # noqa: E402
+
+
+def _case(rows, K, N, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(rows, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    return x, W, b
+
+
+def test_round_bf16_matches_torch():
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(4096, generator=g) * 10.0 ** torch.randint(-6, 6, (4096,), generator=g).float()
+    want = a.to(torch.bfloat16).float().numpy()
+    np.testing.assert_array_equal(lo.round_bf16(a.numpy()), want)
+
+
+@pytest.mark.parametrize("rows,K,N", [(5, 80, 384), (33, 384, 1152), (1, 8, 8)])
+def test_oracle_matches_torch_linear(rows, K, N):
+    x, W, b = _case(rows, K, N, rows + K + N)
+    xb, Wb, bb = x.to(torch.bfloat16), W.to(torch.bfloat16), b.to(torch.bfloat16)
+    # the op the reference runs under autocast, evaluated exactly: fp64 product of the bf16 operands
+    want = (xb.double() @ Wb.double().T + bb.double()).float().to(torch.bfloat16).float().numpy()
+    got = lo.linear_bf16(x.numpy(), W.numpy(), b.numpy())
+    np.testing.assert_array_equal(got, want)
+    # and torch's own bf16 linear on the CPU, to the bf16 bar (its accumulation order is its own)
+    cpu = torch.nn.functional.linear(xb, Wb, bb).float().numpy()
+    np.testing.assert_allclose(got, cpu, rtol=2e-2, atol=2e-2)
+
+
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _assert_bf16_close(got, want):
+    np.testing.assert_allclose(got, want, rtol=2e-2, atol=2e-2)  # bf16 bar
+    # the kernel accumulates in fp32 and rounds once: apart from near-ties it IS the oracle's value
+    assert np.mean(got == want) > 0.97
+    assert np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-3)) < 1e-2  # at most one bf16 ulp
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,K,N,with_bias", [
+    (1, 8, 8, True), (127, 80, 384, True), (129, 384, 384, True), (300, 384, 1152, True), (64, 72, 40, False),
+    (1000, 512, 512, True), (257, 200, 392, True)])
+def test_kernel_matches_oracle(rows, K, N, with_bias):
+    from asr_amd.linear import linear_bf16
+
+    dev = _gpu()
+    x, W, b = _case(rows, K, N, rows * 7 + K + N)
+    bq = b.to(torch.bfloat16).float()
+    got = linear_bf16(x.to(dev).to(torch.bfloat16), W.to(dev).to(torch.bfloat16), bq.to(dev) if with_bias else None)
+    assert got.dtype == torch.bfloat16 and got.shape == (rows, N)
+    want = lo.linear_bf16(x.numpy(), W.numpy(), b.numpy() if with_bias else None)
+    _assert_bf16_close(got.float().cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+def test_kernel_keeps_leading_dimensions_and_empty_input():
+    from asr_amd.linear import linear_bf16
+
+    dev = _gpu()
+    x, W, b = _case(6 * 50, 384, 384, 11)
+    xb = x.view(6, 50, 384).to(dev).to(torch.bfloat16)
+    got = linear_bf16(xb, W.to(dev).to(torch.bfloat16), b.to(dev))
+    assert got.shape == (6, 50, 384)
+    flat = linear_bf16(xb.view(300, 384), W.to(dev).to(torch.bfloat16), b.to(dev))
+    assert torch.equal(got.view(300, 384), flat)
+    empty = linear_bf16(xb[:0], W.to(dev).to(torch.bfloat16), b.to(dev))
+    assert empty.shape == (0, 50, 384)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("res_dtype", [None, torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,K,N", [(1, 8, 8), (130, 384, 384), (515, 384, 256), (77, 80, 200)])
+def test_fused_layer_norm_matches_oracle(rows, K, N, res_dtype, out_dtype):
+    from asr_amd.linear import linear_add_layer_norm_bf16
+
+    dev = _gpu()
+    x, W, b = _case(rows, K, N, rows + 3 * K + N)
+    g = torch.Generator().manual_seed(rows)
+    res = None if res_dtype is None else (torch.randn(rows, N, generator=g) * 2.0).to(res_dtype)
+    gamma, beta = torch.randn(N, generator=g), torch.randn(N, generator=g)
+    bq = b.to(torch.bfloat16).float()
+    y, proj = linear_add_layer_norm_bf16(
+        x.to(dev).to(torch.bfloat16), W.to(dev).to(torch.bfloat16), bq.to(dev), None if res is None else res.to(dev),
+        gamma.to(dev), beta.to(dev), 1e-5, out_dtype=out_dtype, return_projection=True)
+    assert y.dtype == out_dtype and y.shape == (rows, N)
+    # the projection: the bf16 bar against the oracle
+    _assert_bf16_close(proj.float().cpu().numpy(), lo.linear_bf16(x.numpy(), W.numpy(), b.numpy()))
+    # the epilogue: layer norm of THAT projection plus the residual, at the fp32 bar
+    want = lno.add_layer_norm(proj.float().cpu().numpy(), None if res is None else res.float().numpy(),
+                              gamma.numpy(), beta.numpy(), 1e-5)
+    got = y.float().cpu().numpy()
+    if out_dtype == torch.float32:
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-5)
+    else:
+        np.testing.assert_allclose(got, want, rtol=2e-2, atol=2e-2)
+        assert np.mean(got == torch.from_numpy(want).to(torch.bfloat16).float().numpy()) > 0.99
+    # end to end against the oracle of the whole block, at the bf16 bar of its bf16 intermediate
+    full = lo.linear_add_layer_norm(x.numpy(), W.numpy(), b.numpy(), None if res is None else res.float().numpy(),
+                                    gamma.numpy(), beta.numpy(), 1e-5)
+    np.testing.assert_allclose(got, full, rtol=2e-2, atol=5e-2)
+    # without the projection output the result is the same
+    y2 = linear_add_layer_norm_bf16(
+        x.to(dev).to(torch.bfloat16), W.to(dev).to(torch.bfloat16), bq.to(dev), None if res is None else res.to(dev),
+        gamma.to(dev), beta.to(dev), 1e-5, out_dtype=out_dtype)
+    assert torch.equal(y, y2)
+
+
+@pytest.mark.gpu
+def test_fused_layer_norm_in_place_on_the_residual():
+    from asr_amd import _lib
+    from asr_amd.linear import linear_add_layer_norm_bf16
+    import ctypes
+
+    dev = _gpu()
+    x, W, b = _case(200, 384, 384, 5)
+    g = torch.Generator().manual_seed(9)
+    res = torch.randn(200, 384, generator=g)
+    gamma, beta = torch.randn(384, generator=g), torch.randn(384, generator=g)
+    xb, Wb = x.to(dev).to(torch.bfloat16), W.to(dev).to(torch.bfloat16)
+    want = linear_add_layer_norm_bf16(xb, Wb, b.to(dev), res.to(dev), gamma.to(dev), beta.to(dev))
+    buf = res.to(dev).clone()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    gd, bd, bias = gamma.to(dev), beta.to(dev), b.to(dev)
+    rc = _lib.lib.lmufft_linear_ln_bf16(p(xb), p(Wb), p(bias), 200, 384, 384, None, p(buf), _lib.F32, p(gd), p(bd),
+                                        1e-5, p(buf), _lib.F32, None)
+    _lib.check(rc, "lmufft_linear_ln_bf16")
+    torch.cuda.synchronize()
+    assert torch.equal(buf, want)
+
+
+@pytest.mark.gpu
+def test_errors():
+    from asr_amd.linear import linear_add_layer_norm_bf16, linear_bf16
+
+    dev = _gpu()
+    x = torch.zeros(4, 16, device=dev, dtype=torch.bfloat16)
+    W = torch.zeros(8, 16, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        linear_bf16(x.cpu(), W.cpu())
+    with pytest.raises(RuntimeError, match="bfloat16"):
+        linear_bf16(x.float(), W)
+    with pytest.raises(RuntimeError, match="does not match"):
+        linear_bf16(x[:, :8], W)
+    with pytest.raises(RuntimeError, match="multiples of 8"):
+        linear_bf16(x[:, :12].contiguous(), W[:, :12].contiguous())
+    Wide = torch.zeros(392, 16, device=dev, dtype=torch.bfloat16)
+    ones = torch.ones(392, device=dev)
+    with pytest.raises(RuntimeError, match="exceeds"):
+        linear_add_layer_norm_bf16(x, Wide, None, None, ones, ones)
