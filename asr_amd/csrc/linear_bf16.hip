@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "gemm_glds_bf16.h"
 #include "lmufft.h"
 #include "lmufft_internal.h"
@@ -162,11 +164,239 @@ __global__ __launch_bounds__(LinearTile::THREADS) void k_linear_glds_bf16(const 
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Weight-stationary form for K <= 384.
+//
+// The tiled kernel above pulls, per 128 rows, 98 KB of x AND 295 KB of W through the CU's L1 --
+// W, the operand that never changes, is three quarters of the fill traffic, and the fill rate of
+// a CU's L1 is what bounds these GEMMs.  Here a persistent workgroup keeps its 384 columns of W
+// in REGISTERS for its whole life -- eight waves x 48 columns x K: 144 registers per lane as A
+// fragments of v_mfma_f32_16x16x32_bf16 -- and only x streams: 64-row tiles (48 KB) by LDS-DMA
+// into two stages, the next tile in flight while this one is multiplied, one barrier pair per
+// tile instead of one per k-tile.  The product is taken transposed, D = W x^T, so a lane ends up
+// with four consecutive output columns of one row; the tile goes through an LDS image
+// [64][384 + 8] to leave as 16-byte row segments (or through the layer-norm epilogue, sixteen
+// lanes per row).
+//
+// LDS image of an x tile: [64 rows][48 chunks of 16 B], chunk c of row r at position
+// (c & ~15) | ((c ^ r) & 15): the 16 rows a ds_read_b128 lane group reads fall on 16 distinct
+// 16-byte slots of the 256-byte bank row.  The LDS-DMA destination is linear in the lane index,
+// so the permutation is applied to the source address.
+// ---------------------------------------------------------------------------
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int kWsThreads = 512;
+constexpr int kWsRows = 64;                      // x rows per tile
+constexpr int kWsCols = 384;                     // output columns per workgroup: 8 waves x 48
+constexpr int kWsKS = 12;                        // k-steps of 32: K <= 384
+constexpr int kWsCPR = kWsKS * 4;                // 16-byte chunks per LDS row
+constexpr int kWsPitch = kWsCPR * 16;            // bytes per LDS row
+constexpr int kWsStage = kWsRows * kWsPitch;     // 48 KB
+constexpr int kWsNI = kWsStage / 1024 / 8;       // LDS-DMA instructions per wave and tile
+constexpr int kWsOutLd = kWsCols + 8;            // bf16 elements per row of the output image
+constexpr int kWsLds = 2 * kWsStage + kWsRows * kWsOutLd * 2;
+static_assert(kWsLds <= 160 * 1024, "fits the CU's LDS");
+
+template <bool LN, int KSTEPS>
+__global__ __launch_bounds__(kWsThreads) void k_linear_ws_bf16(const bf16_t* __restrict__ x,
+                                                               const bf16_t* __restrict__ W,
+                                                               const float* __restrict__ bias,
+                                                               bf16_t* __restrict__ out, long rows, int K, int N,
+                                                               LinearLn ln) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const bf16_t* const zero = reinterpret_cast<const bf16_t*>(kZeroBytes);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, l15 = lane & 15, q = lane >> 4;
+  const int n_blk = blockIdx.x * kWsCols;
+  const int nw = n_blk + wave * 48;
+
+  // this wave's 48 columns of W as A fragments: lane holds W[nw + 16 t + l15][32 ks + 8 q .. + 8]
+  static_assert(KSTEPS <= kWsKS, "the LDS image holds 32 kWsKS elements per row");
+  bf16x8 wf[3][KSTEPS];  // K <= 32 KSTEPS (the host picks the instantiation)
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int n = nw + t * 16 + l15, k = ks * 32 + 8 * q;
+      wf[t][ks] = *reinterpret_cast<const bf16x8*>((n < N && k < K) ? W + (long)n * K + k : zero);
+    }
+
+  // LDS-DMA sources: slot p of the tile image holds chunk c of row r (recomputed per tile: the
+  // registers are needed for W)
+  auto issue = [&](int stage, long row0) {
+#pragma unroll
+    for (int i = 0; i < kWsNI; ++i) {
+      const int p = (wave * kWsNI + i) * 64 + lane;
+      const int r = p / kWsCPR, cp = p % kWsCPR;
+      const int c = (cp & ~15) | ((cp ^ r) & 15);
+      const bool ok = c * 8 < K && row0 + r < rows;
+      const bf16_t* src = ok ? x + (row0 + r) * K + c * 8 : zero;
+      unsigned char* dst = smem_raw + stage * kWsStage + (wave * kWsNI + i) * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+  int posl[4];  // position of chunk 4 (ks & 3) + q in this lane's rows, before the 16 (ks >> 2) part
+#pragma unroll
+  for (int j = 0; j < 4; ++j) posl[j] = ((4 * j + q) ^ l15) * 16;
+  bf16_t* otile = reinterpret_cast<bf16_t*>(smem_raw + 2 * kWsStage);
+
+  const long ntiles = (rows + kWsRows - 1) / kWsRows;
+  long tile = blockIdx.y;
+  int stage = 0;
+  if (tile < ntiles) issue(0, tile * kWsRows);
+  for (; tile < ntiles; tile += gridDim.y, stage ^= 1) {
+    // this wave's LDS-DMA writes have landed; after the barrier everybody's have, and everybody has
+    // finished with the other stage and with the output image of the previous tile
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tile + gridDim.y < ntiles) issue(stage ^ 1, (tile + gridDim.y) * kWsRows);
+
+    const unsigned char* xs = smem_raw + stage * kWsStage + l15 * kWsPitch;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {  // 32 rows at a time: 24 accumulator registers
+      f32x4a acc[2][3];
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[g][t] = f32x4a{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xs + (half * 2 + g) * 16 * kWsPitch + posl[ks & 3] +
+                                                             256 * (ks >> 2));
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+            acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][ks], xf, acc[g][t], 0, 0, 0);
+        }
+      }
+      // D[n = 4 q + v][row = l15]: four consecutive columns of one row per lane
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int n = nw + t * 16 + 4 * q;
+        f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (bias && n < N) b4 = *reinterpret_cast<const f32x4*>(bias + n);  // N % 8 == 0: all four or none
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          bf16x4 o;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) o[v] = (bf16_t)(acc[g][t][v] + b4[v]);
+          *reinterpret_cast<bf16x4*>(
+              &otile[((half * 2 + g) * 16 + l15) * kWsOutLd + wave * 48 + t * 16 + 4 * q]) = o;
+        }
+      }
+    }
+    __syncthreads();
+
+    const long row0 = tile * kWsRows;
+    if (out) {
+#pragma unroll
+      for (int i = 0; i < kWsRows * (kWsCols / 8) / kWsThreads; ++i) {
+        const int idx = threadIdx.x + i * kWsThreads;
+        const int m = idx / (kWsCols / 8), c = idx % (kWsCols / 8);
+        const long row = row0 + m;
+        const int col = n_blk + c * 8;
+        if (row < rows && col < N)
+          *reinterpret_cast<bf16x8*>(out + row * N + col) = *reinterpret_cast<const bf16x8*>(&otile[m * kWsOutLd + c * 8]);
+      }
+    }
+    if (LN) {  // one column block holds whole rows (the host checks N <= 384)
+      // sixteen lanes per row, 32 rows per pass: a lane keeps 24 sums, which leaves W in its registers
+      static_assert(kWsThreads == 16 * (kWsRows / 2), "sixteen lanes per row, two passes");
+      constexpr int PER = kWsCols / 8 / 16;
+      const int sub = threadIdx.x & 15;
+      const int chunks = N / 8;
+#pragma unroll 1
+      for (int pass = 0; pass < 2; ++pass) {
+        const int rl = pass * (kWsRows / 2) + (threadIdx.x >> 4);
+        const long row = row0 + rl;
+        const bool live = row < rows;
+        float v[PER][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+          const int c = sub + 16 * i;
+          const bool on = c < chunks;
+          const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(&otile[rl * kWsOutLd + c * 8]);
+          float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if (ln.res && on && live) {
+            if (ln.res_bf16) {
+              const bf16x8 rb =
+                  *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(ln.res) + row * N + c * 8);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) r[j] = (float)rb[j];
+            } else {
+              const float* rp = reinterpret_cast<const float*>(ln.res) + row * N + c * 8;
+              const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp);
+              const f32x4 r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                r[j] = r0[j];
+                r[j + 4] = r1[j];
+              }
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            v[i][j] = on ? (float)t8[j] + r[j] : 0.f;
+            s += v[i][j];
+          }
+        }
+#pragma unroll
+        for (int sh = 1; sh < 16; sh <<= 1) s += __shfl_xor(s, sh);
+        const float mean = s / (float)N;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+          const bool on = sub + 16 * i < chunks;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float d = on ? v[i][j] - mean : 0.f;
+            ss += d * d;
+          }
+        }
+#pragma unroll
+        for (int sh = 1; sh < 16; sh <<= 1) ss += __shfl_xor(ss, sh);
+        const float rstd = rsqrtf(ss / (float)N + ln.eps);
+        if (live) {
+#pragma unroll
+          for (int i = 0; i < PER; ++i) {
+            const int c = sub + 16 * i;
+            if (c < chunks) {
+              const f32x4 g0 = *reinterpret_cast<const f32x4*>(ln.gamma + c * 8);
+              const f32x4 g1 = *reinterpret_cast<const f32x4*>(ln.gamma + c * 8 + 4);
+              const f32x4 b0 = *reinterpret_cast<const f32x4*>(ln.beta + c * 8);
+              const f32x4 b1 = *reinterpret_cast<const f32x4*>(ln.beta + c * 8 + 4);
+              float o[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                o[j] = (v[i][j] - mean) * rstd * (j < 4 ? g0[j] : g1[j - 4]) + (j < 4 ? b0[j] : b1[j - 4]);
+              if (ln.y_bf16) {
+                bf16x8 ob8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ob8[j] = (bf16_t)o[j];
+                *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(ln.y) + row * N + c * 8) = ob8;
+              } else {
+                float* yp = reinterpret_cast<float*>(ln.y) + row * N + c * 8;
+                *reinterpret_cast<f32x4*>(yp) = f32x4{o[0], o[1], o[2], o[3]};
+                *reinterpret_cast<f32x4*>(yp + 4) = f32x4{o[4], o[5], o[6], o[7]};
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
 }  // namespace lmufft
 
 using namespace lmufft;
 
 namespace {
+constexpr int kComputeUnits = 256;  // gfx950: persistent workgroups, one per CU
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int linear_impl(const void* x, const void* W, const float* bias, int64_t rows, int32_t K, int32_t N, void* out,
@@ -184,6 +414,26 @@ int linear_impl(const void* x, const void* W, const float* bias, int64_t rows, i
     if (!al16(ln.y) || !al16(ln.res) || !al16(ln.gamma) || !al16(ln.beta))
       return set_error("linear: y, res, gamma and beta must be 16-byte aligned");
   }
+  hipStream_t st = (hipStream_t)stream;
+  if (K <= kWsKS * 32) {  // weight-stationary persistent kernel
+    const int col_blocks = (N + kWsCols - 1) / kWsCols;
+    const long ntiles = (rows + kWsRows - 1) / kWsRows;
+    const long per_block = std::max(1L, (long)kComputeUnits / col_blocks);
+    const dim3 grid(col_blocks, (unsigned)std::min(ntiles, per_block));
+    const bool narrow = K <= 96;  // three k-steps: the input projection (80 mel bins)
+    auto kernel = ln.y ? (narrow ? k_linear_ws_bf16<true, 3> : k_linear_ws_bf16<true, kWsKS>)
+                       : (narrow ? k_linear_ws_bf16<false, 3> : k_linear_ws_bf16<false, kWsKS>);
+    if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWsLds) != hipSuccess)
+      return set_error("cannot reserve %d bytes of LDS for k_linear_ws_bf16", kWsLds);
+    {
+      ProfScope ps("k_linear_ws_bf16", st);
+      hipLaunchKernelGGL(kernel, grid, dim3(kWsThreads), kWsLds, st, (const bf16_t*)x, (const bf16_t*)W, bias,
+                         (bf16_t*)out, (long)rows, K, N, ln);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error("k_linear_ws_bf16: %s", hipGetErrorString(e));
+    return 0;
+  }
   const long row_tiles = (rows + TL::BM - 1) / TL::BM;
   if (row_tiles > 65535) return set_error("linear: %lld rows exceed the launch grid", (long long)rows);
   const dim3 grid((N + TL::BN - 1) / TL::BN, (unsigned)row_tiles);
@@ -192,7 +442,6 @@ int linear_impl(const void* x, const void* W, const float* bias, int64_t rows, i
   if (hipFuncSetAttribute((const void*)k_linear_glds_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
       hipSuccess)
     return set_error("cannot reserve %zu bytes of LDS for k_linear_glds_bf16", lds);
-  hipStream_t st = (hipStream_t)stream;
   {
     ProfScope ps("k_linear_glds_bf16", st);
     hipLaunchKernelGGL(k_linear_glds_bf16, grid, dim3(TL::THREADS), lds, st, (const bf16_t*)x, (const bf16_t*)W, bias,

@@ -38,3 +38,10 @@ for K, N in ((80, 384), (384, 384), (384, 1152)):
             fused = t(lambda: linear_add_layer_norm_bf16(x, W, b, r, g, be, 1e-5, out_dtype=od))
             sep = t(lambda: add_layer_norm(linear_bf16(x, W, b), r, g, be, 1e-5, out_dtype=od))
             print(f"   + residual {rd} + layer norm -> {od}: fused {fused:.1f} us, two kernels {sep:.1f} us")
+
+# launch + weight prologue + one tile per workgroup, against the full batch
+for r in (64 * 256, 64 * 256 * 2, 64 * 256 * 4):
+    x = torch.randn(r, 384, device=dev).bfloat16()
+    W = (torch.randn(384, 384, device=dev) / 20).bfloat16()
+    b = torch.randn(384, device=dev)
+    print(f"rows={r} 384->384: {t(lambda: linear_bf16(x, W, b)):.1f} us")

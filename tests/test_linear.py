@@ -57,7 +57,7 @@ def _assert_bf16_close(got, want):
 @pytest.mark.gpu
 @pytest.mark.parametrize("rows,K,N,with_bias", [
     (1, 8, 8, True), (127, 80, 384, True), (129, 384, 384, True), (300, 384, 1152, True), (64, 72, 40, False),
-    (1000, 512, 512, True), (257, 200, 392, True)])
+    (1000, 512, 512, True), (257, 200, 392, True), (33001, 384, 384, True), (20000, 96, 1152, True)])
 def test_kernel_matches_oracle(rows, K, N, with_bias):
     from asr_amd.linear import linear_bf16
 
@@ -88,7 +88,8 @@ def test_kernel_keeps_leading_dimensions_and_empty_input():
 @pytest.mark.gpu
 @pytest.mark.parametrize("res_dtype", [None, torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("rows,K,N", [(1, 8, 8), (130, 384, 384), (515, 384, 256), (77, 80, 200)])
+@pytest.mark.parametrize("rows,K,N", [(1, 8, 8), (130, 384, 384), (515, 384, 256), (77, 80, 200), (40000, 384, 384),
+                                     (300, 512, 384)])
 def test_fused_layer_norm_matches_oracle(rows, K, N, res_dtype, out_dtype):
     from asr_amd.linear import linear_add_layer_norm_bf16
 
