@@ -195,7 +195,8 @@ constexpr int kWsPitch = kWsCPR * 16;            // bytes per LDS row
 constexpr int kWsStage = kWsRows * kWsPitch;     // 48 KB
 constexpr int kWsNI = kWsStage / 1024 / 8;       // LDS-DMA instructions per wave and tile
 constexpr int kWsOutLd = kWsCols + 8;            // bf16 elements per row of the output image
-constexpr int kWsLds = 2 * kWsStage + kWsRows * kWsOutLd * 2;
+constexpr int kWsLds = 2 * kWsStage + kWsRows * kWsOutLd * 2 + kWsCols * 4;  // x stages | output image | bias
+constexpr int kWsAhead = 2;                      // k-steps between an x fragment's LDS read and its MFMAs
 static_assert(kWsLds <= 160 * 1024, "fits the CU's LDS");
 
 template <bool LN, int KSTEPS>
@@ -241,6 +242,11 @@ __global__ __launch_bounds__(kWsThreads) void k_linear_ws_bf16(const bf16_t* __r
 #pragma unroll
   for (int j = 0; j < 4; ++j) posl[j] = ((4 * j + q) ^ l15) * 16;
   bf16_t* otile = reinterpret_cast<bf16_t*>(smem_raw + 2 * kWsStage);
+  // the bias sits in LDS: a global load inside the round would make its s_waitcnt vmcnt wait for
+  // the next tile's LDS-DMA as well
+  float* bias_s = reinterpret_cast<float*>(smem_raw + 2 * kWsStage + kWsRows * kWsOutLd * 2);
+  if (threadIdx.x < kWsCols)
+    bias_s[threadIdx.x] = (bias && n_blk + (int)threadIdx.x < N) ? bias[n_blk + threadIdx.x] : 0.f;
 
   const long ntiles = (rows + kWsRows - 1) / kWsRows;
   long tile = blockIdx.y;
@@ -261,23 +267,32 @@ __global__ __launch_bounds__(kWsThreads) void k_linear_ws_bf16(const bf16_t* __r
       for (int g = 0; g < 2; ++g)
 #pragma unroll
         for (int t = 0; t < 3; ++t) acc[g][t] = f32x4a{0.f, 0.f, 0.f, 0.f};
+      // x fragments are read kWsAhead k-steps before the MFMAs that use them; the scheduling barriers
+      // keep that distance (left alone, the compiler sinks every read to its use and each k-step
+      // waits out the LDS latency)
+      bf16x8 xq[kWsAhead + 1][2];
+      auto read_x = [&](int ks, bf16x8 (&d)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+          d[g] = *reinterpret_cast<const bf16x8*>(xs + (half * 2 + g) * 16 * kWsPitch + posl[ks & 3] + 256 * (ks >> 2));
+      };
+#pragma unroll
+      for (int ks = 0; ks < kWsAhead && ks < KSTEPS; ++ks) read_x(ks, xq[ks % (kWsAhead + 1)]);
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
+        if (ks + kWsAhead < KSTEPS) read_x(ks + kWsAhead, xq[(ks + kWsAhead) % (kWsAhead + 1)]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xs + (half * 2 + g) * 16 * kWsPitch + posl[ks & 3] +
-                                                             256 * (ks >> 2));
+        for (int g = 0; g < 2; ++g)
 #pragma unroll
           for (int t = 0; t < 3; ++t)
-            acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][ks], xf, acc[g][t], 0, 0, 0);
-        }
+            acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][ks], xq[ks % (kWsAhead + 1)][g], acc[g][t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
       // D[n = 4 q + v][row = l15]: four consecutive columns of one row per lane
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
-        const int n = nw + t * 16 + 4 * q;
-        f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (bias && n < N) b4 = *reinterpret_cast<const f32x4*>(bias + n);  // N % 8 == 0: all four or none
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(&bias_s[wave * 48 + t * 16 + 4 * q]);
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
           bf16x4 o;

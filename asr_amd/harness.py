@@ -22,8 +22,7 @@ from torch import nn
 
 from .attention import SUPPORTED_HEAD_WIDTHS, masked_attention, masked_attention_packed
 from .layernorm import MAX_WIDTH as _LN_MAX_WIDTH, add_layer_norm
-from .linear import (FUSED_LAYER_NORM_MAX_WIDTH as LINEAR_LN_MAX_WIDTH, linear_add_layer_norm_bf16, linear_bf16,
-                     supported as linear_supported)
+from .linear import linear_bf16, supported as linear_supported
 from .ctc import CTCDecoder
 from .lmu import LMUFFT
 
@@ -61,15 +60,9 @@ def _linear(layer: nn.Linear, x: torch.Tensor) -> torch.Tensor:
 
 def _linear_layer_norm(layer: nn.Linear, x: torch.Tensor, ln: nn.LayerNorm, residual: torch.Tensor,
                        out_dtype: Optional[torch.dtype]) -> torch.Tensor:
-    """ln(layer(x) + residual); one kernel for inference under bf16 autocast when the width allows."""
-    if (x.is_cuda and _bf16_inference() and layer.weight.dtype == torch.float32 and ln.elementwise_affine
-            and ln.bias is not None and layer.out_features <= LINEAR_LN_MAX_WIDTH
-            and residual.dtype in (torch.float32, torch.bfloat16)):
-        w16, _, b32 = _bf16_params(layer)
-        xb = x.to(torch.bfloat16)
-        if linear_supported(xb, w16):
-            return linear_add_layer_norm_bf16(xb, w16, b32, residual, ln.weight, ln.bias, ln.eps,
-                                              out_dtype=out_dtype or torch.float32)
+    """ln(layer(x) + residual).  Two kernels: at the encoder's sizes the GEMM followed by the one-pass
+    add + layer-norm kernel is faster than linear_add_layer_norm_bf16's fused epilogue, whose
+    residual loads sit inside the persistent GEMM loop."""
     return _layer_norm(ln, _linear(layer, x), residual, out_dtype)
 
 
