@@ -209,7 +209,10 @@ __global__ __launch_bounds__(kWsThreads) void k_linear_ws_bf16(const bf16_t* __r
   const bf16_t* const zero = reinterpret_cast<const bf16_t*>(kZeroBytes);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63, l15 = lane & 15, q = lane >> 4;
-  const int n_blk = blockIdx.x * kWsCols;
+  // blockIdx.y = column block, blockIdx.x = persistent slot: with a slot count that is a multiple
+  // of eight, the workgroups that walk the same x tiles for different column blocks sit on the
+  // same XCD (workgroup id % 8) and share those tiles through its L2
+  const int n_blk = blockIdx.y * kWsCols;
   const int nw = n_blk + wave * 48;
 
   // this wave's 48 columns of W as A fragments: lane holds W[nw + 16 t + l15][32 ks + 8 q .. + 8]
@@ -249,15 +252,15 @@ __global__ __launch_bounds__(kWsThreads) void k_linear_ws_bf16(const bf16_t* __r
     bias_s[threadIdx.x] = (bias && n_blk + (int)threadIdx.x < N) ? bias[n_blk + threadIdx.x] : 0.f;
 
   const long ntiles = (rows + kWsRows - 1) / kWsRows;
-  long tile = blockIdx.y;
+  long tile = blockIdx.x;
   int stage = 0;
   if (tile < ntiles) issue(0, tile * kWsRows);
-  for (; tile < ntiles; tile += gridDim.y, stage ^= 1) {
+  for (; tile < ntiles; tile += gridDim.x, stage ^= 1) {
     // this wave's LDS-DMA writes have landed; after the barrier everybody's have, and everybody has
     // finished with the other stage and with the output image of the previous tile
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tile + gridDim.y < ntiles) issue(stage ^ 1, (tile + gridDim.y) * kWsRows);
+    if (tile + gridDim.x < ntiles) issue(stage ^ 1, (tile + gridDim.x) * kWsRows);
 
     const unsigned char* xs = smem_raw + stage * kWsStage + l15 * kWsPitch;
 #pragma unroll
@@ -433,8 +436,9 @@ int linear_impl(const void* x, const void* W, const float* bias, int64_t rows, i
   if (K <= kWsKS * 32) {  // weight-stationary persistent kernel
     const int col_blocks = (N + kWsCols - 1) / kWsCols;
     const long ntiles = (rows + kWsRows - 1) / kWsRows;
-    const long per_block = std::max(1L, (long)kComputeUnits / col_blocks);
-    const dim3 grid(col_blocks, (unsigned)std::min(ntiles, per_block));
+    long per_block = std::max(1L, (long)kComputeUnits / col_blocks);
+    if (col_blocks > 1 && per_block >= 8) per_block &= ~7L;  // same-XCD placement of the column blocks of a tile
+    const dim3 grid((unsigned)std::min(ntiles, per_block), col_blocks);
     const bool narrow = K <= 96;  // three k-steps: the input projection (80 mel bins)
     auto kernel = ln.y ? (narrow ? k_linear_ws_bf16<true, 3> : k_linear_ws_bf16<true, kWsKS>)
                        : (narrow ? k_linear_ws_bf16<false, 3> : k_linear_ws_bf16<false, kWsKS>);
