@@ -64,16 +64,25 @@ __device__ __forceinline__ void prep_weights_blocks(const WeightPrep& q, int blo
   bf16_t* __restrict__ Wb = q.Wb;
   bf16_t* __restrict__ WbT = q.WbT;
   const int Hd = q.Hd, MD = q.MD, ldW = q.ldW, ldWT = q.ldWT;
-  const long n1 = Wb ? (long)Hd * ldW : 0;
-  const long n2 = WbT ? (long)MD * ldWT : 0;
+  // a thread writes eight consecutive bf16 (one 16-byte store); ldW and ldWT are multiples of 8.
+  // Wb: eight consecutive k of one row.  WbT: eight consecutive n of one column j, with
+  // consecutive threads on consecutive j, so that the strided reads of W coalesce across lanes.
+  const int g1 = ldW / 8, g2 = ldWT / 8;
+  const long n1 = Wb ? (long)Hd * g1 : 0;
+  const long n2 = WbT ? (long)MD * g2 : 0;
   for (long i = block * (long)kThreads + threadIdx.x; i < n1 + n2; i += (long)nblocks * kThreads) {
+    bf16x8 o;
     if (i < n1) {
-      const int n = (int)(i / ldW), k = (int)(i % ldW);
-      Wb[i] = (bf16_t)(k < MD ? W[(long)n * MD + k] : 0.f);
+      const int n = (int)(i / g1), k0 = (int)(i % g1) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(k0 + e < MD ? W[(long)n * MD + k0 + e] : 0.f);
+      *reinterpret_cast<bf16x8*>(Wb + (long)n * ldW + k0) = o;
     } else {
       const long r = i - n1;
-      const int j = (int)(r / ldWT), n = (int)(r % ldWT);
-      WbT[r] = (bf16_t)(n < Hd ? W[(long)n * MD + j] : 0.f);
+      const int j = (int)(r % MD), n0 = (int)(r / MD) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(n0 + e < Hd ? W[(long)(n0 + e) * MD + j] : 0.f);
+      *reinterpret_cast<bf16x8*>(WbT + (long)j * ldWT + n0) = o;
     }
   }
 }
@@ -116,23 +125,33 @@ __global__ __launch_bounds__(kThreads) void k_encode_fwd_bf16(const bf16_t* __re
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const float bias = b_u[0];
   const int eblock = blockIdx.x - prep_blocks, eblocks = gridDim.x - prep_blocks;
-  for (int row = eblock * 4 + wave; row < rows; row += eblocks * 4) {
-    const bf16_t* xr = x + (long)row * D;
-    float s = 0.f;
-    if (VEC) {
-      for (int c = lane * 8; c < D; c += 512) {
+  if (VEC) {
+    // sixteen lanes per row, four rows per wave: a row is 16-byte loads of 256 contiguous bytes per
+    // pass, a lane has all its loads in flight at once, and the reduction is four shuffles
+    const int sub = lane & 15;
+    for (long row = ((long)eblock * 4 + wave) * 4 + (lane >> 4); row < rows; row += (long)eblocks * 16) {
+      const bf16_t* xr = x + row * D;
+      float s = 0.f;
+      for (int c = sub * 8; c < D; c += 128) {
         const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xr + c);
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(w_u + c);
         const f32x4 w1 = *reinterpret_cast<const f32x4*>(w_u + c + 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) s += (float)xv[j] * w0[j] + (float)xv[4 + j] * w1[j];
       }
-    } else {
-      for (int c = lane; c < D; c += 64) s += (float)xr[c] * w_u[c];
-    }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) u[row] = fmaxf(s + bias, 0.f);
+      for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off);
+      if (sub == 0) u[row] = fmaxf(s + bias, 0.f);
+    }
+  } else {
+    for (int row = eblock * 4 + wave; row < rows; row += eblocks * 4) {
+      const bf16_t* xr = x + (long)row * D;
+      float s = 0.f;
+      for (int c = lane; c < D; c += 64) s += (float)xr[c] * w_u[c];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+      if (lane == 0) u[row] = fmaxf(s + bias, 0.f);
+    }
   }
 }
 
@@ -1209,7 +1228,7 @@ size_t lmufft_wprep_bytes(const lmufft_shape* s) {
 static WeightPrep weight_prep(const lmufft_shape& s, const float* W_h, void* wprep, int* blocks) {
   const WprepLayout l = wprep_layout(s);
   const int MD = s.M + s.D;
-  const long n = (long)s.Hd * l.ldW + (long)MD * l.ldWT;
+  const long n = ((long)s.Hd * l.ldW + (long)MD * l.ldWT) / 8;  // eight elements per thread
   *blocks = min(cdivb(n, kThreads), 2048);
   return WeightPrep{W_h, (bf16_t*)((char*)wprep + l.off_Wb), (bf16_t*)((char*)wprep + l.off_WbT), s.Hd, MD, l.ldW,
                     l.ldWT};
@@ -1257,7 +1276,7 @@ static int forward_bf16_impl(const lmufft_shape* s, const void* x_, const float*
     int prep_blocks = 0;
     WeightPrep prep{nullptr, nullptr, nullptr, 0, 0, 0, 0};
     if (W_h) prep = weight_prep(*s, W_h, wprep, &prep_blocks);
-    const dim3 grid(prep_blocks + min(cdivb(rows, 4), 4096));
+    const dim3 grid(prep_blocks + min(cdivb(rows, vec ? 16 : 4), 4096));
     PROFB("k_encode_fwd_bf16");
     if (vec)
       hipLaunchKernelGGL(k_encode_fwd_bf16<true>, grid, dim3(kThreads), 0, st, x, w_u, b_u, u, (int)rows, s->D, prep,
