@@ -7,6 +7,9 @@
 //   `self.layer_norm(output + residual)` (src/models/lmu_encoder.py:97): the bf16 projection plus
 //   the residual in fp32, torch.nn.LayerNorm statistics in fp32, biased variance.
 //
+// Two kernels: k_linear_ws_bf16 (weight-stationary, K <= 384: every Linear of the encoder; described at
+//   its definition below) and the tiled k_linear_glds_bf16 for longer rows.
+//
 // k_linear_glds_bf16: out[rows][N] = x[rows][K] W[N][K]^T + bias.  Both operands are plain
 //   k-contiguous rows, so they are staged by LDS-DMA (gemm_glds_bf16.h) with no transposition.
 //   Tile 128 rows x 384 columns on eight waves: for N <= 384 every row of x passes through a CU's
