@@ -29,15 +29,13 @@ typedef float attn_f16v __attribute__((ext_vector_type(16)));
 typedef float attn_f4 __attribute__((ext_vector_type(4)));
 typedef __bf16 attn_bf16;
 
-constexpr int kAttnThreads = 256;
 constexpr int kAttnKeys = 32;       // keys per tile
-constexpr int kAttnQBlock = 128;    // queries per workgroup
 
 template <class T>
 __device__ __forceinline__ float attn_ld(const T* p) { return (float)*p; }
 
-template <int DK, class TIO>
-__global__ __launch_bounds__(kAttnThreads, DK <= 64 ? 4 : 1) void k_attention_fwd(const TIO* __restrict__ q, const TIO* __restrict__ k,
+template <int DK, class TIO, int NW>
+__global__ __launch_bounds__(64 * NW, DK <= 64 ? 4 : 1) void k_attention_fwd(const TIO* __restrict__ q, const TIO* __restrict__ k,
                                                                 const TIO* __restrict__ v,
                                                                 const int* __restrict__ lengths,
                                                                 TIO* __restrict__ ctx, int T, int H, int ld,
@@ -55,7 +53,7 @@ __global__ __launch_bounds__(kAttnThreads, DK <= 64 ? 4 : 1) void k_attention_fw
   const int len = lengths ? min(max(lengths[b], 0), T) : T;
   const long base = (long)b * T * C + (long)h * DK;    // context rows are dense
   const long ibase = (long)b * T * ld + (long)h * DK;  // q, k, v rows are ld elements apart
-  const int qi = blockIdx.x * kAttnQBlock + wave * 32 + r;  // this lane's query
+  const int qi = blockIdx.x * (32 * NW) + wave * 32 + r;  // this lane's query
   const bool q_in = qi < T, q_valid = qi < len;
 
   // Q[qi][d] for d = s + hh*NS, pre-scaled by 1/sqrt(dk): the B operand of every score step
@@ -72,13 +70,13 @@ __global__ __launch_bounds__(kAttnThreads, DK <= 64 ? 4 : 1) void k_attention_fw
 
   // staging: thread -> (row, 4-float chunk) of the K and V tiles
   constexpr int CH = DK / 4;                       // chunks per row
-  constexpr int NV = kAttnKeys * CH / kAttnThreads;  // chunks per thread and tensor (DK = 64: 2)
-  static_assert(kAttnKeys * CH % kAttnThreads == 0, "whole chunks per thread");
+  constexpr int NV = (kAttnKeys * CH + 64 * NW - 1) / (64 * NW);  // chunks per thread and tensor
   attn_f4 kst[NV], vst[NV];
   auto fetch = [&](int j0) {
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
-      const int idx = tid + n * kAttnThreads, row = idx / CH, c = (idx % CH) * 4;
+      const int idx = tid + n * (64 * NW), row = idx / CH, c = (idx % CH) * 4;
+      if (idx >= kAttnKeys * CH) continue;
       const int j = min(j0 + row, T - 1);  // rows past T are masked below; keep the address valid
       const TIO* kp = k + ibase + (long)j * ld + c;
       const TIO* vp = v + ibase + (long)j * ld + c;
@@ -92,7 +90,8 @@ __global__ __launch_bounds__(kAttnThreads, DK <= 64 ? 4 : 1) void k_attention_fw
   auto stage = [&]() {
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
-      const int idx = tid + n * kAttnThreads, row = idx / CH, c = (idx % CH) * 4;
+      const int idx = tid + n * (64 * NW), row = idx / CH, c = (idx % CH) * 4;
+      if (idx >= kAttnKeys * CH) continue;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         Ks[row * KP + c + e] = kst[n][e];
@@ -157,8 +156,9 @@ __global__ __launch_bounds__(kAttnThreads, DK <= 64 ? 4 : 1) void k_attention_fw
   const float inv = 1.0f / l_run;
   // each wave owns a strip of 8 queries x KP floats of the (now free) K tile and empties its 32
   // queries in four passes
-  constexpr int STRIP = 8 * KP;  // 4 waves x 8 x KP = the K tile
-  float* ws = Ks + wave * STRIP;
+  constexpr int STRIP = 8 * KP;  // 4 waves x 8 x KP = the K tile; waves 4..7 use the V tile (VP > KP) likewise
+  static_assert(NW <= 8, "two tiles hold eight strips");
+  float* ws = (wave < 4 ? Ks : Vs) + (wave & 3) * STRIP;
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
     // queries 8*pass .. 8*pass+7 of this wave
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kAttnThreads, DK <= 64 ? 4 : 1) void k_attention_fw
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private strip: program order suffices
     for (int idx = lane; idx < 8 * DK; idx += 64) {
       const int ql = idx / DK, d = idx % DK;
-      const int qq = blockIdx.x * kAttnQBlock + wave * 32 + pass * 8 + ql;
+      const int qq = blockIdx.x * (32 * NW) + wave * 32 + pass * 8 + ql;
       if (qq < T) ctx[base + (long)qq * C + d] = (TIO)ws[ql * KP + d];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -192,8 +192,8 @@ __global__ __launch_bounds__(kAttnThreads, DK <= 64 ? 4 : 1) void k_attention_fw
 typedef __bf16 attn_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 attn_bf16x4 __attribute__((ext_vector_type(4)));
 
-template <int DK>
-__global__ __launch_bounds__(kAttnThreads, DK <= 64 ? 4 : 1) void k_attention_fwd_bf16(const attn_bf16* __restrict__ q,
+template <int DK, int NW>
+__global__ __launch_bounds__(64 * NW, DK <= 64 ? 4 : 1) void k_attention_fwd_bf16(const attn_bf16* __restrict__ q,
                                                                      const attn_bf16* __restrict__ k,
                                                                      const attn_bf16* __restrict__ v,
                                                                      const int* __restrict__ lengths,
@@ -210,14 +210,14 @@ __global__ __launch_bounds__(kAttnThreads, DK <= 64 ? 4 : 1) void k_attention_fw
   constexpr int OP = DK + 1;          // fp32 output strip pitch
   __shared__ __attribute__((aligned(16))) attn_bf16 Ks[KEYS * KP];
   __shared__ __attribute__((aligned(16))) attn_bf16 Vs[KEYS * VP];
-  __shared__ float Os[4 * 8 * OP];
+  __shared__ float Os[NW * 8 * OP];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
   const int C = H * DK;
   const int len = lengths ? min(max(lengths[b], 0), T) : T;
   const long base = (long)b * T * C + (long)h * DK;    // context rows are dense
   const long ibase = (long)b * T * ld + (long)h * DK;  // q, k, v rows are ld elements apart
-  const int qi = blockIdx.x * kAttnQBlock + wave * 32 + r;
+  const int qi = blockIdx.x * (32 * NW) + wave * 32 + r;
   const bool q_valid = qi < len;
   const int qc = min(qi, T - 1);
 
@@ -238,12 +238,12 @@ __global__ __launch_bounds__(kAttnThreads, DK <= 64 ? 4 : 1) void k_attention_fw
   const int tq = (lane & 15) >> 2, tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
 
   constexpr int CH = DK / 8;                         // 16-byte chunks per key row
-  constexpr int NV = (KEYS * CH + kAttnThreads - 1) / kAttnThreads;
+  constexpr int NV = (KEYS * CH + (64 * NW) - 1) / (64 * NW);
   attn_bf16x8 kst[NV], vst[NV];
   auto fetch = [&](int j0) {
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
-      const int idx = tid + n * kAttnThreads;
+      const int idx = tid + n * (64 * NW);
       if (idx < KEYS * CH) {
         const int row = idx / CH, c = (idx % CH) * 8;
         const int j = min(j0 + row, T - 1);
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(kAttnThreads, DK <= 64 ? 4 : 1) void k_attention_fw
   auto stage = [&]() {
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
-      const int idx = tid + n * kAttnThreads;
+      const int idx = tid + n * (64 * NW);
       if (idx < KEYS * CH) {
         const int row = idx / CH, c = (idx % CH) * 8;
         *reinterpret_cast<attn_bf16x8*>(&Ks[row * KP + c]) = kst[n];
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(kAttnThreads, DK <= 64 ? 4 : 1) void k_attention_fw
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     for (int idx = lane; idx < 8 * DK; idx += 64) {
       const int ql = idx / DK, d = idx % DK;
-      const int qq = blockIdx.x * kAttnQBlock + wave * 32 + pass * 8 + ql;
+      const int qq = blockIdx.x * (32 * NW) + wave * 32 + pass * 8 + ql;
       if (qq < T) ctx[base + (long)qq * C + d] = (attn_bf16)ws[ql * OP + d];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -395,11 +395,22 @@ int lmufft_attention_fwd_ld(const void* q, const void* k, const void* v, int dty
   if (dtype == LMUFFT_BF16 && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) != 0)
     return set_error("attention: bf16 tensors must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((T + kAttnQBlock - 1) / kAttnQBlock, H, B);
+  // Waves (32 queries each) per workgroup: every workgroup sweeps all keys, so the sweeps should be
+  // few and full.  T = 400 is 12.5 wave tiles: four waves per workgroup need four sweeps (the last
+  // for 16 queries), eight need two -- bf16 0.20 -> 0.17 ms at B = 256, and 0.70 -> 0.63 ms at
+  // B = 32, T = 3000.  Five or seven waves (fewer idle wave slots on paper) load the four SIMDs
+  // unevenly and were slower than either.
+  const int nw = (T + 31) / 32 <= 4 ? 4 : 8;
+  const dim3 grid((T + 32 * nw - 1) / (32 * nw), H, B);
   const float scale = 1.0f / sqrtf((float)DK);
-#define ATTN_LAUNCH(DKV, TY)                                                                                   \
-  hipLaunchKernelGGL((k_attention_fwd<DKV, TY>), grid, dim3(kAttnThreads), 0, st, (const TY*)q, (const TY*)k,  \
+#define ATTN_LAUNCH_W(DKV, TY, NWV)                                                                              \
+  hipLaunchKernelGGL((k_attention_fwd<DKV, TY, NWV>), grid, dim3(64 * NWV), 0, st, (const TY*)q, (const TY*)k,   \
                      (const TY*)v, lengths, (TY*)ctx, T, H, (int)ld, scale)
+#define ATTN_LAUNCH(DKV, TY)                   \
+  do {                                         \
+    if (nw == 8) ATTN_LAUNCH_W(DKV, TY, 8);    \
+    else ATTN_LAUNCH_W(DKV, TY, 4);            \
+  } while (0)
   {
     ProfScope ps("k_attention_fwd", st);
     if (dtype == LMUFFT_F32) {
@@ -407,16 +418,23 @@ int lmufft_attention_fwd_ld(const void* q, const void* k, const void* v, int dty
       else if (DK == 64) ATTN_LAUNCH(64, float);
       else ATTN_LAUNCH(128, float);
     } else {
-#define ATTN_LAUNCH_B(DKV)                                                                                       \
-  hipLaunchKernelGGL((k_attention_fwd_bf16<DKV>), grid, dim3(kAttnThreads), 0, st, (const attn_bf16*)q,          \
+#define ATTN_LAUNCH_BW(DKV, NWV)                                                                                  \
+  hipLaunchKernelGGL((k_attention_fwd_bf16<DKV, NWV>), grid, dim3(64 * NWV), 0, st, (const attn_bf16*)q,         \
                      (const attn_bf16*)k, (const attn_bf16*)v, lengths, (attn_bf16*)ctx, T, H, (int)ld, scale)
+#define ATTN_LAUNCH_B(DKV)                    \
+  do {                                        \
+    if (nw == 8) ATTN_LAUNCH_BW(DKV, 8);      \
+    else ATTN_LAUNCH_BW(DKV, 4);              \
+  } while (0)
       if (DK == 32) ATTN_LAUNCH_B(32);
       else if (DK == 64) ATTN_LAUNCH_B(64);
       else ATTN_LAUNCH_B(128);
+#undef ATTN_LAUNCH_BW
 #undef ATTN_LAUNCH_B
     }
   }
 #undef ATTN_LAUNCH
+#undef ATTN_LAUNCH_W
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error("launch of k_attention_fwd failed: %s", hipGetErrorString(e));
   return 0;
