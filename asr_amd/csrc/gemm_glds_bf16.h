@@ -184,7 +184,7 @@ __device__ __forceinline__ void gemm_loop_glds_deep(const OA& a, const OB& b, f3
 // Writes the workgroup's accumulator tile as bf16 rows through LDS so that HBM
 // sees 16-byte stores of whole row segments instead of 2-byte column stores.
 //   value(tm, tn, i, m, n, v)  -> float to store for tile-local (m, n)
-//   out[(row0 + m) * ld + col0 + n], rows < row_limit, cols < col_limit,
+//   out[(row0 + m) * ld + col0 + n], 0 <= rows < row_limit (row0 may be negative), cols < col_limit,
 //   col_limit % 8 == 0 and 16-byte aligned rows (the caller checks); out == NULL: only the LDS image.
 // `lds` needs BM * (BN + 8) * 2 bytes.  Returns with the tile still in LDS
 // (image [BM][BN + 8]) so that callers can copy rows out of it again.
@@ -202,7 +202,7 @@ __device__ __forceinline__ void store_tile_bf16(const f32x16 (&acc)[T::TM][T::TN
     const int m = idx / CH, c = idx % CH;
     const long row = row0 + m;
     const int col = col0 + c * 8;
-    if (out && row < row_limit && col < col_limit)
+    if (out && row >= 0 && row < row_limit && col < col_limit)
       *reinterpret_cast<bf16x8*>(out + row * ld + col) = *reinterpret_cast<const bf16x8*>(&lds[m * LDT + c * 8]);
   }
 }

@@ -187,8 +187,12 @@ __global__ __launch_bounds__(kThreads) void k_conv_fwd_bf16(const float* __restr
   const int n0 = blockIdx.x * TL::BN;
   const int b = blockIdx.y;
   const int tb = gridDim.z - 1 - blockIdx.z;
-  const int t0 = tb * TL::BM;
-  const int kend = min(T, t0 + TL::BM);
+  // The partial tile is the FIRST one (t0 < 0 there, rows before frame 0 are dropped): a tile's
+  // k-loop runs over its causal past, so the short loop goes with the tile that has few frames --
+  // T = 400: tiles end at 16 / 144 / 272 / 400 (1 + 3 + 5 + 7 k-tiles) instead of 128 / 256 / 384 /
+  // 400 (2 + 4 + 6 + 7, the last seven for sixteen frames).
+  const int t0 = tb * TL::BM - (TL::BM - T % TL::BM) % TL::BM;
+  const int kend = t0 + TL::BM;  // <= T by construction
   const int kend_pad = cdiv_dev(kend, TL::BK) * TL::BK;
 
   auto lb = plain_load_b([=](int r, int k) -> bf16x8 {
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_fwd_bf16(const float* __restr
   } else {
     tileb_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
       const int t = t0 + mm, n = n0 + nn;
-      if (t < T && n < M) mb[(long)t * M + n] = (bf16_t)v;
+      if (t >= 0 && t < T && n < M) mb[(long)t * M + n] = (bf16_t)v;
     });
   }
   LMUFFT_STAMP(2, 3);
