@@ -100,6 +100,10 @@ __global__ __launch_bounds__(256) void k_mel_power(const float* __restrict__ wav
   __syncthreads();
 
   const int base = (32 * wv + r) * kMelPitch;  // this lane's frame starts at chunk 32*wv + r
+  // a wave whose 32 frames all lie past the utterance's last frame skips the contractions (its output
+  // rows are written as zeros below); it still takes part in the barriers and the staging.  With
+  // 400 frames per utterance the fourth block holds 16 frames: three of its waves have none.
+  const bool active = f0 + 32 * wv < min(Tb, Tmax);
   f32x16m melacc[3];
 #pragma unroll
   for (int t = 0; t < 3; ++t)
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(256) void k_mel_power(const float* __restrict__ wav
     }
     // MFMA k-step: lanes 0..31 carry n = 2j, 2j+1; lanes 32..63 carry n = 2j+2, 2j+3
 #pragma unroll 2
-    for (int j = 0; j < 102; j += 2) {
+    for (int j = 0; active && j < 102; j += 2) {
       const int n0 = 2 * (j + hh);
       const float xa0 = S[sample_addr(base, n0)], xa1 = S[sample_addr(base, n0 + 1)];
       const float xb0 = S[sample_addr(base, kMelFft - n0)], xb1 = S[sample_addr(base, kMelFft - 1 - n0)];
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(256) void k_mel_power(const float* __restrict__ wav
         phi[i] = rh * rh + ih * ih;
       }
 #pragma unroll
-      for (int mt = 0; mt < 3; ++mt) {
+      for (int mt = 0; active && mt < 3; ++mt) {
         const float* frow = fbS + (32 * mt + r) * kMelFbPitch + 4 * hh;
         if ((fbmask >> (bt * 6 + mt * 2)) & 1u) {
 #pragma unroll
