@@ -61,14 +61,15 @@ constexpr int kLdsS = 0;
 constexpr int kLdsTab = (kMelSamples + 1) & ~1;
 constexpr int kLdsWin = kLdsTab + 2 * kMelFft;
 constexpr int kLdsFb = kLdsWin + kMelW;
-constexpr int kLdsTotal = kLdsFb + kMelFbRows * kMelFbPitch;
-static_assert(kMelFrames * kMelTilePitch <= kMelSamples, "output tile reuses the sample area");
+constexpr int kLdsTotal = kLdsFb + 2 * kMelFbRows * kMelFbPitch;  // one filterbank tile per wave group
+static_assert(2 * kMelFrames * kMelTilePitch <= kMelSamples, "output tile and the exchange tile reuse the sample area");
+constexpr int kMelThreads = 512;  // two groups of four waves: group g takes bin tiles 2g, 2g+1 of the same 128 frames
 
 __device__ __forceinline__ int sample_addr(int base, int n) {  // frame-relative sample n in [0, 400]
   return base + n + (n >= kMelHop ? 1 : 0) + (n >= 2 * kMelHop ? 1 : 0);
 }
 
-__global__ __launch_bounds__(256) void k_mel_power(const float* __restrict__ wave, const int* __restrict__ lengths,
+__global__ __launch_bounds__(kMelThreads) void k_mel_power(const float* __restrict__ wave, const int* __restrict__ lengths,
                                                    long ld_wave, int L, float* __restrict__ mel, int Tmax,
                                                    const char* __restrict__ prep, uint32_t fbmask) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -76,7 +77,10 @@ __global__ __launch_bounds__(256) void k_mel_power(const float* __restrict__ wav
   float2* tab = reinterpret_cast<float2*>(lds + kLdsTab);
   float* win = lds + kLdsWin;
   float* fbS = lds + kLdsFb;
-  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int wv = (tid >> 6) & 3;  // which 32 frames of the block
+  const int grp = tid >> 8;       // which half of the bins (wave-uniform)
+  const int gtid = tid & 255;     // thread index inside the group
   const int b = blockIdx.y, f0 = blockIdx.x * kMelFrames;
   int len = lengths ? lengths[b] : L;
   len = min(max(len, 1), L);
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(256) void k_mel_power(const float* __restrict__ wav
   const float* wb = wave + (long)b * ld_wave;
 
   // samples f0*160 - 200 ... of the centred, reflect-padded utterance
-  for (int q = tid; q < kMelChunks * kMelHop; q += 256) {
+  for (int q = tid; q < kMelChunks * kMelHop; q += kMelThreads) {
     int s = f0 * kMelHop - kMelPad + q;
     if (s < 0) s = -s;
     if (s >= len) s = 2 * (len - 1) - s;
@@ -93,9 +97,9 @@ __global__ __launch_bounds__(256) void k_mel_power(const float* __restrict__ wav
   }
   {
     const float* ptab = reinterpret_cast<const float*>(prep + kPrepTab);
-    for (int i = tid; i < 2 * kMelFft; i += 256) lds[kLdsTab + i] = ptab[i];
+    for (int i = tid; i < 2 * kMelFft; i += kMelThreads) lds[kLdsTab + i] = ptab[i];
     const float* pwin = reinterpret_cast<const float*>(prep + kPrepWin);
-    for (int i = tid; i < kMelW; i += 256) win[i] = pwin[i];
+    for (int i = tid; i < kMelW; i += kMelThreads) win[i] = pwin[i];
   }
   __syncthreads();
 
@@ -110,7 +114,12 @@ __global__ __launch_bounds__(256) void k_mel_power(const float* __restrict__ wav
 #pragma unroll
     for (int i = 0; i < 16; ++i) melacc[t][i] = 0.f;
 
-  for (int pass = 0; pass < 2; ++pass) {
+  // Each group of four waves takes one half of the bins (bin tiles 2 grp, 2 grp + 1) for all 128
+  // frames: two waves per SIMD instead of one hide each other's LDS latency; the two partial mel
+  // sums are added through LDS below.
+  float* fbG = fbS + grp * kMelFbRows * kMelFbPitch;
+  {
+    const int pass = grp;
     f32x16m acc[2][4];
     int idx_e[2], idx_o[2], step[2];
 #pragma unroll
@@ -152,7 +161,7 @@ __global__ __launch_bounds__(256) void k_mel_power(const float* __restrict__ wav
       const int bt = 2 * pass + t;
       __syncthreads();
       const float* pfb = reinterpret_cast<const float*>(prep + kPrepFb) + (size_t)bt * kMelFbRows * 64;
-      for (int i = tid; i < kMelFbRows * 64; i += 256) fbS[(i >> 6) * kMelFbPitch + (i & 63)] = pfb[i];
+      for (int i = gtid; i < kMelFbRows * 64; i += 256) fbG[(i >> 6) * kMelFbPitch + (i & 63)] = pfb[i];
       __syncthreads();
       f32x16m plo, phi;
 #pragma unroll
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(256) void k_mel_power(const float* __restrict__ wav
       }
 #pragma unroll
       for (int mt = 0; active && mt < 3; ++mt) {
-        const float* frow = fbS + (32 * mt + r) * kMelFbPitch + 4 * hh;
+        const float* frow = fbG + (32 * mt + r) * kMelFbPitch + 4 * hh;
         if ((fbmask >> (bt * 6 + mt * 2)) & 1u) {
 #pragma unroll
           for (int i = 0; i < 16; ++i)
@@ -180,19 +189,36 @@ __global__ __launch_bounds__(256) void k_mel_power(const float* __restrict__ wav
     }
   }
 
-  // 10 log10, transposed through LDS (the sample area is free now), rows of 80 floats out
+  // group 1 hands its partial mel sums to group 0 through LDS (the sample area is free now); group 0
+  // adds them, takes 10 log10 and lays the tile out as rows of 80 floats
   __syncthreads();
   float* tile = S;
+  float* xch = S + kMelFrames * kMelTilePitch;
+  if (grp == 1) {
 #pragma unroll
-  for (int mt = 0; mt < 3; ++mt)
+    for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int c = 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * hh;
-      if (c < kMelN) tile[(32 * wv + r) * kMelTilePitch + c] = 10.0f * log10f(fmaxf(melacc[mt][i], 1e-10f));
-    }
+      for (int i = 0; i < 16; ++i) {
+        const int c = 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        if (c < kMelN) xch[(32 * wv + r) * kMelTilePitch + c] = melacc[mt][i];
+      }
+  }
+  __syncthreads();
+  if (grp == 0) {
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int c = 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        if (c < kMelN) {
+          const int at = (32 * wv + r) * kMelTilePitch + c;
+          tile[at] = 10.0f * log10f(fmaxf(melacc[mt][i] + xch[at], 1e-10f));
+        }
+      }
+  }
   __syncthreads();
   float* mb = mel + (long)b * Tmax * kMelN;
-  for (int idx = tid; idx < kMelFrames * kMelN; idx += 256) {
+  for (int idx = tid; idx < kMelFrames * kMelN; idx += kMelThreads) {
     const int f = idx / kMelN, c = idx % kMelN, t = f0 + f;
     if (t < Tmax) mb[(long)t * kMelN + c] = t < Tb ? tile[f * kMelTilePitch + c] : 0.f;
   }
@@ -329,7 +355,7 @@ int lmufft_mel_forward_f32(const float* wave, const int32_t* lengths, int32_t B,
     return set_error("cannot reserve %zu bytes of LDS for k_mel_power", lds);
   {
     ProfScope ps("k_mel_power", st);
-    hipLaunchKernelGGL(k_mel_power, dim3((Tmax + kMelFrames - 1) / kMelFrames, B), dim3(256), lds, st, wave, lengths,
+    hipLaunchKernelGGL(k_mel_power, dim3((Tmax + kMelFrames - 1) / kMelFrames, B), dim3(kMelThreads), lds, st, wave, lengths,
                        (long)ld_wave, L, mel, Tmax, (const char*)melprep, mc.fbmask);
   }
   hipError_t e = hipGetLastError();
