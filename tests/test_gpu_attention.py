@@ -25,6 +25,9 @@ CASES = [
     (1, 200, 2, 128, [150]),
     (2, 70, 2, 64, [0, 70]),       # an empty utterance: every row attends uniformly
     (1, 1, 1, 32, [1]),
+    (2, 128, 2, 64, None),         # exactly four wave tiles: the four-wave workgroup
+    (1, 257, 2, 64, [257]),        # eight-wave workgroups, the second with one query
+    (2, 520, 2, 128, [520, 300]),  # eight waves at the widest head
 ]
 
 
