@@ -224,10 +224,12 @@ __global__ __launch_bounds__(kMelThreads) void k_mel_power(const float* __restri
   }
 }
 
-// grid (5, B): 16 mel bins per block; thread = (bin c, row group g of 16)
-__global__ __launch_bounds__(256) void k_mel_norm(float* __restrict__ mel, const int* __restrict__ lengths, int L,
+// grid (5, B): 16 mel bins per block; thread = (bin c, row group g of kMelNormGroups): 1024 threads, so that a
+// 30 s utterance (3000 frames) is 47 rows per thread and pass rather than 188
+constexpr int kMelNormGroups = 64;
+__global__ __launch_bounds__(16 * kMelNormGroups) void k_mel_norm(float* __restrict__ mel, const int* __restrict__ lengths, int L,
                                                   int Tmax) {
-  __shared__ float red[16][17];
+  __shared__ float red[kMelNormGroups][17];
   __shared__ float stat[2][16];
   const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
   const int b = blockIdx.y, c0 = blockIdx.x * 16;
@@ -236,19 +238,19 @@ __global__ __launch_bounds__(256) void k_mel_norm(float* __restrict__ mel, const
   const int Tb = min(1 + len / kMelHop, Tmax);
   float* mb = mel + (long)b * Tmax * kMelN + c0 + c;
   float s = 0.f;
-  for (int t = g; t < Tb; t += 16) s += mb[(long)t * kMelN];
+  for (int t = g; t < Tb; t += kMelNormGroups) s += mb[(long)t * kMelN];
   red[g][c] = s;
   __syncthreads();
   if (g == 0) {
     float tot = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) tot += red[i][c];
+    for (int i = 0; i < kMelNormGroups; ++i) tot += red[i][c];
     stat[0][c] = tot / (float)Tb;
   }
   __syncthreads();
   const float mean = stat[0][c];
   float q = 0.f;
-  for (int t = g; t < Tb; t += 16) {
+  for (int t = g; t < Tb; t += kMelNormGroups) {
     const float d = mb[(long)t * kMelN] - mean;
     q += d * d;
   }
@@ -258,13 +260,13 @@ __global__ __launch_bounds__(256) void k_mel_norm(float* __restrict__ mel, const
   if (g == 0) {
     float tot = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) tot += red[i][c];
+    for (int i = 0; i < kMelNormGroups; ++i) tot += red[i][c];
     float sd = sqrtf(tot / (float)(Tb - 1));  // unbiased, as torch.std (NaN for a single frame, as there)
     stat[1][c] = sd == 0.f ? 1.f : sd;
   }
   __syncthreads();
   const float sd = stat[1][c];
-  for (int t = g; t < Tb; t += 16) mb[(long)t * kMelN] = (mb[(long)t * kMelN] - mean) / sd;
+  for (int t = g; t < Tb; t += kMelNormGroups) mb[(long)t * kMelN] = (mb[(long)t * kMelN] - mean) / sd;
 }
 
 // ---------------------------------------------------------------------------
@@ -363,7 +365,7 @@ int lmufft_mel_forward_f32(const float* wave, const int32_t* lengths, int32_t B,
   if (normalize) {
     {
       ProfScope ps("k_mel_norm", st);
-      hipLaunchKernelGGL(k_mel_norm, dim3(kMelN / 16, B), dim3(256), 0, st, mel, lengths, L, Tmax);
+      hipLaunchKernelGGL(k_mel_norm, dim3(kMelN / 16, B), dim3(16 * kMelNormGroups), 0, st, mel, lengths, L, Tmax);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return set_error("launch of k_mel_norm failed: %s", hipGetErrorString(e));
