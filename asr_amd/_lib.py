@@ -18,7 +18,8 @@ BF16 = 1
 CONV_AUTO = 0
 CONV_TOEPLITZ = 1
 CONV_FFT = 2
-ABI_VERSION = 5
+NOALLOC_SCRATCH_BYTES = 8 << 20
+ABI_VERSION = 6
 
 
 class Shape(ctypes.Structure):
@@ -62,6 +63,8 @@ def _load():
     lib.lmufft_conv_forward_f32.argtypes = [sp, vp, vp, vp, vp, ci, vp, sz, vp]
     lib.lmufft_conv_backward_f32.restype = ci
     lib.lmufft_conv_backward_f32.argtypes = [sp, vp, vp, vp, vp, ci, vp, sz, vp]
+    lib.lmufft_conv_backward_noalloc_f32.restype = ci
+    lib.lmufft_conv_backward_noalloc_f32.argtypes = [sp, vp, vp, vp, vp, ci, vp]
     lib.lmufft_melprep_bytes.restype = sz
     lib.lmufft_melprep_bytes.argtypes = []
     lib.lmufft_melprep.restype = ci
@@ -133,6 +136,7 @@ EXPORTS = (
     "lmufft_conv_workspace_bytes",
     "lmufft_conv_forward_f32",
     "lmufft_conv_backward_f32",
+    "lmufft_conv_backward_noalloc_f32",
     "lmufft_fftprep_bytes",
     "lmufft_fftprep_f32",
     "lmufft_melprep_bytes",

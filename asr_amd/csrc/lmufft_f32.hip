@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <type_traits>
 
 #include "gemm_core_f32.h"
@@ -832,6 +833,57 @@ int lmufft_conv_backward_f32(const lmufft_shape* s, const float* gm, const float
     return fft_conv_backward(*s, gm, fftprep, nullptr, gu, workspace, st);
   }
   return conv_backward_toeplitz(*s, gm, H, nullptr, (float*)workspace, gu, st);
+}
+
+// ---------------------------------------------------------------------------
+// Allocation-free variant of lmufft_conv_backward_f32: the partial slabs (Toeplitz route) or
+// partial spectra (FFT route) live in a file-scope device array instead of a caller workspace.
+// Host code never passes the array's NAME to a kernel or a runtime call -- on the host that symbol
+// is a stand-in, not a device address; the address is asked for once per device and kept.
+// ---------------------------------------------------------------------------
+static __device__ __align__(256) unsigned char g_noalloc_scratch[LMUFFT_NOALLOC_SCRATCH_BYTES];
+static constexpr int kNoAllocMaxDevices = 64;
+static void* g_noalloc_ptr[kNoAllocMaxDevices];  // per device: address of ITS copy of the array
+static std::mutex g_noalloc_mutex;
+
+// Address of the current device's scratch array (looked up on the first call on that device).
+static int noalloc_scratch(void** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return set_error("noalloc: hipGetDevice failed: %s", hipGetErrorString(e));
+  if (dev < 0 || dev >= kNoAllocMaxDevices) return set_error("noalloc: device ordinal %d out of range", dev);
+  std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+  if (!g_noalloc_ptr[dev]) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_noalloc_scratch));
+    if (e != hipSuccess || !p)
+      return set_error("noalloc: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+    g_noalloc_ptr[dev] = p;
+  }
+  *out = g_noalloc_ptr[dev];
+  return 0;
+}
+
+int lmufft_conv_backward_noalloc_f32(const lmufft_shape* s, const float* gm, const float* H, const void* fftprep,
+                                     float* gu, int conv_algo, void* stream) {
+  if (!s || s->B <= 0 || s->T <= 0 || s->M <= 0) return set_error("conv: bad shape");
+  if (s->T > s->ldH) return set_error("sequence length %d exceeds the impulse response length %d", s->T, s->ldH);
+  if (!gm || !H || !gu) return set_error("conv: NULL pointer");
+  if (int rc = check_algo(*s, conv_algo, fftprep)) return rc;
+  const size_t need = lmufft_conv_workspace_bytes(s, LMUFFT_F32, conv_algo);
+  if (need > (size_t)LMUFFT_NOALLOC_SCRATCH_BYTES)
+    return set_error("conv backward (no-alloc): this shape needs %zu bytes of scratch, the built-in buffer holds %zu; "
+                     "use lmufft_conv_backward_f32 with a workspace",
+                     need, (size_t)LMUFFT_NOALLOC_SCRATCH_BYTES);
+  void* scratch = nullptr;
+  if (int rc = noalloc_scratch(&scratch)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  // Nothing in the scratch has to start at zero: both routes write every partial they later read
+  // (k_conv_bwd writes diagonals 0..send-1 of each slab and k_gu_reduce reads only those; the FFT
+  // kernels write every partial spectrum of the call's shape), so the previous call's contents
+  // are simply overwritten.
+  if (use_fft(*s, conv_algo, fftprep)) return fft_conv_backward(*s, gm, fftprep, nullptr, gu, scratch, st);
+  return conv_backward_toeplitz(*s, gm, H, nullptr, (float*)scratch, gu, st);
 }
 
 int lmufft_forward_f32(const lmufft_shape* s, const float* x, const float* w_u, const float* b_u,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMUFFT_ABI_VERSION 5
+#define LMUFFT_ABI_VERSION 6
 
 /* element types of the activations (x, h, gh, gx, m) */
 #define LMUFFT_F32 0
@@ -108,6 +108,27 @@ int lmufft_conv_forward_f32(const lmufft_shape* s, const float* u, const float* 
 int lmufft_conv_backward_f32(const lmufft_shape* s, const float* gm, const float* H,
                              const void* fftprep, float* gu, int conv_algo,
                              void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Allocation-free form of lmufft_conv_backward_f32.  It has no counterpart in
+ * the reference; it exists for callers that cannot allocate device memory or
+ * carry a workspace: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  Same arguments and result as
+ * lmufft_conv_backward_f32 minus the workspace: the partial slabs / partial
+ * spectra live in a device array of LMUFFT_NOALLOC_SCRATCH_BYTES that is part
+ * of the library's code object (every GPU the library runs on holds its own
+ * copy until the process ends).  The call allocates and frees nothing.
+ *   - shapes whose lmufft_conv_workspace_bytes exceeds
+ *     LMUFFT_NOALLOC_SCRATCH_BYTES are rejected with an error;
+ *   - all calls on one GPU share that GPU's array: calls that overlap in time
+ *     on one GPU (different streams, or threads) race -- serialise them;
+ *   - the device that is current at the call must be the stream's device; the
+ *     first call on a device looks the array's address up (make that call
+ *     outside graph capture).
+ * ---------------------------------------------------------------------- */
+#define LMUFFT_NOALLOC_SCRATCH_BYTES (8u << 20)
+int lmufft_conv_backward_noalloc_f32(const lmufft_shape* s, const float* gm, const float* H,
+                                     const void* fftprep, float* gu, int conv_algo, void* stream);
 
 /* ------------------------------------------------------------------------
  * Spectra of the impulse response for the FFT route (the counterpart of the
