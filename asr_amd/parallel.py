@@ -2,19 +2,31 @@
 
 The layer shards by batch: every rank runs the same kernels on its own
 utterances and the only exchange step is the sum of parameter gradients
-(reference: DistributedDataParallel in scripts/train_flexible.py:285-289).
-Here each bucket (by default one per layer, ~0.9 MB) is a flat fp32 buffer
-whose slices ARE the parameters' .grad tensors, so no pack/unpack copies are
-needed; a bucket's all-reduce is launched as soon as the last of its
-gradients has been accumulated, and overlaps the backward of earlier layers.
-The buckets are consecutive slices of one arena, so a graph-replayed step,
-whose backward runs no Python, exchanges all of them in ONE all-reduce.
+(reference: DistributedDataParallel in scripts/train_flexible.py:285-289, the
+per-GPU batch is total batch / world size, :198-203).  Here each bucket (by
+default one per layer, ~0.9 MB; `bucket_mb` merges consecutive layers) is a
+flat fp32 buffer whose slices ARE the parameters' .grad tensors, so no
+pack/unpack copies are needed.  Three ways to run a step:
+
+  eager, overlap=True   a bucket's all-reduce is launched as soon as the last
+                        of its gradients has been written, and overlaps the
+                        backward of the layers below;
+  eager, deferred       (overlap=False, or inside `accumulate()`): nothing is
+                        launched during the backward(s); finish() exchanges the
+                        whole arena in ONE all-reduce.  This is the mode for
+                        gradient accumulation (several backwards per step);
+  HIP graph replay      capture_step (one graph, one all-reduce after it) or
+                        capture_pipeline (the step cut into segments, one graph
+                        each; the buckets completed by a segment are exchanged
+                        while the next segment's graph runs).
+
 On MI355X `backend="nccl"` is RCCL over xGMI.  Constant buffers (A, B, H,
 fft_H) are never communicated.
 """
 from __future__ import annotations
 
-from typing import Iterable, List, Sequence
+import contextlib
+from typing import Callable, List, Sequence
 
 import torch
 import torch.distributed as dist
@@ -23,83 +35,146 @@ import torch.distributed as dist
 _ALIGN = 64  # every gradient starts on a 256-byte boundary of its bucket (vector stores in the kernels)
 
 
-class GradBuckets:
-    """groups: one entry per bucket, each an iterable of Parameters or an nn.Module.
+def _group_params(grp):
+    module = grp if isinstance(grp, torch.nn.Module) else None
+    params = [p for p in (module.parameters() if module is not None else grp) if p.requires_grad]
+    return module, params
 
-    For an LMUFFT module with fp32 parameters the bucket also becomes the
-    layer's gradient sink: its backward kernels write the gradients into the
-    flat buffer directly.  Every other parameter reaches the buffer through
-    autograd's accumulation into `.grad` (a view of the buffer).
+
+class GradBuckets:
+    """groups: modules and/or iterables of Parameters, in the order their gradients become ready
+    (the last layer of a stack first).
+
+    bucket_mb = None: one bucket per group.  Otherwise consecutive groups are merged into buckets
+    of at most `bucket_mb` MB of gradients (a group larger than that is a bucket of its own;
+    `float("inf")` puts everything into one bucket).
+
+    For an LMUFFT module with fp32 parameters the bucket also becomes the layer's gradient sink:
+    its backward kernels write the gradients into the flat buffer directly.  Every other parameter
+    reaches the buffer through autograd's accumulation into `.grad` (a view of the buffer).
     Every parameter of a bucket must receive a gradient in every step (as with
-    DistributedDataParallel without find_unused_parameters).
+    DistributedDataParallel without find_unused_parameters): finish() raises otherwise.
+    With overlap=True a step has exactly ONE backward: a gradient that arrives for a bucket whose
+    all-reduce has already been launched raises.  Use `with buckets.accumulate():` (or
+    overlap=False) for steps with several backwards.
     """
 
-    def __init__(self, groups: Sequence, process_group=None, average: bool = True, overlap: bool = True):
+    def __init__(self, groups: Sequence, process_group=None, average: bool = True, overlap: bool = True,
+                 bucket_mb=None, exchange_single_rank: bool = False):
         from .functional import GradSink
         from .lmu import LMUFFT
 
         self.group = process_group
         self.average = average
-        # overlap=True: a bucket's all-reduce starts as soon as its gradients are complete, during the
-        # backward.  overlap=False: finish() starts them all -- for steps replayed from a HIP graph,
-        # whose backward runs no Python.
         self.overlap = overlap
+        # run the collectives even in a one-rank group (they change nothing there; used to exercise the
+        # RCCL stream hand-over on a single GPU)
+        self.exchange_single_rank = exchange_single_rank
         self.buckets: List[torch.Tensor] = []
         self._params: List[List[torch.nn.Parameter]] = []
         self._views: List[List[torch.Tensor]] = []
-        self._sinks: List = []
+        self._sinks: List[list] = []        # per bucket: the gradient sinks of its LMUFFT members
+        self._plain: List[List[torch.Tensor]] = []  # per bucket: views fed by autograd accumulation
         self._pending: List[int] = []
+        self._launched: List[bool] = []
         self._handles = []
         self._hooks = []
         self._sunk_modules = []
-        plan = []
+        self._deferred = 0       # depth of accumulate() contexts
+        self._capturing = False  # inside a graph capture: record which buckets complete, launch nothing
+        self._ready_log: List[int] = []
+        self._replay = False     # steps come from graph replays: no Python runs in the backward
+
+        members = []
         for grp in groups:
-            module = grp if isinstance(grp, torch.nn.Module) else None
-            params = [p for p in (module.parameters() if module is not None else grp) if p.requires_grad]
-            if not params:
-                continue
-            offs, n = [], 0
-            for p in params:
-                offs.append(n)
-                n += -(-p.numel() // _ALIGN) * _ALIGN
-            plan.append((module, params, offs, n))
-        # All buckets are slices of ONE allocation when they agree on dtype and device: a step whose
-        # backward ran without Python (graph replay) then exchanges every gradient with a single
-        # all-reduce -- one collective latency instead of one per layer.
-        kinds = {(ps[0].dtype, ps[0].device) for _, ps, _, _ in plan}
+            module, params = _group_params(grp)
+            if params:
+                members.append((module, params, sum(-(-p.numel() // _ALIGN) * _ALIGN for p in params)))
+        # bucket plan
+        plan: List[list] = []
+        cap = None if bucket_mb is None else float(bucket_mb) * (1 << 20)
+        for mem in members:
+            nbytes = mem[2] * mem[1][0].element_size()
+            if (cap is not None and plan and plan[-1][1] + nbytes <= cap
+                    and plan[-1][0][0][1][0].dtype == mem[1][0].dtype
+                    and plan[-1][0][0][1][0].device == mem[1][0].device):
+                plan[-1][0].append(mem)
+                plan[-1][1] += nbytes
+            else:
+                plan.append([[mem], nbytes])
+        # All buckets are slices of ONE allocation when they agree on dtype and device: a deferred
+        # step then exchanges every gradient with a single all-reduce -- one collective latency
+        # instead of one per bucket.
+        kinds = {(mems[0][1][0].dtype, mems[0][1][0].device) for mems, _ in plan}
         self.arena = None
         if len(kinds) == 1:
             (dtype, device), = kinds
-            self.arena = torch.zeros(sum(n for _, _, _, n in plan), dtype=dtype, device=device)
+            self.arena = torch.zeros(sum(m[2] for mems, _ in plan for m in mems), dtype=dtype, device=device)
         start = 0
-        for module, params, offs, n in plan:
+        for mems, _ in plan:
+            n = sum(m[2] for m in mems)
             if self.arena is not None:
-                flat = self.arena[start : start + n]
+                flat = self.arena[start:start + n]
                 start += n
             else:
-                flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
-            views = [flat[o : o + p.numel()].view_as(p) for o, p in zip(offs, params)]
+                flat = torch.zeros(n, dtype=mems[0][1][0].dtype, device=mems[0][1][0].device)
             bi = len(self.buckets)
             self.buckets.append(flat)
-            self._params.append(params)
-            self._views.append(views)
-            self._pending.append(len(params))
-            sink = None
-            if (isinstance(module, LMUFFT) and len(params) == 4
-                    and all(p.dtype == torch.float32 for p in params)):
-                sink = GradSink(params, views, self._make_ready(bi))
-                module.grad_sink = sink
-                self._sunk_modules.append(module)
-            self._sinks.append(sink)
-            for p, v in zip(params, views):
-                p.grad = None if sink is not None else v
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi, v)))
+            all_params, all_views, sinks, plain = [], [], [], []
+            off = 0
+            for module, params, _ in mems:
+                views = []
+                for p in params:
+                    views.append(flat[off:off + p.numel()].view_as(p))
+                    off += -(-p.numel() // _ALIGN) * _ALIGN
+                sink = None
+                if (isinstance(module, LMUFFT) and len(params) == 4
+                        and all(p.dtype == torch.float32 for p in params)):
+                    sink = GradSink(params, views, self._make_ready(bi))
+                    module.grad_sink = sink
+                    self._sunk_modules.append(module)
+                    sinks.append(sink)
+                else:
+                    plain.extend(views)
+                for p, v in zip(params, views):
+                    p.grad = None if sink is not None else v
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi, v)))
+                all_params.extend(params)
+                all_views.extend(views)
+            self._params.append(all_params)
+            self._views.append(all_views)
+            self._sinks.append(sinks)
+            self._plain.append(plain)
+            self._pending.append(len(all_params))
+            self._launched.append(False)
+
+    # -- bookkeeping ------------------------------------------------------------------------
+    def _distributed(self) -> bool:
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_world_size(self.group) > 1 or self.exchange_single_rank
+
+    def _immediate(self) -> bool:
+        return self.overlap and self._deferred == 0
+
+    def _arrived(self, bi: int, count: int) -> None:
+        if self._launched[bi]:
+            raise RuntimeError(
+                f"GradBuckets: a gradient arrived for bucket {bi} after its all-reduce had been launched in this "
+                "step (a second backward, or a layer used twice). Run such steps inside "
+                "`with buckets.accumulate():` or construct GradBuckets(overlap=False); finish() then exchanges "
+                "the accumulated gradients.")
+        if self._pending[bi] > 0:
+            self._pending[bi] = max(0, self._pending[bi] - count)
+            if self._pending[bi] == 0:
+                if self._capturing:
+                    self._ready_log.append(bi)
+                elif self._immediate():
+                    self._launch(bi)
 
     def _make_ready(self, bi: int):
         def ready(count: int):
-            self._pending[bi] -= count
-            if self._pending[bi] == 0:
-                self._launch(bi)
+            self._arrived(bi, count)
 
         return ready
 
@@ -110,69 +185,132 @@ class GradBuckets:
             if g is not None and g.data_ptr() != view.data_ptr():
                 view.copy_(g)
                 param.grad = view
-            if self._pending[bi] > 0:
-                self._pending[bi] -= 1
-                if self._pending[bi] == 0:
-                    self._launch(bi)
+            self._arrived(bi, 1)
 
         return hook
 
-    def _launch(self, bi: int, force: bool = False) -> None:
-        if not (self.overlap or force):
-            return
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            self._handles.append(dist.all_reduce(self.buckets[bi], op=dist.ReduceOp.SUM, group=self.group,
-                                                 async_op=True))
+    def _all_reduce(self, flat: torch.Tensor) -> None:
+        # RCCL averages inside the collective; gloo has no AVG, finish() divides there
+        op = dist.ReduceOp.SUM
+        if self.average and dist.get_backend(self.group) == "nccl":
+            op = dist.ReduceOp.AVG
+        self._handles.append((dist.all_reduce(flat, op=op, group=self.group, async_op=True), flat,
+                              op == dist.ReduceOp.SUM and self.average))
+
+    def _launch(self, bi: int) -> None:
+        self._launched[bi] = True
+        if self._distributed():
+            self._all_reduce(self.buckets[bi])
+
+    # -- step protocol ----------------------------------------------------------------------
+    @contextlib.contextmanager
+    def accumulate(self):
+        """Inside this context no all-reduce is launched during a backward, so a step may run
+        several backwards (gradient accumulation; the reference declares accumulate_grad_batches,
+        src/config/config.py:42).  finish() exchanges the sums."""
+        self._deferred += 1
+        try:
+            yield self
+        finally:
+            self._deferred -= 1
 
     def zero_grad(self) -> None:
-        """Start a step: re-arm the buckets.  Buckets fed by a gradient sink need no
-        clearing (their first backward overwrites); the others are zeroed in place."""
-        for bi, flat in enumerate(self.buckets):
-            sink = self._sinks[bi]
-            if sink is not None:
+        """Start a step: re-arm the buckets.  Parameters fed by a gradient sink need no clearing
+        (their first backward overwrites); the others are zeroed in place."""
+        for bi in range(len(self.buckets)):
+            for sink in self._sinks[bi]:
                 sink.filled = False
-                for p in self._params[bi]:
+                for p in sink.params:
                     p.grad = None
-            else:
-                flat.zero_()
+            for v in self._plain[bi]:
+                v.zero_()
             self._pending[bi] = len(self._params[bi])
+            self._launched[bi] = False
         self._handles = []
 
     def finish(self) -> None:
-        """Wait for the outstanding all-reduces and turn sums into means."""
-        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
-        if not self.overlap and distributed:
-            if self.arena is not None:
-                self._handles.append(dist.all_reduce(self.arena, op=dist.ReduceOp.SUM, group=self.group,
-                                                     async_op=True))
+        """Launch what has not been launched, wait for the all-reduces, turn sums into means."""
+        if not self._replay:
+            missing = [bi for bi in range(len(self.buckets)) if self._pending[bi] > 0]
+            if missing:
+                raise RuntimeError(
+                    f"GradBuckets.finish(): buckets {missing} are incomplete -- "
+                    f"{[self._pending[bi] for bi in missing]} of their parameters received no gradient in this "
+                    "step; every parameter of a bucket must get one (freeze unused parameters with "
+                    "requires_grad_(False) before building the buckets)")
+        todo = [bi for bi in range(len(self.buckets)) if not self._launched[bi]]
+        if todo and self._distributed():
+            if len(todo) == len(self.buckets) and self.arena is not None:
+                self._all_reduce(self.arena)
             else:
-                for bi in range(len(self.buckets)):
-                    self._launch(bi, force=True)
-        for h in self._handles:
+                for bi in todo:
+                    self._all_reduce(self.buckets[bi])
+        for bi in todo:
+            self._launched[bi] = True
+        ws = dist.get_world_size(self.group) if self._distributed() else 1
+        for h, flat, divide in self._handles:
             h.wait()
-        self._handles = []
-        if self.average and distributed:
-            ws = dist.get_world_size(self.group)
-            for flat in ([self.arena] if self.arena is not None else self.buckets):
+            if divide:
                 flat.div_(ws)
+        self._handles = []
 
-    def capture_step(self, fn):
-        """Capture fn() -- forward and backward of one step on static tensors -- into a HIP graph
-        and return a callable that replays it and then exchanges the gradients.  The kernels of
-        this library allocate nothing and launch on the capturing stream; gradients land in the
-        flat buckets, whose addresses are fixed.  Call after a few eager warm-up steps."""
-        self.overlap = False
-        self.zero_grad()
+    # -- HIP graph replay -------------------------------------------------------------------
+    def _capture(self, fn: Callable, first: bool, pool=None):
         graph = torch.cuda.CUDAGraph()
-        # thread_local: calls made meanwhile by other threads (e.g. the process group's watchdog)
-        # neither break nor join the capture
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            fn()
-        self._graph = graph  # keeps the graph's private memory pool alive
+        self._ready_log = []
+        self._capturing = True
+        try:
+            # thread_local: calls made meanwhile by other threads (e.g. the process group's
+            # watchdog) neither break nor join the capture.  The segments share one memory pool:
+            # a later segment reads tensors an earlier one produced.
+            with torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"):
+                if first:
+                    # parameters without a sink receive `grad += g` from autograd: the graph itself
+                    # must clear them, or every replay would add onto the previous step's result
+                    for views in self._plain:
+                        for v in views:
+                            v.zero_()
+                fn()
+        finally:
+            self._capturing = False
+        return graph, list(self._ready_log)
+
+    def capture_step(self, fn: Callable):
+        """Capture fn() -- forward and backward of one step on static tensors -- into a HIP graph
+        and return a callable that replays it and then exchanges the gradients (one all-reduce
+        over the arena).  The kernels of this library allocate nothing and launch on the capturing
+        stream; gradients land in the flat buckets, whose addresses are fixed.  Call after a few
+        eager warm-up steps."""
+        return self.capture_pipeline([fn], overlap=False)
+
+    def capture_pipeline(self, fns: Sequence[Callable], overlap: bool = True):
+        """Capture a step given as consecutive segments fns[0], fns[1], ... (e.g. forward + the last
+        layer's backward, then one backward segment per remaining layer), one HIP graph each.
+        The returned step() replays them in order; with overlap=True the buckets a segment
+        completed are all-reduced (on RCCL's stream) while the following segments run, otherwise
+        one all-reduce follows the last segment.  Every bucket must be completed by some segment."""
+        self.zero_grad()
+        graphs, ready = [], []
+        for i, fn in enumerate(fns):
+            g, r = self._capture(fn, first=(i == 0), pool=graphs[0].pool() if graphs else None)
+            graphs.append(g)
+            ready.append(r)
+        done = sorted(bi for r in ready for bi in r)
+        if done != list(range(len(self.buckets))):
+            raise RuntimeError(f"capture_pipeline: the captured segments completed buckets {done}, "
+                               f"expected all of 0..{len(self.buckets) - 1}")
+        self._graphs = graphs  # keeps the graphs' private memory pools alive
+        self._replay = True
 
         def step():
             self._handles = []
-            graph.replay()
+            for bi in range(len(self.buckets)):
+                self._launched[bi] = False
+            for g, r in zip(graphs, ready):
+                g.replay()
+                if overlap:
+                    for bi in r:
+                        self._launch(bi)
             self.finish()
 
         return step

@@ -6,23 +6,30 @@
 
 One "step" = forward + backward through the encoder's stack of three LMUFFT
 layers (hidden 384, memory 192, theta 1000, 400 frames: the layer shape the
-training-throughput metric is quoted on) on one synthetic batch of 64 utterances per GPU, including the
-data-parallel gradient exchange.  Rank 0 prints ONE JSON line.
+training-throughput metric is quoted on) on one synthetic batch per GPU (64
+utterances; `--workload c3`: 96, the 8-GPU data-parallel configuration), including
+the data-parallel gradient exchange.  Rank 0 prints ONE JSON line.
+
+`--gpus N` with N > 1 and no torchrun environment starts the N ranks itself
+(as child processes, before this process touches a GPU) and exits with their
+status, so both launch forms measure N ranks on RCCL.
+
+`--unit conv` measures the causal convolution and its adjoint alone (the
+conv-only unit of the roofline: (2M+2) * element size bytes per frame).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, spec
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # dense matrix peaks, spec
@@ -31,9 +38,12 @@ MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # dense matrix peaks, spec
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c2_lmu", choices=["c2_lmu", "c3"],
+                    help="c2_lmu: batch 64 per GPU (single-GPU training configuration); c3: batch 96 per GPU "
+                         "(the 8-GPU data-parallel configuration)")
+    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (overrides --workload)")
     ap.add_argument("--frames", type=int, default=400)
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--hidden", type=int, default=384)
@@ -42,10 +52,30 @@ def parse_args():
     ap.add_argument("--conv", default="auto", choices=["auto", "toeplitz", "fft"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"],
                     help="activation / MFMA operand type (fp32 accumulation either way)")
+    ap.add_argument("--unit", default="layer", choices=["layer", "conv"])
+    ap.add_argument("--bucket-mb", type=float, default=None,
+                    help="gradient bucket size in MB (default: one bucket per layer, 0.89 MB; 'inf' = one bucket)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="exchange all gradients in one all-reduce after the backward instead of per bucket "
+                         "behind the remaining backward segments")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying HIP graphs")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 96 if args.workload == "c3" else 64
+    return args
+
+
+def spawn_ranks(args) -> int:
+    """Start the N ranks as children through torch.distributed.run; nothing in this process has
+    touched a GPU yet.  Returns the launcher's exit status."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
 
 
 def kernel_work(name, B, T, D, M, Hd, s=4):
@@ -74,11 +104,27 @@ def kernel_work(name, B, T, D, M, Hd, s=4):
     return table.get(name)
 
 
+def host_threads():
+    """Threads for the CPU baseline: the job's CPU share, not the machine's core count (a GPU box
+    exports its share as OMP_NUM_THREADS; os.cpu_count() there is the whole host)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    env = os.environ.get("OMP_NUM_THREADS")
+    if env and env.isdigit() and int(env) > 0:
+        n = min(n, int(env))
+    return n
+
+
 def cpu_baseline(args, H, seconds):
     """The reference's own route (torch.fft + autograd) timed on the host cores."""
+    import torch
+
     from oracle.lmufft_torch_port import PortLMUFFT
 
-    threads = min(os.cpu_count() or 1, 16)
+    threads = host_threads()
     torch.set_num_threads(threads)
     torch.manual_seed(1234)
     Hc = H.cpu()
@@ -123,6 +169,7 @@ def cpu_baseline(args, H, seconds):
         "value": args.batch * args.frames / med,
         "unit": "frames/s",
         "cores": threads,
+        "host_cpus": os.cpu_count(),
         "kind": "port",
         "sample": f"same workload (batch {args.batch} x {args.frames} frames x {args.layers} layers, fp32, "
                   f"torch.fft route + autograd), median of {len(times)} steps, {med * 1e3:.1f} ms/step",
@@ -130,19 +177,111 @@ def cpu_baseline(args, H, seconds):
     }
 
 
+def read_profile(_lib, steps):
+    kern = _lib.profile_read()
+    return {k: {"avg_us": v[0] / max(v[1], 1) * 1e3, "launches_per_step": v[1] / steps,
+                "total_ms_per_step": v[0] / steps} for k, v in kern.items()}
+
+
+def roofline_of(dom, per_kernel, work, dtype, per_layer_launches):
+    flops, nbytes = work
+    t_hbm = nbytes / (HBM_PEAK_GBS * 1e9)
+    t_mfma = flops / (MFMA_PEAK_TFLOPS[dtype] * 1e12)
+    bound = "hbm" if t_hbm >= t_mfma else "mfma"
+    flops, nbytes = flops / per_layer_launches, nbytes / per_layer_launches  # per launch, like the duration
+    dur_s = per_kernel[dom]["avg_us"] * 1e-6
+    if bound == "mfma":
+        achieved, peak, unit = flops / dur_s / 1e12, MFMA_PEAK_TFLOPS[dtype], "TFLOP/s"
+    else:
+        achieved, peak, unit = nbytes / dur_s / 1e9, HBM_PEAK_GBS, "GB/s"
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get(dom)
+    return {"kernel": dom, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
+            "frac": achieved / peak, "traffic": traffic, "avg_us": per_kernel[dom]["avg_us"],
+            "algorithmic_flops": flops, "algorithmic_bytes": nbytes}
+
+
+def bench_conv(args, dev):
+    """Conv-only unit: causal convolution + adjoint through the C ABI's conv entry points."""
+    import torch
+
+    from asr_amd import _lib
+    from asr_amd import functional as F
+    from asr_amd.lmu import impulse_response, legendre_state_space
+
+    B, T, M = args.batch, args.frames, args.memory
+    A, Bm = legendre_state_space(M, args.theta)
+    H, _ = impulse_response(A, Bm, T)
+    H = H.to(dev)
+    g = torch.Generator(device=dev).manual_seed(1234)
+    u = torch.relu(torch.randn(B, T, device=dev, generator=g))
+    esize = 2 if args.dtype == "bf16" else 4
+    routes = ["toeplitz"] if args.dtype == "bf16" else (["toeplitz", "fft"] if F.fft_supported(T, M) else ["toeplitz"])
+    out = {}
+    for route in routes:
+        run = F.conv_pair_runner(u, H, route, args.dtype)  # preallocated outputs and workspaces
+        for _ in range(args.warmup):
+            run()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        torch.cuda.synchronize(dev)
+        wall = (time.perf_counter() - t0) / args.steps
+        _lib.profile_reset()
+        _lib.profile_enable(True)
+        for _ in range(10):
+            run()
+        torch.cuda.synchronize(dev)
+        _lib.profile_enable(False)
+        per_kernel = read_profile(_lib, 10)
+        t_k = sum(v["total_ms_per_step"] for v in per_kernel.values()) * 1e-3
+        nbytes = B * T * (2 * M + 2) * esize  # u in, m out; gm in, gu out
+        out[route] = {"wall_us": wall * 1e6, "kernels_us": t_k * 1e6, "algorithmic_bytes": nbytes,
+                      "achieved_GBs": nbytes / t_k / 1e9, "frac": nbytes / t_k / 1e9 / HBM_PEAK_GBS,
+                      "kernels": per_kernel}
+    best = max(out, key=lambda r: out[r]["frac"])
+    return {
+        "metric": "LMU causal convolution fwd+adjoint frames/sec", "value": B * T / (out[best]["kernels_us"] * 1e-6),
+        "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": out[best]["kernels_us"] * 1e-3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"conv-only unit: u[{B},{T}] * H[{M},{T}] -> m and its adjoint, {args.dtype}",
+                   "route": best},
+        "roofline": {"kernel": f"conv fwd+adjoint ({best})", "bound": "hbm", "achieved": out[best]["achieved_GBs"],
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": out[best]["frac"], "traffic": None},
+        "routes": out,
+    }
+
+
 def main():
     args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        raise SystemExit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    world = int(world_env or "1")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
+
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the LMUFFT layer has no CPU path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.unit == "conv":
+        print(json.dumps(bench_conv(args, dev)))
+        return
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=dev)
+        if dist.get_world_size() != args.gpus or dist.get_backend() != "nccl":
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks on {dist.get_backend()}, "
+                             f"expected {args.gpus} on nccl")
 
     from asr_amd import LMUFFT, _lib
     from asr_amd.parallel import GradBuckets
@@ -158,23 +297,41 @@ def main():
         torch.nn.init.zeros_(l.W_u.bias)
         torch.nn.init.zeros_(l.W_h.bias)
         layers.append(l.to(dev))
-    buckets = GradBuckets(list(reversed(layers)))
+    overlap = not args.no_overlap
+    buckets = GradBuckets(list(reversed(layers)), bucket_mb=args.bucket_mb, overlap=overlap)
     g = torch.Generator(device=dev).manual_seed(1234 + 2 + rank)  # each rank its own utterances
     tdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     esize = 2 if args.dtype == "bf16" else 4
     x = torch.randn(B, T, D, device=dev, generator=g).to(tdt).requires_grad_(True)
     gy = torch.randn(B, T, Hd, device=dev, generator=g).to(tdt)
 
-    def fwd_bwd():
+    # The step as segments: [forward of every layer + backward of the last], then one backward
+    # segment per remaining layer.  The layers are chained through detached copies, so each
+    # backward segment is its own autograd call (and its own HIP graph); a layer's gradient
+    # bucket is complete when its segment ends and is exchanged while the next segments run.
+    st = {}
+
+    def seg_first():
+        ins, outs = [], []
         y = x
-        for l in layers:
-            y, _ = l(y)
-        y.backward(gy)
+        for i, l in enumerate(layers):
+            xin = y if i == 0 else y.detach().requires_grad_(True)
+            y, _ = l(xin)
+            ins.append(xin)
+            outs.append(y)
+        st["ins"], st["outs"] = ins, outs
+        outs[-1].backward(gy)
+
+    def seg_back(k):
+        return lambda: st["outs"][k].backward(st["ins"][k + 1].grad)
+
+    segments = [seg_first] + [seg_back(k) for k in range(len(layers) - 2, -1, -1)]
 
     def step_eager():
         buckets.zero_grad()
         x.grad = None
-        fwd_bwd()
+        for s in segments:
+            s()
         buckets.finish()
 
     step = step_eager
@@ -188,15 +345,14 @@ def main():
     for _ in range(max(1, args.warmup if args.no_graph else 3)):
         step_eager()
     if not args.no_graph:
-        # the whole forward+backward as one HIP graph: the step is ~40 short kernels, and launching
-        # them one by one from Python costs about as much as running them
+        # the step replayed from HIP graphs: it is ~30 short kernels, and launching them one by one
+        # from Python costs about as much as running them
         x.grad = None
         try:
-            step = buckets.capture_step(fwd_bwd)
+            step = buckets.capture_pipeline(segments, overlap=overlap)
         except Exception as e:  # fall back to eager launches rather than lose the measurement
             print(f"[bench] HIP graph capture failed ({type(e).__name__}: {e}); launching eagerly", file=sys.stderr)
             args.no_graph = True
-            buckets.overlap = True
             torch.cuda.synchronize(dev)
         for _ in range(args.warmup):
             step()
@@ -213,47 +369,29 @@ def main():
 
     # second, untimed pass with event brackets around every kernel launch
     # (every rank runs it -- the steps contain collectives -- but only rank 0 records events)
-    kern = {}
+    per_kernel = {}
+    psteps = min(args.steps, 10)
     if rank == 0:
         _lib.profile_reset()
         _lib.profile_enable(True)
-    buckets.overlap = True
-    for _ in range(min(args.steps, 10)):
+    buckets._replay = False
+    for _ in range(psteps):
         step_eager()
     torch.cuda.synchronize(dev)
     if rank == 0:
         _lib.profile_enable(False)
-        kern = _lib.profile_read()
+        per_kernel = read_profile(_lib, psteps)
     if world > 1:
         dist.barrier()
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = world * B * T / (elapsed / args.steps)
-        per_kernel = {k: {"avg_us": v[0] / max(v[1], 1) * 1e3, "launches_per_step": v[1] / min(args.steps, 10),
-                          "total_ms_per_step": v[0] / min(args.steps, 10)} for k, v in kern.items()}
         dom = max(per_kernel, key=lambda k: per_kernel[k]["total_ms_per_step"]) if per_kernel else None
         roofline = None
         if dom and kernel_work(dom, B, T, D, M, Hd, esize):
-            flops, nbytes = kernel_work(dom, B, T, D, M, Hd, esize)
-            # which roof is lower for this kernel's algorithmic work, at the spec peaks
-            t_hbm = nbytes / (HBM_PEAK_GBS * 1e9)
-            t_mfma = flops / (MFMA_PEAK_TFLOPS[args.dtype] * 1e12)
-            bound = "hbm" if t_hbm >= t_mfma else "mfma"
-            per_layer = per_kernel[dom]["launches_per_step"] / args.layers  # launches per layer pass
-            flops, nbytes = flops / per_layer, nbytes / per_layer  # per launch, like the duration
-            dur_s = per_kernel[dom]["avg_us"] * 1e-6
-            if bound == "mfma":
-                achieved, peak, unit = flops / dur_s / 1e12, MFMA_PEAK_TFLOPS[args.dtype], "TFLOP/s"
-            else:
-                achieved, peak, unit = nbytes / dur_s / 1e9, HBM_PEAK_GBS, "GB/s"
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get(dom)
-            roofline = {"kernel": dom, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
-                        "frac": achieved / peak, "traffic": traffic, "avg_us": per_kernel[dom]["avg_us"],
-                        "algorithmic_flops": flops, "algorithmic_bytes": nbytes}
+            roofline = roofline_of(dom, per_kernel, kernel_work(dom, B, T, D, M, Hd, esize), args.dtype,
+                                   per_kernel[dom]["launches_per_step"] / args.layers)
         # whole-step view against the layer's algorithmic HBM bytes: (3D+3Hd)*elsize B per frame and layer
         layer_bytes = args.layers * B * T * (3 * D + 3 * Hd) * esize
         t_kern = sum(v["total_ms_per_step"] for v in per_kernel.values()) * 1e-3
@@ -276,7 +414,11 @@ def main():
                             f"accumulation and fp32 parameters, conv={args.conv}; "
                             "training-throughput layer shape",
                 "batch_per_gpu": B, "frames": T, "layers": args.layers, "parallelism": f"dp{world}",
-                "launch": "eager" if args.no_graph else "hip graph replay",
+                "world_size": world, "backend": "nccl (RCCL)" if world > 1 else "none (single rank)",
+                "gradient_buckets": len(buckets.buckets),
+                "bucket_mb": [round(b.numel() * 4 / (1 << 20), 3) for b in buckets.buckets],
+                "exchange": "per bucket, behind the remaining backward segments" if overlap else "one all-reduce after the backward",
+                "launch": "eager" if args.no_graph else f"hip graph replay ({len(segments)} segments)",
             },
             "roofline": roofline,
             "step_hbm": {"algorithmic_bytes_per_step": layer_bytes,
@@ -285,7 +427,7 @@ def main():
                          "frac_of_peak_wall": layer_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
             "kernels": per_kernel,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, layers[0].H, args.cpu_seconds)
         print(json.dumps(out))
     if world > 1:

@@ -1,0 +1,173 @@
+"""GPU tests of the data-parallel step machinery on one rank: HIP-graph replay of a step cut into
+segments, with RCCL (backend "nccl") collectives actually issued in a one-rank group, buckets that
+mix LMUFFT layers with ordinary modules, and the reference's own wrapper, DistributedDataParallel
+(scripts/train_flexible.py:285-289)."""
+import copy
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.fixture()
+def nccl_one_rank():
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        yield dev
+    finally:
+        torch.cuda.synchronize(dev)
+        dist.destroy_process_group()
+
+
+def _close(got, want, what, rtol=2e-2):
+    got = got.detach().float().cpu().numpy().astype(np.float64)
+    want = want.detach().float().cpu().numpy().astype(np.float64)
+    err = np.abs(got - want).max()
+    assert err <= rtol * np.abs(want).max() + 1e-12, (what, err, np.abs(want).max())
+
+
+def _stack(dev, n=3):
+    from asr_amd import LMUFFT
+
+    torch.manual_seed(3)
+    return [LMUFFT(48, 48, 24, 64, 16).to(dev) for _ in range(n)]
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("bucket_mb", [None, float("inf")])
+def test_graph_pipeline_with_rccl_one_rank(nccl_one_rank, overlap, bucket_mb):
+    """capture_pipeline + finish with the all-reduces really issued on RCCL (one-rank group): the
+    replayed, exchanged gradients equal plain autograd's, on three replays in a row."""
+    from asr_amd.parallel import GradBuckets
+
+    dev = nccl_one_rank
+    layers = _stack(dev)
+    ref_layers = copy.deepcopy(layers)
+    buckets = GradBuckets(list(reversed(layers)), bucket_mb=bucket_mb, overlap=overlap, exchange_single_rank=True)
+    x = torch.randn(4, 64, 48, device=dev).requires_grad_(True)
+    gy = torch.randn(4, 64, 48, device=dev)
+    st = {}
+
+    def seg_first():
+        ins, outs = [], []
+        y = x
+        for i, l in enumerate(layers):
+            xin = y if i == 0 else y.detach().requires_grad_(True)
+            y, _ = l(xin)
+            ins.append(xin)
+            outs.append(y)
+        st["ins"], st["outs"] = ins, outs
+        outs[-1].backward(gy)
+
+    segs = [seg_first] + [(lambda k=k: st["outs"][k].backward(st["ins"][k + 1].grad)) for k in (1, 0)]
+    for _ in range(2):  # eager warm-up through the same protocol
+        buckets.zero_grad()
+        x.grad = None
+        for s in segs:
+            s()
+        buckets.finish()
+    x.grad = None
+    step = buckets.capture_pipeline(segs, overlap=overlap)
+    # reference: plain autograd on copies
+    xr = x.detach().clone().requires_grad_(True)
+    y = xr
+    for l in ref_layers:
+        y, _ = l(y)
+    y.backward(gy)
+    for rep in range(3):
+        step()
+        torch.cuda.synchronize(dev)
+        for l, r in zip(layers, ref_layers):
+            for (n, p), q in zip(l.named_parameters(), r.parameters()):
+                _close(p.grad, q.grad, f"{n} replay {rep}", rtol=1e-4)
+        _close(x.grad, xr.grad, f"gx replay {rep}", rtol=1e-4)
+    buckets.remove()
+
+
+def test_graph_replay_mixed_bucket_matches_eager():
+    """A bucket that holds an LMUFFT layer (gradient sink) AND an ordinary Linear head (autograd
+    accumulates `grad += g` into the bucket view): the captured step clears the head's views
+    itself, so replays do not pile up on earlier steps' gradients."""
+    from asr_amd import LMUFFT
+    from asr_amd.parallel import GradBuckets
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    layer = LMUFFT(48, 48, 24, 64, 16).to(dev)
+    head = torch.nn.Linear(48, 7).to(dev)
+    ref_layer, ref_head = copy.deepcopy(layer), copy.deepcopy(head)
+    buckets = GradBuckets([head, layer], bucket_mb=float("inf"))
+    assert len(buckets.buckets) == 1
+    x = torch.randn(3, 64, 48, device=dev)
+    gy = torch.randn(3, 64, 7, device=dev)
+
+    def fn():
+        h, _ = layer(x)
+        head(h).backward(gy)
+
+    for _ in range(2):
+        buckets.zero_grad()
+        fn()
+        buckets.finish()
+    step = buckets.capture_step(fn)
+    h, _ = ref_layer(x)
+    ref_head(h).backward(gy)
+    for rep in range(3):
+        step()
+        torch.cuda.synchronize(dev)
+        for (n, p), q in zip(list(layer.named_parameters()) + list(head.named_parameters()),
+                             list(ref_layer.parameters()) + list(ref_head.parameters())):
+            _close(p.grad, q.grad, f"{n} replay {rep}", rtol=1e-4)
+    buckets.remove()
+
+
+def test_distributed_data_parallel_wrapper_one_rank(nccl_one_rank):
+    """The reference wraps its model in DistributedDataParallel (scripts/train_flexible.py:287);
+    the layer must work under it: ordinary Parameters, gradients through autograd, RCCL buckets."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+
+    dev = nccl_one_rank
+    layers = _stack(dev, 2)
+    model = torch.nn.Sequential()
+    ref = copy.deepcopy(layers)
+
+    class Stack(torch.nn.Module):
+        def __init__(self, ls):
+            super().__init__()
+            self.ls = torch.nn.ModuleList(ls)
+
+        def forward(self, x):
+            for l in self.ls:
+                x, _ = l(x)
+            return x
+
+    del model
+    ddp = DDP(Stack(layers), device_ids=[0], broadcast_buffers=False)
+    x = torch.randn(3, 64, 48, device=dev)
+    gy = torch.randn(3, 64, 48, device=dev)
+    for _ in range(2):
+        ddp.zero_grad(set_to_none=True)
+        ddp(x).backward(gy)
+    y = x
+    for l in ref:
+        y, _ = l(y)
+    y.backward(gy)
+    torch.cuda.synchronize(dev)
+    for l, r in zip(layers, ref):
+        for (n, p), q in zip(l.named_parameters(), r.parameters()):
+            _close(p.grad, q.grad, n, rtol=1e-4)

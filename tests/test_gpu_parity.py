@@ -322,10 +322,13 @@ def test_gradient_sink_matches_autograd_accumulation(dtype):
     for step in range(2):
         a.zero_grad(set_to_none=True)
         buckets.zero_grad()
-        for rep in range(1 + step):  # second step: two backwards accumulate
-            a(x)[0].backward(gh)
-            b(x)[0].backward(gh)
-        buckets.finish()
+        # second step: two backwards accumulate -- legal only in accumulate mode, which keeps the
+        # exchange back until finish()
+        with buckets.accumulate():
+            for rep in range(1 + step):
+                a(x)[0].backward(gh)
+                b(x)[0].backward(gh)
+            buckets.finish()
         for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
             _close(pb.grad.cpu().numpy(), pa.grad.cpu().numpy(), f"{n} step {step}", rtol=1e-5, atol_rel=1e-6)
             assert buckets.buckets[0].data_ptr() <= pb.grad.data_ptr() < buckets.buckets[0].data_ptr() + \

@@ -87,8 +87,43 @@ def _worker(rank, world, port, ret):
                 for p in l.parameters():
                     assert torch.allclose(p.grad, torch.full_like(p, want)), (rank, step)
             assert torch.allclose(head.weight.grad, torch.full_like(head.weight, 3 * want))
+        # two backwards per step (gradient accumulation): only legal in accumulate mode, where the
+        # exchange waits for finish(); the means must cover both backwards of both ranks
+        buckets.overlap = True
+        buckets.zero_grad()
+        with buckets.accumulate():
+            for rep in range(2):
+                head(torch.full((3, 10), float(rank + 1))).sum().backward()
+            for l in reversed(layers):
+                _emulate_layer_backward(l, float(rank + 1))
+                for p in l.parameters():  # the second backward: autograd adds into the same views
+                    p.grad.add_(10.0 * (rank + 1))
+                    for hook in p._post_accumulate_grad_hooks.values():
+                        hook(p)
+            assert not buckets._handles
+            buckets.finish()
+        want = sum(11.0 * (r + 1) for r in range(world)) / world
+        for l in layers:
+            for p in l.parameters():
+                assert torch.allclose(p.grad, torch.full_like(p, want)), rank
+        want_head = 2 * 3 * sum(r + 1 for r in range(world)) / world
+        assert torch.allclose(head.weight.grad, torch.full_like(head.weight, want_head))
         buckets.remove()
         assert all(l.grad_sink is None for l in layers)
+        # merged buckets: the two layers and the head share one flat buffer and one all-reduce
+        merged = GradBuckets(list(reversed(layers)) + [head.parameters()], bucket_mb=float("inf"))
+        assert len(merged.buckets) == 1
+        merged.zero_grad()
+        head(torch.full((3, 10), float(rank + 1))).sum().backward()
+        assert not merged._handles  # the layers' gradients are still missing
+        for l in reversed(layers):
+            _emulate_layer_backward(l, float(rank + 1))
+        assert len(merged._handles) == 1
+        merged.finish()
+        want = sum(r + 1 for r in range(world)) / world
+        assert all(torch.allclose(p.grad, torch.full_like(p, want)) for l in layers for p in l.parameters())
+        assert torch.allclose(head.weight.grad, torch.full_like(head.weight, 3 * want))
+        merged.remove()
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()
@@ -103,6 +138,11 @@ def test_grad_buckets_world2():
     assert dict(ret) == {0: "ok", 1: "ok"}
 
 
+def _fire_hooks(p):
+    for hook in p._post_accumulate_grad_hooks.values():
+        hook(p)
+
+
 def test_grad_buckets_single_process():
     from asr_amd import LMUFFT
     from asr_amd.parallel import GradBuckets
@@ -112,11 +152,48 @@ def test_grad_buckets_single_process():
     b.zero_grad()
     assert all(p.grad is None for p in layer.parameters())
     _emulate_layer_backward(layer, 1.0)
-    # a second backward in the same step goes through autograd's accumulation into the same views
     assert not layer.grad_sink.usable([True] * 4)
-    for p in layer.parameters():
-        p.grad.add_(1.0)
-    b.finish()
+    # overlap mode: the bucket's all-reduce was launched when its last gradient arrived, so a second
+    # backward in the same step (autograd accumulating into the same views) must be refused loudly
+    p0 = next(layer.parameters())
+    p0.grad.add_(1.0)
+    with pytest.raises(RuntimeError, match="accumulate"):
+        _fire_hooks(p0)
+    # accumulate mode: nothing is launched before finish(), any number of backwards is fine
+    b.zero_grad()
+    with b.accumulate():
+        _emulate_layer_backward(layer, 1.0)
+        for p in layer.parameters():
+            p.grad.add_(1.0)
+            _fire_hooks(p)
+        b.finish()
     assert all(torch.equal(p.grad, torch.full_like(p, 2.0)) for p in layer.parameters())
     b.zero_grad()
     assert layer.grad_sink.usable([True] * 4) and not layer.grad_sink.usable([True, True, False, True])
+    # a bucket that did not receive all of its gradients is an error, not a silent skip
+    head = torch.nn.Linear(4, 3)
+    b2 = GradBuckets([head])
+    b2.zero_grad()
+    head.weight.grad.add_(1.0)
+    _fire_hooks(head.weight)  # the bias never gets its gradient
+    with pytest.raises(RuntimeError, match="incomplete"):
+        b2.finish()
+
+
+def test_bucket_plan():
+    from asr_amd import LMUFFT
+    from asr_amd.parallel import GradBuckets
+
+    layers = [LMUFFT(12, 10, 6, 16, 8) for _ in range(4)]
+    per_layer = sum(-(-p.numel() // 64) * 64 for p in layers[0].parameters()) * 4 / (1 << 20)
+    assert len(GradBuckets(layers).buckets) == 4
+    assert len(GradBuckets(layers, bucket_mb=float("inf")).buckets) == 1
+    two = GradBuckets(layers, bucket_mb=2.1 * per_layer)
+    assert len(two.buckets) == 2 and all(len(s) == 2 for s in two._sinks)
+    # every layer keeps its own sink inside the shared bucket, and the views do not overlap
+    ptrs = sorted(v.data_ptr() for vs in two._views for v in vs)
+    assert len(set(ptrs)) == len(ptrs) == 16
+    two.zero_grad()
+    for l in layers[:2]:
+        _emulate_layer_backward(l, 1.0)
+    assert two._launched == [True, False]
