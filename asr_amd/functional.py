@@ -88,10 +88,11 @@ class GradSink:
     which adds them into `.grad` -- by then the same tensors.
     """
 
-    def __init__(self, params, views, on_ready):
+    def __init__(self, params, views, on_ready, on_late=None):
         self.params = list(params)  # W_u.weight, W_u.bias, W_h.weight, W_h.bias
         self.views = list(views)    # fp32, contiguous, 16-byte aligned, same shapes
         self.on_ready = on_ready
+        self.on_late = on_late      # called when a further backward of the same step reaches the layer
         self.filled = False
 
     def usable(self, needs) -> bool:
@@ -188,6 +189,8 @@ class _LMUFFTFunction(torch.autograd.Function):
             gh_n = gh_n.to(dt).contiguous()
         gx = torch.empty_like(x) if need_x else None
         sink = ctx.grad_sink
+        if sink is not None and sink.filled and sink.on_late is not None:
+            sink.on_late()  # raises when the bucket has already been handed to the all-reduce
         direct = sink is not None and sink.usable(ctx.needs_input_grad[1:5])
         if direct:
             gw_u, gb_u, gW_h, gb_h = sink.views

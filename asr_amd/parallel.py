@@ -130,7 +130,7 @@ class GradBuckets:
                 sink = None
                 if (isinstance(module, LMUFFT) and len(params) == 4
                         and all(p.dtype == torch.float32 for p in params)):
-                    sink = GradSink(params, views, self._make_ready(bi))
+                    sink = GradSink(params, views, self._make_ready(bi), self._make_late(bi))
                     module.grad_sink = sink
                     self._sunk_modules.append(module)
                     sinks.append(sink)
@@ -138,7 +138,7 @@ class GradBuckets:
                     plain.extend(views)
                 for p, v in zip(params, views):
                     p.grad = None if sink is not None else v
-                    self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi, v)))
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi, v, sink)))
                 all_params.extend(params)
                 all_views.extend(views)
             self._params.append(all_params)
@@ -157,13 +157,16 @@ class GradBuckets:
     def _immediate(self) -> bool:
         return self.overlap and self._deferred == 0
 
-    def _arrived(self, bi: int, count: int) -> None:
+    def _check_open(self, bi: int) -> None:
         if self._launched[bi]:
             raise RuntimeError(
                 f"GradBuckets: a gradient arrived for bucket {bi} after its all-reduce had been launched in this "
                 "step (a second backward, or a layer used twice). Run such steps inside "
                 "`with buckets.accumulate():` or construct GradBuckets(overlap=False); finish() then exchanges "
                 "the accumulated gradients.")
+
+    def _arrived(self, bi: int, count: int) -> None:
+        self._check_open(bi)
         if self._pending[bi] > 0:
             self._pending[bi] = max(0, self._pending[bi] - count)
             if self._pending[bi] == 0:
@@ -178,8 +181,18 @@ class GradBuckets:
 
         return ready
 
-    def _make_hook(self, bi: int, view: torch.Tensor):
+    def _make_late(self, bi: int):
+        return lambda: self._check_open(bi)
+
+    def _make_hook(self, bi: int, view: torch.Tensor, sink=None):
         def hook(param):
+            # A layer whose sink took this step's gradients has been counted by the sink itself.
+            # Autograd may still run this hook for the same backward (it does so although the
+            # layer returned no gradient), and it runs it again when a further backward adds into
+            # the view -- that case is refused, or allowed, where the layer's backward starts
+            # (GradSink.on_late), before any kernel has touched the bucket.
+            if sink is not None and sink.filled:
+                return
             # autograd delivered this gradient itself; make sure it lives in the bucket
             g = param.grad
             if g is not None and g.data_ptr() != view.data_ptr():

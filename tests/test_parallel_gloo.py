@@ -155,14 +155,13 @@ def test_grad_buckets_single_process():
     assert not layer.grad_sink.usable([True] * 4)
     # overlap mode: the bucket's all-reduce was launched when its last gradient arrived, so a second
     # backward in the same step (autograd accumulating into the same views) must be refused loudly
-    p0 = next(layer.parameters())
-    p0.grad.add_(1.0)
     with pytest.raises(RuntimeError, match="accumulate"):
-        _fire_hooks(p0)
+        layer.grad_sink.on_late()  # what the layer's backward calls when it runs again in the same step
     # accumulate mode: nothing is launched before finish(), any number of backwards is fine
     b.zero_grad()
     with b.accumulate():
         _emulate_layer_backward(layer, 1.0)
+        layer.grad_sink.on_late()  # no complaint here
         for p in layer.parameters():
             p.grad.add_(1.0)
             _fire_hooks(p)
