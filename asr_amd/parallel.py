@@ -301,7 +301,10 @@ class GradBuckets:
         layer's backward, then one backward segment per remaining layer), one HIP graph each.
         The returned step() replays them in order; with overlap=True the buckets a segment
         completed are all-reduced (on RCCL's stream) while the following segments run, otherwise
-        one all-reduce follows the last segment.  Every bucket must be completed by some segment."""
+        one all-reduce follows the last segment.  Every bucket must be completed by some segment.
+        Before calling, drop every reference to autograd graphs of earlier eager steps (outputs,
+        losses, detached-boundary tensors): autograd would otherwise reuse their gradient-accumulation
+        nodes, which belong to the eager stream, inside the capture."""
         self.zero_grad()
         graphs, ready = [], []
         for i, fn in enumerate(fns):

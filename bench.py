@@ -347,6 +347,9 @@ def main():
     if not args.no_graph:
         # the step replayed from HIP graphs: it is ~30 short kernels, and launching them one by one
         # from Python costs about as much as running them
+        # no autograd graph of the eager steps may stay alive: its gradient-accumulation nodes belong to
+        # the stream they were made on and would be reused inside the capture
+        st.clear()
         x.grad = None
         try:
             step = buckets.capture_pipeline(segments, overlap=overlap)

@@ -81,6 +81,7 @@ def test_graph_pipeline_with_rccl_one_rank(nccl_one_rank, overlap, bucket_mb):
         for s in segs:
             s()
         buckets.finish()
+    st.clear()  # drop the eager steps' autograd graphs (their accumulation nodes are tied to the eager stream)
     x.grad = None
     step = buckets.capture_pipeline(segs, overlap=overlap)
     # reference: plain autograd on copies
