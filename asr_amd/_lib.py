@@ -19,7 +19,7 @@ CONV_AUTO = 0
 CONV_TOEPLITZ = 1
 CONV_FFT = 2
 NOALLOC_SCRATCH_BYTES = 8 << 20
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class Shape(ctypes.Structure):
@@ -106,6 +106,10 @@ def _load():
     lib.lmufft_forward_bf16.argtypes = [sp] + [vp] * 11 + [ci, vp, sz, vp]
     lib.lmufft_forward_ln_bf16.restype = ci
     lib.lmufft_forward_ln_bf16.argtypes = [sp] + [vp] * 13 + [ctypes.c_float, vp, ci, ci, vp, sz, vp]
+    lib.lmufft_conv_forward_bf16.restype = ci
+    lib.lmufft_conv_forward_bf16.argtypes = [sp, vp, vp, vp, vp]
+    lib.lmufft_conv_backward_bf16.restype = ci
+    lib.lmufft_conv_backward_bf16.argtypes = [sp, vp, vp, vp, vp, sz, vp]
     lib.lmufft_backward_bf16.restype = ci
     lib.lmufft_backward_bf16.argtypes = [sp] + [vp] * 15 + [ci, vp, sz, vp]
     lib.lmufft_profile_enable.restype = ci
@@ -157,6 +161,8 @@ EXPORTS = (
     "lmufft_forward_bf16",
     "lmufft_forward_ln_bf16",
     "lmufft_backward_bf16",
+    "lmufft_conv_forward_bf16",
+    "lmufft_conv_backward_bf16",
     "lmufft_profile_enable",
     "lmufft_profile_reset",
     "lmufft_profile_count",

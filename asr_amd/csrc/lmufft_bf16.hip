@@ -1175,6 +1175,13 @@ static BwdPlanB plan_backward_b(const lmufft_shape& s) {
 }
 
 size_t forward_workspace_bf16(const lmufft_shape&) { return 256; }
+size_t conv_workspace_bf16(const lmufft_shape& s0) {
+  lmufft_shape s = s0;
+  s.D = std::max(s.D, 1);
+  s.Hd = std::max(s.Hd, 1);
+  const BwdPlanB p = plan_backward_b(s);
+  return p.off_ga - p.off_gupart;
+}
 size_t backward_workspace_bf16(const lmufft_shape& s) { return plan_backward_b(s).total; }
 
 #define PROFB(name) ProfScope prof_scope_(name, st)
@@ -1255,6 +1262,31 @@ int lmufft_wprep_bf16(const lmufft_shape* s, const float* W_h, void* wprep, void
 
 }  // extern "C"
 
+// m = causal convolution of u with H (bf16 out)
+static int conv_forward_bf16_any(const lmufft_shape& sh, const float* u, const bf16_t* Hb, int ldHb, bf16_t* m,
+                                 hipStream_t st) {
+  const lmufft_shape* s = &sh;
+  {
+    using TL = ConvFwdTileB;
+    const dim3 grid(cdivb(s->M, TL::BN), s->B, cdivb(s->T, TL::BM));
+    const int kpad = cdivb(s->T, TL::BK) * TL::BK;
+    const size_t lds = std::max(sizeof(bf16_t) * ((size_t)TL::BN * (TL::BK + 8) + (size_t)(kpad / 8 + TL::BM / 8) * 64) +
+                                    sizeof(float) * (size_t)kpad,
+                                sizeof(bf16_t) * (size_t)TL::BM * (TL::BN + 8));  // the epilogue's staging tile
+    if (lds > 160 * 1024) return set_error("sequence too long for the Toeplitz forward kernel (T=%d)", s->T);
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)k_conv_fwd_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+      return set_error("cannot reserve %zu bytes of LDS for k_conv_fwd_bf16", lds);
+    {
+      PROFB("k_conv_fwd_bf16");
+      hipLaunchKernelGGL(k_conv_fwd_bf16, grid, dim3(kThreads), lds, st, u, Hb, m, s->T, s->M, ldHb);
+    }
+    LAUNCH_CHECKB("k_conv_fwd_bf16");
+  }
+  return 0;
+}
+
 static int forward_bf16_impl(const lmufft_shape* s, const void* x_, const float* w_u, const float* b_u, void* wprep,
                              const float* W_h, const float* b_h, const void* hprep, float* u, void* m_, void* h_,
                              void* h_n_, int conv_algo, void* stream, const LnEpilogue& ln) {
@@ -1290,24 +1322,7 @@ static int forward_bf16_impl(const lmufft_shape* s, const void* x_, const float*
                          prep_blocks);
   }
   LAUNCH_CHECKB("k_encode_fwd_bf16");
-  {
-    using TL = ConvFwdTileB;
-    const dim3 grid(cdivb(s->M, TL::BN), s->B, cdivb(s->T, TL::BM));
-    const int kpad = cdivb(s->T, TL::BK) * TL::BK;
-    const size_t lds = std::max(sizeof(bf16_t) * ((size_t)TL::BN * (TL::BK + 8) + (size_t)(kpad / 8 + TL::BM / 8) * 64) +
-                                    sizeof(float) * (size_t)kpad,
-                                sizeof(bf16_t) * (size_t)TL::BM * (TL::BN + 8));  // the epilogue's staging tile
-    if (lds > 160 * 1024) return set_error("sequence too long for the Toeplitz forward kernel (T=%d)", s->T);
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void*)k_conv_fwd_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess)
-      return set_error("cannot reserve %zu bytes of LDS for k_conv_fwd_bf16", lds);
-    {
-      PROFB("k_conv_fwd_bf16");
-      hipLaunchKernelGGL(k_conv_fwd_bf16, grid, dim3(kThreads), lds, st, u, Hb, m, s->T, s->M, hl.ldHb);
-    }
-    LAUNCH_CHECKB("k_conv_fwd_bf16");
-  }
+  if (int rc = conv_forward_bf16_any(*s, u, Hb, hl.ldHb, m, st)) return rc;
   {
     using TL = ProjTileB;
     const bool vec = (s->M % 8 == 0) && (s->D % 8 == 0) && (s->Hd % 8 == 0) && al16(m) && al16(x) && al16(h) &&
@@ -1337,6 +1352,71 @@ static int forward_bf16_impl(const lmufft_shape* s, const void* x_, const float*
                          s->T, s->M, s->D, s->Hd, ldW);
     }
     LAUNCH_CHECKB("k_proj_fwd_bf16");
+  }
+  return 0;
+}
+
+// Adjoint convolution of gm.  Either leaves `ga` = gu * (u > 0) finished (u may be NULL: no mask),
+// or -- when `defer` is set and the slab form ran -- leaves P partial slabs in `gupart` and describes
+// them in *ga_parts for the input-gradient GEMM to sum.
+static int conv_backward_bf16_any(const lmufft_shape& sh, const bf16_t* gm, const HprepLayout& hl, const bf16_t* HbT,
+                                  const BwdPlanB& p, float* gupart, const float* u, float* ga, bool defer,
+                                  GaParts* ga_parts, hipStream_t st) {
+  const lmufft_shape* s = &sh;
+  const long rows = (long)s->B * s->T;
+  const bool dgrad_x_fast = defer;
+  const int KS = cdivb(s->M, 16);
+  if (s->M % 8 == 0 && al16(gm) && (KS == 2 || KS == 4 || KS == 8 || KS == 12 || KS == 16)) {
+    const int P = p.cb2_P;
+    const dim3 grid(P, cdivb(s->T, kCb2St), cdivb(s->B, kCb2Bt));
+    const int Lp_max = cdivb(s->T, P);
+    const size_t lds = (size_t)(Lp_max + kCb2St - 1) * (KS * 16 + 8) * sizeof(bf16_t) +
+                       sizeof(float) * 4 * kCb2Bt * kCb2St;
+    if (lds > 160 * 1024) return set_error("adjoint convolution: LDS window of %zu bytes does not fit", lds);
+#define LAUNCH_CB2(KSV)                                                                                       \
+  do {                                                                                                        \
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)k_conv_bwd2_bf16<KSV>,                             \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+      return set_error("cannot reserve %zu bytes of LDS for k_conv_bwd2_bf16", lds);                          \
+    PROFB("k_conv_bwd_bf16");                                                                                 \
+    hipLaunchKernelGGL(k_conv_bwd2_bf16<KSV>, grid, dim3(kThreads), lds, st, (const bf16_t*)gm, HbT, gupart,   \
+                       s->B, s->T, s->M, hl.ldHT, hl.ldHb, P);                                                \
+  } while (0)
+    switch (KS) {
+      case 2: LAUNCH_CB2(2); break;
+      case 4: LAUNCH_CB2(4); break;
+      case 8: LAUNCH_CB2(8); break;
+      case 12: LAUNCH_CB2(12); break;
+      default: LAUNCH_CB2(16); break;
+    }
+#undef LAUNCH_CB2
+    LAUNCH_CHECKB("k_conv_bwd_bf16");
+    if (dgrad_x_fast && P <= kGaMaxParts) {
+      *ga_parts = GaParts{gupart, u, ga, rows, P};
+    } else {
+      if (int rc = launch_sum_slabs_masked(gupart, u, ga, rows, P, st)) return rc;
+    }
+  } else {
+    using TL = ConvBwdTileB;
+    const dim3 grid(1, s->B, p.ntt);
+    const size_t lds = sizeof(bf16_t) * (size_t)(TL::BM + TL::BN) * (TL::BK + 8) + sizeof(float) * (size_t)p.ntt * TL::BM;
+    if (lds > 160 * 1024) return set_error("sequence too long for the Toeplitz backward kernel (T=%d)", s->T);
+    const bool vec = (s->M % 8 == 0) && al16(gm);
+    const void* fn = vec ? (const void*)k_conv_bwd_bf16<true> : (const void*)k_conv_bwd_bf16<false>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return set_error("cannot reserve %zu bytes of LDS for k_conv_bwd_bf16", lds);
+    {
+      PROFB("k_conv_bwd_bf16");
+      if (vec)
+        hipLaunchKernelGGL(k_conv_bwd_bf16<true>, grid, dim3(kThreads), lds, st, gm, HbT, gupart, s->T, s->M,
+                           hl.ldHT, hl.ldHb);
+      else
+        hipLaunchKernelGGL(k_conv_bwd_bf16<false>, grid, dim3(kThreads), lds, st, gm, HbT, gupart, s->T, s->M,
+                           hl.ldHT, hl.ldHb);
+    }
+    LAUNCH_CHECKB("k_conv_bwd_bf16");
+    if (int rc = launch_gu_reduce(gupart, u, ga, s->B, s->T, p.ntt, TL::BM, st)) return rc;
   }
   return 0;
 }
@@ -1449,59 +1529,7 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
   const bool dgrad_x_fast = gx && (s->Hd % 8 == 0) && (s->D % 8 == 0) && al16(gx);
   GaParts ga_parts = no_parts;
   // ga = (adjoint conv of gm) * (u > 0)
-  const int KS = cdivb(s->M, 16);
-  if (s->M % 8 == 0 && al16(gm) && (KS == 2 || KS == 4 || KS == 8 || KS == 12 || KS == 16)) {
-    const int P = p.cb2_P;
-    const dim3 grid(P, cdivb(s->T, kCb2St), cdivb(s->B, kCb2Bt));
-    const int Lp_max = cdivb(s->T, P);
-    const size_t lds = (size_t)(Lp_max + kCb2St - 1) * (KS * 16 + 8) * sizeof(bf16_t) +
-                       sizeof(float) * 4 * kCb2Bt * kCb2St;
-    if (lds > 160 * 1024) return set_error("adjoint convolution: LDS window of %zu bytes does not fit", lds);
-#define LAUNCH_CB2(KSV)                                                                                       \
-  do {                                                                                                        \
-    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)k_conv_bwd2_bf16<KSV>,                             \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
-      return set_error("cannot reserve %zu bytes of LDS for k_conv_bwd2_bf16", lds);                          \
-    PROFB("k_conv_bwd_bf16");                                                                                 \
-    hipLaunchKernelGGL(k_conv_bwd2_bf16<KSV>, grid, dim3(kThreads), lds, st, (const bf16_t*)gm, HbT, gupart,   \
-                       s->B, s->T, s->M, hl.ldHT, hl.ldHb, P);                                                \
-  } while (0)
-    switch (KS) {
-      case 2: LAUNCH_CB2(2); break;
-      case 4: LAUNCH_CB2(4); break;
-      case 8: LAUNCH_CB2(8); break;
-      case 12: LAUNCH_CB2(12); break;
-      default: LAUNCH_CB2(16); break;
-    }
-#undef LAUNCH_CB2
-    LAUNCH_CHECKB("k_conv_bwd_bf16");
-    if (dgrad_x_fast && P <= kGaMaxParts) {
-      ga_parts = GaParts{gupart, u, ga, rows, P};
-    } else {
-      if (int rc = launch_sum_slabs_masked(gupart, u, ga, rows, P, st)) return rc;
-    }
-  } else {
-    using TL = ConvBwdTileB;
-    const dim3 grid(1, s->B, p.ntt);
-    const size_t lds = sizeof(bf16_t) * (size_t)(TL::BM + TL::BN) * (TL::BK + 8) + sizeof(float) * (size_t)p.ntt * TL::BM;
-    if (lds > 160 * 1024) return set_error("sequence too long for the Toeplitz backward kernel (T=%d)", s->T);
-    const bool vec = (s->M % 8 == 0) && al16(gm);
-    const void* fn = vec ? (const void*)k_conv_bwd_bf16<true> : (const void*)k_conv_bwd_bf16<false>;
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return set_error("cannot reserve %zu bytes of LDS for k_conv_bwd_bf16", lds);
-    {
-      PROFB("k_conv_bwd_bf16");
-      if (vec)
-        hipLaunchKernelGGL(k_conv_bwd_bf16<true>, grid, dim3(kThreads), lds, st, gm, HbT, gupart, s->T, s->M,
-                           hl.ldHT, hl.ldHb);
-      else
-        hipLaunchKernelGGL(k_conv_bwd_bf16<false>, grid, dim3(kThreads), lds, st, gm, HbT, gupart, s->T, s->M,
-                           hl.ldHT, hl.ldHb);
-    }
-    LAUNCH_CHECKB("k_conv_bwd_bf16");
-    if (int rc = launch_gu_reduce(gupart, u, ga, s->B, s->T, p.ntt, TL::BM, st)) return rc;
-  }
+  if (int rc = conv_backward_bf16_any(*s, gm, hl, HbT, p, gupart, u, ga, dgrad_x_fast, &ga_parts, st)) return rc;
   // gx = gz W_h[:, M:] + ga w_u
   if (gx)
     if (int rc = dgrad(DgradXGldsTile{}, DgradXTileB{}, "k_dgrad_x_bf16", gx, s->M, s->D, (const float*)ga, w_u, ga_parts))
@@ -1528,6 +1556,36 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
     if (int rc = launch_reduce_slabs(wslab, p.S, wgrad_outputs(*s, gW_h, gb_h, gw_u, gb_u), st)) return rc;
   }
   return 0;
+}
+
+int lmufft_conv_forward_bf16(const lmufft_shape* s, const float* u, const void* hprep, void* m, void* stream) {
+  if (!s || s->B <= 0 || s->T <= 0 || s->M <= 0) return set_error("conv: bad shape");
+  if (s->T > s->ldH) return set_error("sequence length %d exceeds the impulse response length %d", s->T, s->ldH);
+  if (!u || !hprep || !m) return set_error("conv: NULL pointer");
+  if (!al16(hprep)) return set_error("conv: hprep must be 16-byte aligned");
+  const HprepLayout hl = hprep_layout(s->M, s->ldH);
+  const bf16_t* Hb = (const bf16_t*)((const char*)hprep + hl.off_Hb);
+  return conv_forward_bf16_any(*s, u, Hb, hl.ldHb, (bf16_t*)m, (hipStream_t)stream);
+}
+
+int lmufft_conv_backward_bf16(const lmufft_shape* s, const void* gm, const void* hprep, float* gu, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  if (!s || s->B <= 0 || s->T <= 0 || s->M <= 0) return set_error("conv: bad shape");
+  if (s->T > s->ldH) return set_error("sequence length %d exceeds the impulse response length %d", s->T, s->ldH);
+  if (!gm || !hprep || !gu) return set_error("conv: NULL pointer");
+  if (!al16(hprep)) return set_error("conv: hprep must be 16-byte aligned");
+  lmufft_shape sh = *s;
+  sh.D = std::max(sh.D, 1);
+  sh.Hd = std::max(sh.Hd, 1);
+  const BwdPlanB p = plan_backward_b(sh);
+  const size_t need = p.off_ga - p.off_gupart;
+  if (!workspace || workspace_bytes < need || !al16(workspace))
+    return set_error("conv backward: 16-byte aligned workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+  const HprepLayout hl = hprep_layout(s->M, s->ldH);
+  const bf16_t* HbT = (const bf16_t*)((const char*)hprep + hl.off_HbT);
+  GaParts unused{nullptr, nullptr, nullptr, 0, 0};
+  return conv_backward_bf16_any(sh, (const bf16_t*)gm, hl, HbT, p, (float*)workspace, nullptr, gu, false, &unused,
+                                (hipStream_t)stream);
 }
 
 }  // extern "C"

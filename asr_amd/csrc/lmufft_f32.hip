@@ -488,6 +488,7 @@ __device__ __forceinline__ T pick4(const T* a, int q) {
 }
 __device__ __forceinline__ void slab_store4(const SlabOutputs& o, int seg, long local, const float (&v)[4]) {
   float* dst = pick4(o.out, seg);
+  if (!dst) return;  // a segment whose sum nobody wants
   const long nn = pick4(o.n, seg);
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -786,9 +787,9 @@ size_t lmufft_backward_workspace_bytes(const lmufft_shape* s, int dtype) {
 }
 
 size_t lmufft_conv_workspace_bytes(const lmufft_shape* s, int dtype, int conv_algo) {
-  (void)dtype;
   (void)conv_algo;
   if (!s || s->B <= 0 || s->T <= 0) return 0;
+  if (dtype == LMUFFT_BF16) return s->M > 0 ? conv_workspace_bf16(*s) : 0;
   const int ntt = cdiv(s->T, ConvBwdTile::BM);
   return align256(std::max(sizeof(float) * (size_t)s->B * ntt * s->T, fft_conv_workspace_bytes(*s)));
 }

@@ -45,6 +45,7 @@ int launch_gu_reduce(const float* gu_part, const float* u, float* out, int B, in
 // workspace sizes of the bf16 path (defined in lmufft_bf16.hip)
 size_t forward_workspace_bf16(const lmufft_shape& s);
 size_t backward_workspace_bf16(const lmufft_shape& s);
+size_t conv_workspace_bf16(const lmufft_shape& s);  // scratch of lmufft_conv_backward_bf16
 
 // FFT route of the causal convolution (defined in fft_conv_f32.hip)
 int fft_length(int T);                      // 0 when one transform cannot hold the sequence (2T - 1 > 1024)

@@ -318,3 +318,82 @@ def causal_conv_adjoint(gm, H, conv_algo="auto", fftprep=None):
                                                _ptr(ws), ws.numel(), _stream(gm.device))
     _lib.check(rc, "lmufft_conv_backward_f32")
     return gu
+
+
+def causal_conv_bf16(u, H, hprep=None):
+    """m = causal convolution of u [B, T] (fp32) with H, written as bf16 [B, T, M] by the bf16
+    kernels (no autograd; kernel-level entry point, src/lmu.py:303-312)."""
+    _require_gpu(u, "u")
+    _require_gpu(H, "H")
+    u = u.contiguous().float()
+    B, T = u.shape
+    M, ldH = H.shape
+    if hprep is None:
+        hprep = prepare_impulse_bf16(H)
+    m = torch.empty((B, T, M), dtype=torch.bfloat16, device=u.device)
+    shp = _shape(B, T, 1, M, 1, ldH)
+    with torch.cuda.device(u.device):
+        rc = _lib.lib.lmufft_conv_forward_bf16(ctypes.byref(shp), _ptr(u), _ptr(hprep), _ptr(m), _stream(u.device))
+    _lib.check(rc, "lmufft_conv_forward_bf16")
+    return m
+
+
+def causal_conv_adjoint_bf16(gm, H, hprep=None, workspace=None, out=None):
+    """gu[b,s] = sum_{t>=s} sum_k H[k,t-s] gm[b,t,k] for bf16 gm, fp32 result (no autograd)."""
+    _require_gpu(gm, "gm")
+    _require_gpu(H, "H")
+    if gm.dtype != torch.bfloat16:
+        raise RuntimeError("causal_conv_adjoint_bf16: gm must be bfloat16")
+    gm = gm.contiguous()
+    B, T, M = gm.shape
+    ldH = H.shape[1]
+    if hprep is None:
+        hprep = prepare_impulse_bf16(H)
+    gu = out if out is not None else torch.empty((B, T), dtype=torch.float32, device=gm.device)
+    shp = _shape(B, T, 1, M, 1, ldH)
+    with torch.cuda.device(gm.device):
+        if workspace is None:
+            workspace = _workspace(_lib.lib.lmufft_conv_workspace_bytes(ctypes.byref(shp), _lib.BF16, _lib.CONV_AUTO),
+                                   gm.device)
+        rc = _lib.lib.lmufft_conv_backward_bf16(ctypes.byref(shp), _ptr(gm), _ptr(hprep), _ptr(gu), _ptr(workspace),
+                                                workspace.numel(), _stream(gm.device))
+    _lib.check(rc, "lmufft_conv_backward_bf16")
+    return gu
+
+
+def conv_pair_runner(u, H, conv_algo, dtype):
+    """A callable that runs the causal convolution of u and the adjoint of its result through the
+    C ABI's conv-only entry points with every buffer preallocated (benchmarks)."""
+    dev = u.device
+    B, T = u.shape
+    M, ldH = H.shape
+    shp = _shape(B, T, 1, M, 1, ldH)
+    st = _stream(dev)
+    if dtype == "bf16":
+        hprep = prepare_impulse_bf16(H)
+        m = torch.empty((B, T, M), dtype=torch.bfloat16, device=dev)
+        gu = torch.empty((B, T), dtype=torch.float32, device=dev)
+        ws = _workspace(_lib.lib.lmufft_conv_workspace_bytes(ctypes.byref(shp), _lib.BF16, _lib.CONV_AUTO), dev)
+
+        def run():
+            _lib.check(_lib.lib.lmufft_conv_forward_bf16(ctypes.byref(shp), _ptr(u), _ptr(hprep), _ptr(m), st),
+                       "lmufft_conv_forward_bf16")
+            _lib.check(_lib.lib.lmufft_conv_backward_bf16(ctypes.byref(shp), _ptr(m), _ptr(hprep), _ptr(gu), _ptr(ws),
+                                                         ws.numel(), st), "lmufft_conv_backward_bf16")
+            return m, gu
+
+        return run
+    algo = _ALGOS[conv_algo]
+    fftprep = prepare_impulse_fft(H, T) if conv_algo == "fft" else None
+    m = torch.empty((B, T, M), dtype=torch.float32, device=dev)
+    gu = torch.empty((B, T), dtype=torch.float32, device=dev)
+    ws = _workspace(_lib.lib.lmufft_conv_workspace_bytes(ctypes.byref(shp), _lib.F32, algo), dev)
+
+    def run():
+        _lib.check(_lib.lib.lmufft_conv_forward_f32(ctypes.byref(shp), _ptr(u), _ptr(H), _ptr(fftprep), _ptr(m), algo,
+                                                   _ptr(ws), ws.numel(), st), "lmufft_conv_forward_f32")
+        _lib.check(_lib.lib.lmufft_conv_backward_f32(ctypes.byref(shp), _ptr(m), _ptr(H), _ptr(fftprep), _ptr(gu), algo,
+                                                    _ptr(ws), ws.numel(), st), "lmufft_conv_backward_f32")
+        return m, gu
+
+    return run

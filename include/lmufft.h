@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMUFFT_ABI_VERSION 6
+#define LMUFFT_ABI_VERSION 7
 
 /* element types of the activations (x, h, gh, gx, m) */
 #define LMUFFT_F32 0
@@ -185,6 +185,15 @@ int lmufft_forward_ln_bf16(const lmufft_shape* s, const void* x, const float* w_
                            const float* gamma, const float* beta, float eps, void* y,
                            int y_dtype, int conv_algo, void* workspace,
                            size_t workspace_bytes, void* stream);
+
+/* The bf16 causal convolution (eq. 26, src/lmu.py:303-312) and its adjoint on their own, for
+ * kernel-level parity and roofline measurement: u [B][T] f32 -> m [B][T][M] bf16; gm [B][T][M]
+ * bf16 -> gu [B][T] f32 (unmasked).  Only B, T, M, ldH of the shape are read.  The backward takes
+ * a workspace of lmufft_conv_workspace_bytes(s, LMUFFT_BF16, LMUFFT_CONV_AUTO). */
+int lmufft_conv_forward_bf16(const lmufft_shape* s, const float* u, const void* hprep, void* m,
+                             void* stream);
+int lmufft_conv_backward_bf16(const lmufft_shape* s, const void* gm, const void* hprep, float* gu,
+                              void* workspace, size_t workspace_bytes, void* stream);
 
 int lmufft_backward_bf16(const lmufft_shape* s, const void* x, const float* w_u,
                          const void* wprep, const void* hprep, const float* u,

@@ -206,3 +206,4 @@ def test_bf16_full_size_properties():
     x2[:, 300:] = 0
     h_c, _ = layer(x2)
     assert torch.equal(h_c[:, :300], h.detach()[:, :300])
+
