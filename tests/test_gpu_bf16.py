@@ -16,6 +16,8 @@ from oracle import lmufft_oracle as orc
 pytestmark = pytest.mark.gpu
 
 RTOL = 2e-2
+SLACK = {}  # output name -> worst err / (2e-2 |ref|) over the non-cancelling elements seen so far
+COUNT = {}  # output name -> how many such elements were checked
 
 
 def _dev():
@@ -48,9 +50,20 @@ def _close(got, ref, name, termnorm=None):
         f"max err {err.max():.3e}, rms rel err {rel:.3e}, ref rms {rms:.3e}")
     rms_all = max(rms, float(np.sqrt(np.mean(tn ** 2))))
     assert float(np.sqrt(np.mean(err ** 2))) < 1e-2 * rms_all, f"{name}: rms relative error {rel:.3e}"
+    # The stated bar, as stated: rtol 2e-2 on every element that does not cancel (|value| at least
+    # twice the norm of its terms, so that 2e-2 |value| is about six standard deviations of the bf16
+    # rounding noise).  The worst use of that budget is recorded and reported by
+    # test_zz_bf16_slack_report.
+    plain = (np.abs(ref) >= 2.0 * tn) & (np.abs(ref) > 1e-3 * np.abs(ref).max())
+    if plain.any():
+        used = float(np.max(err[plain] / (RTOL * np.abs(ref[plain]))))
+        key = name.split(" ")[0].split("[")[0]
+        SLACK[key] = max(SLACK.get(key, 0.0), used)
+        COUNT[key] = COUNT.get(key, 0) + int(plain.sum())
+        assert used <= 1.0, f"{name}: a non-cancelling element is off by {used:.2f} x (2e-2 |ref|)"
 
 
-def _termnorms(x, w_u, W_h, H, ref):
+def _termnorms(x, w_u, W_h, H, ref, conv="direct"):
     """sqrt(sum of squared terms) for every output of the layer (see _close); rounding noise of
     intermediate results (gm, gu) is carried along into the sums that consume them."""
     M = ref["m"].shape[2]
@@ -61,11 +74,16 @@ def _termnorms(x, w_u, W_h, H, ref):
     H2 = H[:, :T].astype(np.float64) ** 2
     tn = {}
     # m is itself a (cancelling) sum stored in bf16: carry its own term norm along
-    m2 = m ** 2 + orc.causal_conv_direct(ref["u"] ** 2, H2)
+    if conv == "direct":
+        cconv, ccorr = orc.causal_conv_direct, orc.anticausal_corr_direct
+    else:  # sums of squares through fp64 FFTs: clip the round-off of exact zeros
+        cconv = lambda a, b: np.maximum(orc.causal_conv_fft(np.asarray(a, np.float64), b), 0.0)  # noqa: E731
+        ccorr = lambda a, b: np.maximum(orc.anticausal_corr_fft(a, b), 0.0)  # noqa: E731
+    m2 = m ** 2 + cconv(ref["u"] ** 2, H2)
     tn["h"] = np.sqrt(m2 @ (Wm ** 2).T + (x ** 2) @ (Wx ** 2).T)
     tn["h_n"] = tn["h"][:, -1, :]
     tn_gm2 = (gz ** 2) @ (Wm ** 2)
-    tn_gu2 = orc.anticausal_corr_direct(gm ** 2 + tn_gm2, H2)
+    tn_gu2 = ccorr(gm ** 2 + tn_gm2, H2)
     ga2 = ref["ga"] ** 2 + tn_gu2 * (ref["u"] > 0)
     tn["gx"] = np.sqrt((gz ** 2) @ (Wx ** 2) + ga2[:, :, None] * w2[None, None, :])
     tn["gw_u"] = np.sqrt(np.einsum("bt,btd->d", ga2, x ** 2))[None, :]
@@ -207,3 +225,12 @@ def test_bf16_full_size_properties():
     h_c, _ = layer(x2)
     assert torch.equal(h_c[:, :300], h.detach()[:, :300])
 
+
+
+def test_zz_bf16_slack_report():
+    """How much of the stated rtol 2e-2 the bf16 kernels use on elements that do not cancel, over
+    every comparison this module made (printed with -s; the assertion itself sits in _close)."""
+    assert SLACK, "no comparison recorded: run the whole module"
+    for k in sorted(SLACK):
+        print(f"bf16 {k:6s}: worst err / (2e-2 |ref|) = {SLACK[k]:.3f} over {COUNT[k]} non-cancelling elements")
+    assert max(SLACK.values()) <= 1.0

@@ -119,3 +119,51 @@ def test_round_bf16():
     r = orc.round_bf16(a)
     assert r[0] == 1.0 and r[1] == 1.0 and r[2] == np.float32(1.0078125)
     assert abs(r[3] + 3.140625) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["tiny_f32", "smoke100_f32", "cfg1a_f32", "cfg1c_f32"])
+def test_torch_port_matches_reference(golden_dir, name):
+    """oracle/lmufft_torch_port.py -- what bench.py times as the CPU baseline -- reproduces the
+    reference's own outputs and gradients (it follows the same torch.fft route in fp32, so the gap is
+    fp32 round-off of two runs of the same arithmetic)."""
+    import torch
+
+    from oracle.lmufft_torch_port import PortLMUFFT
+
+    g = _load(golden_dir, name)
+    D, Hd, M = g["x"].shape[2], g["W_h"].shape[0], g["H"].shape[0]
+    layer = PortLMUFFT(D, Hd, M, torch.from_numpy(g["H"]))
+    with torch.no_grad():
+        layer.W_u.weight.copy_(torch.from_numpy(g["w_u"]))
+        layer.W_u.bias.copy_(torch.from_numpy(g["b_u"]))
+        layer.W_h.weight.copy_(torch.from_numpy(g["W_h"]))
+        layer.W_h.bias.copy_(torch.from_numpy(g["b_h"]))
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    h, h_n = layer(x)
+    np.testing.assert_allclose(h.detach().numpy(), g["h"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(h_n.detach().numpy(), g["h_n"], rtol=1e-4, atol=2e-5)
+    loss = (h * torch.from_numpy(g["gh"])).sum()
+    if g["gh_n"].size:
+        loss = loss + (h_n * torch.from_numpy(g["gh_n"])).sum()
+    loss.backward()
+    got = {"gx": x.grad, "gw_u": layer.W_u.weight.grad, "gb_u": layer.W_u.bias.grad,
+           "gW_h": layer.W_h.weight.grad, "gb_h": layer.W_h.bias.grad}
+    for k, v in got.items():
+        ref = g[k]
+        scale = max(1.0, float(np.abs(ref).max()))
+        np.testing.assert_allclose(v.numpy(), ref, rtol=1e-4, atol=2e-5 * scale, err_msg=k)
+
+
+def test_fft_adjoint_equals_direct_adjoint():
+    rng = np.random.default_rng(3)
+    H = rng.standard_normal((7, 90)) * np.exp(-np.arange(90) / 25.0)[None, :]
+    gm = rng.standard_normal((3, 90, 7))
+    a = orc.anticausal_corr_direct(gm, H)
+    b = orc.anticausal_corr_fft(gm, H)
+    np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-11)
+    x = rng.standard_normal((2, 90, 5))
+    args = (x, rng.standard_normal((1, 5)), np.array([0.1]), rng.standard_normal((4, 12)), rng.standard_normal(4), H,
+            rng.standard_normal((2, 90, 4)))
+    d, f = orc.lmufft_backward(*args), orc.lmufft_backward(*args, conv="fft")
+    for k in ("gx", "gw_u", "gb_u", "gW_h", "gb_h", "h"):
+        np.testing.assert_allclose(d[k], f[k], rtol=1e-8, atol=1e-10, err_msg=k)
