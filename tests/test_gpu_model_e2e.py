@@ -51,6 +51,81 @@ def test_full_model_matches_reference(golden_dir):
     assert model.transcribe(spec, lengths) == want
 
 
+def test_full_model_at_benchmark_shape_matches_reference(golden_dir):
+    """The reference's model at the benchmark's shape -- 80 -> 384 / 192, three FFT-LMU layers with
+    6-head attention, 400 frames, vocabulary 34, four utterances of 400 / 400 / 317 / 146 frames
+    (tests/golden/model_c2.npz, made by tests/golden/make_golden_model_c2.py from the reference's own
+    LMUASRModel and decode()): log-probabilities to 1e-3, greedy token lists identical, on both
+    convolution routes of the fp32 layer; and the bf16 run agrees with it on nearly every frame."""
+    from asr_amd.harness import LMUASRModel
+
+    dev = torch.device("cuda:0")
+    g = dict(np.load(os.path.join(golden_dir, "model_c2.npz")))
+    model = LMUASRModel(input_size=80, hidden_size=384, memory_size=192, num_lmu_layers=3, theta=1000.0, seq_len=400,
+                        vocab_size=34, num_attention_heads=6)
+    sd = model.state_dict()  # A and fft_H are this package's own (pinned by buffers_theta1000_M192.npz)
+    given = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}
+    assert set(given) <= set(sd) and {k for k in sd if k not in given} == {
+        f"encoder.lmu_layers.{i}.{b}" for i in range(3) for b in ("A", "fft_H")}
+    for k, v in given.items():
+        assert sd[k].shape == v.shape and sd[k].dtype == v.dtype, k
+    # the module's own impulse response equals the reference's to fp32 round-off of the same recursion
+    assert float((sd["encoder.lmu_layers.0.H"] - given["encoder.lmu_layers.0.H"]).abs().max()) <= 1e-6
+    sd.update(given)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    spec = torch.from_numpy(g["spec"]).to(dev)
+    lengths = torch.from_numpy(g["lengths"]).to(dev)
+    want = [list(map(int, g["tokens"][i, : int(g["counts"][i])])) for i in range(4)]
+    ref = g["log_probs"]
+    valid = (np.arange(400)[None, :] < g["lengths"][:, None])
+    for algo in ("auto", "toeplitz"):
+        for layer in model.encoder.lmu_layers:
+            layer.conv_algo = algo
+        with torch.no_grad():
+            lp, states = model(spec, lengths)
+        assert len(states) == 3 and states[0].shape == (4, 384)
+        err = np.abs(lp.cpu().numpy() - ref)[valid]
+        assert err.max() <= 1e-3 * max(1.0, np.abs(ref).max()), (algo, err.max())
+        assert model.transcribe(spec, lengths) == want, algo
+    # bf16 autocast: the same arg-max on nearly every valid frame
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        lpb = model(spec, lengths)[0].float().cpu().numpy()
+    agree = (lpb.argmax(-1) == ref.argmax(-1))[valid].mean()
+    assert agree > 0.97, agree
+
+
+def test_audio_to_tokens_pipeline_batch256():
+    """The inference configuration at its full batch: 256 utterances of 4 s of raw audio -> mel ->
+    encoder (bf16) -> greedy CTC.  Shape and structural checks (there is no reference output at this
+    size): every utterance decodes on its own -- a permutation of the batch permutes the
+    transcripts -- and padding does not leak: an utterance decoded alone gives the same tokens."""
+    from asr_amd import MelFrontend
+    from asr_amd.harness import LMUASRModel
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(10)
+    model = LMUASRModel(input_size=80, hidden_size=384, memory_size=192, num_lmu_layers=3, theta=1000.0, seq_len=400,
+                        vocab_size=34, num_attention_heads=6).to(dev).eval()
+    with torch.no_grad():
+        model.decoder.ctc_projection.weight.mul_(6.0)
+    g = torch.Generator(device=dev).manual_seed(1234 + 5)
+    wave = 0.1 * torch.randn(256, 63840, device=dev, generator=g)
+    samples = torch.randint(16000, 63841, (256,), device=dev, generator=g)
+    samples[0] = 63840
+    mel, frames = MelFrontend()(wave, samples)
+    assert mel.shape == (256, 400, 80)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        tokens = model.transcribe(mel, frames)
+        perm = torch.randperm(256, device=dev, generator=g)
+        tokens_p = model.transcribe(mel[perm], frames[perm])
+        alone = model.transcribe(mel[37:38, : int(frames[37])].contiguous(), frames[37:38])
+    assert len(tokens) == 256 and all(len(t) <= int(f) for t, f in zip(tokens, frames))
+    assert all(0 <= k < 33 for t in tokens for k in t)
+    assert [tokens[int(i)] for i in perm] == tokens_p
+    assert alone[0] == tokens[37]
+
+
 def test_audio_to_tokens_pipeline():
     """Raw 16 kHz audio in HBM -> mel frontend -> encoder -> greedy CTC, nothing touching the host
     until the token lists (the inference benchmark pipeline at a small batch); bf16 and fp32 runs
