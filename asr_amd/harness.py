@@ -27,6 +27,36 @@ from .ctc import CTCDecoder
 from .lmu import LMUFFT
 
 
+# Which implementation ran: every op of the harness that has both a HIP kernel of this package and a
+# torch formulation counts its calls here ("hip:<op>" / "torch:<op>"), and inside `strict_kernels()`
+# a torch formulation raises instead of running -- so a benchmark cannot silently time hipBLASLt or
+# torch's attention.  (fp32 Linear layers are torch ops by design and are counted as "torch:linear";
+# strict mode therefore only makes sense for bf16 inference, where every op has a kernel here.)
+PATHS: dict = {}
+_STRICT = [False]
+
+
+class strict_kernels:
+    """Context manager: inside it, any harness op that would run as a torch op raises RuntimeError."""
+
+    def __enter__(self):
+        self._old = _STRICT[0]
+        _STRICT[0] = True
+        return self
+
+    def __exit__(self, *exc):
+        _STRICT[0] = self._old
+        return False
+
+
+def _took(kind: str, op: str) -> None:
+    key = f"{kind}:{op}"
+    PATHS[key] = PATHS.get(key, 0) + 1
+    if kind == "torch" and _STRICT[0]:
+        raise RuntimeError(f"asr_amd.harness: `{op}` would run as a torch op here (strict_kernels is on); "
+                           "the HIP kernel needs a GPU tensor, inference mode (no grad) and supported widths / dtypes")
+
+
 def _bf16_inference() -> bool:
     return (not torch.is_grad_enabled() and torch.is_autocast_enabled()
             and torch.get_autocast_dtype("cuda") == torch.bfloat16)
@@ -53,8 +83,11 @@ def _linear(layer: nn.Linear, x: torch.Tensor) -> torch.Tensor:
         w16, b16, b32 = _bf16_params(layer)
         xb = x.to(torch.bfloat16)
         if linear_supported(xb, w16):
+            _took("hip", "linear")
             return linear_bf16(xb, w16, b32)
+        _took("torch", "linear")
         return torch.nn.functional.linear(xb, w16, b16)
+    _took("torch", "linear")
     return layer(x)
 
 
@@ -80,7 +113,9 @@ def _qkv_projection(wq: nn.Linear, wk: nn.Linear, wv: nn.Linear, x: torch.Tensor
         wq.__dict__["_qkv_copy"] = hit
     xd = x.to(dt)
     if bf16 and linear_supported(xd, hit[1]):
+        _took("hip", "qkv_projection")
         return linear_bf16(xd, hit[1], hit[3])
+    _took("torch", "qkv_projection")
     with torch.autocast("cuda", enabled=False):
         return torch.nn.functional.linear(xd, hit[1], hit[2])
 
@@ -92,7 +127,9 @@ def _layer_norm(ln: nn.LayerNorm, x: torch.Tensor, residual: Optional[torch.Tens
     if (x.is_cuda and not torch.is_grad_enabled() and ln.elementwise_affine and ln.bias is not None
             and C % 4 == 0 and C <= _LN_MAX_WIDTH and x.dtype in (torch.float32, torch.bfloat16)
             and (residual is None or residual.dtype in (torch.float32, torch.bfloat16))):
+        _took("hip", "layer_norm")
         return add_layer_norm(x, residual, ln.weight, ln.bias, ln.eps, out_dtype=out_dtype)
+    _took("torch", "layer_norm")
     y = ln(x if residual is None else x + residual)
     return y if out_dtype is None else y.to(out_dtype)
 
@@ -117,6 +154,7 @@ class _MultiHeadAttention(nn.Module):
         B, T, C = x.shape
         if x.is_cuda and self.d_k in SUPPORTED_HEAD_WIDTHS and not torch.is_grad_enabled():
             # HIP kernel: no [B, heads, T, T] score tensor, no per-utterance mask loop
+            _took("hip", "attention")
             if all(l.bias is not None for l in (self.w_q, self.w_k, self.w_v)):
                 # one GEMM for the three projections; the kernel reads q, k, v as column blocks of its output
                 ctx = masked_attention_packed(_qkv_projection(self.w_q, self.w_k, self.w_v, x), self.num_heads, lengths)
@@ -124,6 +162,7 @@ class _MultiHeadAttention(nn.Module):
                 ctx = masked_attention(_linear(self.w_q, x), _linear(self.w_k, x), _linear(self.w_v, x),
                                        self.num_heads, lengths)
             return _linear_layer_norm(self.w_o, ctx, self.layer_norm, x, out_dtype)
+        _took("torch", "attention")
         split = lambda t: t.view(B, T, self.num_heads, self.d_k).transpose(1, 2)  # noqa: E731
         q, k, v = split(self.w_q(x)), split(self.w_k(x)), split(self.w_v(x))
         scores = q @ k.transpose(-2, -1) / math.sqrt(self.d_k)

@@ -126,6 +126,11 @@ class LMUFFT(nn.Module):
         """
         if torch.is_autocast_enabled() and x.is_cuda and torch.get_autocast_dtype("cuda") == torch.bfloat16:
             x = x.to(torch.bfloat16)
+        elif x.dtype == torch.float16:
+            # fp16 autocast is what the reference's trainer runs under (src/training/distributed.py:66,143);
+            # there torch.fft takes the layer to fp32 anyway.  Same here: fp16 activations are widened
+            # and the exact-fp32 kernels run (the result is fp32, as an autocast-to-fp32 op returns).
+            x = x.float()
         hprep = self._impulse_bf16() if (x.is_cuda and x.dtype == torch.bfloat16) else None
         fftprep = None
         if x.is_cuda and x.dtype == torch.float32 and x.dim() == 3:

@@ -191,3 +191,31 @@ def test_cached_bf16_weights_follow_parameter_updates():
         enc.attention_layers[0].attention.w_q.weight.mul_(3.0)  # context is zero whatever the scores are
         b = enc(x, lengths)[0].float()
         assert torch.equal(a, b)
+
+
+def test_strict_kernels_and_fp16_input():
+    """Under bf16 autocast in inference every op of the harness runs a HIP kernel of this package:
+    inside strict_kernels() nothing raises and no torch formulation is counted.  With gradients enabled
+    the same call raises instead of silently timing torch ops.  fp16 activations (the reference
+    trainer's autocast dtype) are widened to fp32 by the layer."""
+    from asr_amd import LMUFFT, harness
+    from asr_amd.harness import LMUASRModel
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    model = LMUASRModel(input_size=80, hidden_size=384, memory_size=192, num_lmu_layers=3, theta=1000.0, seq_len=400,
+                        vocab_size=34, num_attention_heads=6).to(dev).eval()
+    spec = torch.randn(4, 400, 80, device=dev)
+    lengths = torch.tensor([400, 300, 200, 100], device=dev)
+    harness.PATHS.clear()
+    with harness.strict_kernels(), torch.autocast("cuda", dtype=torch.bfloat16):
+        model.transcribe(spec, lengths)
+    assert harness.PATHS and not [k for k in harness.PATHS if k.startswith("torch:")], harness.PATHS
+    with pytest.raises(RuntimeError, match="strict_kernels"):
+        with harness.strict_kernels(), torch.enable_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            model.encoder(spec, lengths)
+    layer = LMUFFT(80, 96, 64, 100, 50.0).to(dev)
+    x = torch.randn(2, 100, 80, device=dev)
+    h16, _ = layer(x.half())
+    h32, _ = layer(x.half().float())
+    assert h16.dtype == torch.float32 and torch.equal(h16, h32)

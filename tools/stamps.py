@@ -1,5 +1,5 @@
 """Per-workgroup timeline of k_wgrad_bf16 from a library built with -DLMUFFT_STAMPS
-(scratch/build_stamps.sh; run with LMUFFT_LIBRARY pointing at it)."""
+(tools/build_stamps.sh; run with LMUFFT_LIBRARY pointing at it)."""
 import ctypes, numpy as np, torch
 from asr_amd import LMUFFT, _lib
 dev = torch.device("cuda:0")
