@@ -28,6 +28,12 @@ def read_checkpoint(path: str) -> Dict:
         raise RuntimeError(f"{path}: expected a dictionary, found {type(ckpt).__name__}")
     if "model_state_dict" not in ckpt:
         ckpt = {"model_state_dict": ckpt}
+    # the reference's single-GPU trainer saves the model as it holds it (src/training/trainer.py:294),
+    # possibly wrapped in DataParallel / DistributedDataParallel: every key then starts with "module."
+    sd = ckpt["model_state_dict"]
+    if sd and all(k.startswith("module.") for k in sd):
+        ckpt = dict(ckpt)
+        ckpt["model_state_dict"] = {k[len("module."):]: v for k, v in sd.items()}
     return ckpt
 
 
@@ -52,7 +58,8 @@ def lmu_layers_from_checkpoint(ckpt: Dict, conv_algo: str = "auto", theta: Optio
         layer = LMUFFT(mem_plus_in - memory, hidden, memory, seq_len, theta if theta is not None else float(seq_len),
                        conv_algo=conv_algo)
         layer.load_state_dict({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)})
-        layer.theta = theta
+        if theta is not None:
+            layer.theta = theta
         layers.append(layer)
     return layers
 

@@ -53,9 +53,19 @@ class MelFrontend:
         B, L = wave.shape
         dev = wave.device
         if lengths is not None:
+            given_on_gpu = lengths.is_cuda
+            host_lengths = lengths
             lengths = lengths.to(device=dev, dtype=torch.int32).contiguous()
             if lengths.shape != (B,):
                 raise RuntimeError(f"MelFrontend: lengths must have shape ({B},), got {tuple(lengths.shape)}")
+            if not given_on_gpu:
+                # lengths that came from the host are checked here; lengths already on the GPU are the
+                # caller's to keep in range (no device-to-host synchronisation on this path)
+                lo, hi = int(host_lengths.min()), int(host_lengths.max())
+                if lo <= self.n_fft // 2 or hi > L:
+                    raise RuntimeError(
+                        f"MelFrontend: every utterance needs more than {self.n_fft // 2} samples (the reflect padding "
+                        f"of the STFT, as torchaudio requires) and at most {L}; got lengths in [{lo}, {hi}]")
         T = self.num_frames(L)
         mel = torch.empty((B, T, self.n_mels), dtype=torch.float32, device=dev)
         prep = self._constants(dev)
@@ -68,7 +78,8 @@ class MelFrontend:
         if lengths is None:
             frames = torch.full((B,), T, dtype=torch.int32, device=dev)
         else:
-            frames = 1 + torch.div(lengths, self.hop_length, rounding_mode="floor")
+            # (the kernel clamps a length to [1, L]; the frame counts follow the same clamp)
+            frames = 1 + torch.div(lengths.clamp(1, L), self.hop_length, rounding_mode="floor")
         return mel, frames
 
     def extract_mel_features(self, waveform: torch.Tensor) -> torch.Tensor:

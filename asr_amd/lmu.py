@@ -101,6 +101,8 @@ class LMUFFT(nn.Module):
         self._fftprep = {}  # T -> (key, spectra of H[:, :T]) for the FFT route
         self.grad_sink = None  # set by asr_amd.parallel.GradBuckets: gradients land in its flat buffer
 
+    _FFTPREP_MAX = 8  # cached FFT-route spectra (one per distinct sequence length)
+
     def _impulse_bf16(self):
         H = self.H
         key = (H.data_ptr(), H._version, H.device, H.dtype)
@@ -113,8 +115,16 @@ class LMUFFT(nn.Module):
         key = (H.data_ptr(), H._version, H.device, H.dtype)
         hit = self._fftprep.get(T)
         if hit is None or hit[0] != key:
+            # spectra of other lengths made from an older H are stale too; and a layer fed batches of
+            # many different lengths keeps the most recent few only (each entry is ~M * N * 8 bytes)
+            for t in [t for t, v in self._fftprep.items() if v[0] != key]:
+                del self._fftprep[t]
+            while len(self._fftprep) >= self._FFTPREP_MAX:
+                del self._fftprep[next(iter(self._fftprep))]
             hit = (key, prepare_impulse_fft(H, T))
-            self._fftprep[T] = hit
+        else:
+            del self._fftprep[T]  # re-insert: most recently used last
+        self._fftprep[T] = hit
         return hit[1]
 
     def forward(self, x):

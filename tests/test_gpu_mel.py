@@ -124,3 +124,12 @@ def test_mel_errors():
         fe(torch.zeros(1, 200, device=dev))
     with pytest.raises(ValueError):
         MelFrontend(n_mels=40)
+    # a ragged batch with an utterance too short for the reflect padding: lengths given from the host are
+    # refused (torchaudio raises for such an utterance too); on the GPU they are clamped, frames with them
+    wave = torch.zeros(3, 4000, device=dev)
+    with pytest.raises(RuntimeError, match="reflect"):
+        fe(wave, torch.tensor([4000, 150, 3000]))
+    with pytest.raises(RuntimeError, match="reflect"):
+        fe(wave, torch.tensor([4000, 4001, 3000]))
+    _, frames = fe(wave, torch.tensor([4000, 0, 3000], device=dev))
+    assert frames.tolist() == [26, 1, 19]
