@@ -10,21 +10,34 @@
 //   0..8000 Hz without normalisation, 10 log10(max(., 1e-10)), then per mel bin
 //   (x - mean_t) / std_t with the unbiased std, std == 0 replaced by 1.
 //
-// k_mel_power: the windowed 400-point real DFT as fp32 MFMA contractions with
-// both symmetries of the real transform folded in.  With y = window * frame,
-//   e[n] = y[n] + y[400-n], o[n] = y[n] - y[400-n]   (n = 0..200),
-//   Re X[k]      =  Ee[k] + Eo[k],   Im X[k]      = -(Oe[k] + Oo[k]),
-//   Re X[200-k]  =  Ee[k] - Eo[k],   Im X[200-k]  =   Oe[k] - Oo[k],
-// where Ee / Eo sum e[n] cos(2 pi k n / 400) over even / odd n and Oe / Oo sum
-// o[n] sin(.) likewise: four products with K ~ 100 and 101 output bins instead
-// of two with K = 400 and 201 bins.  The MFMA output layout (lane = frame,
-// registers = bins) is exactly the B-operand layout of the next contraction, so
-// the power spectrum goes into the mel filterbank product straight from
-// registers.  One wave owns 32 frames; the samples of a block's 128 frames sit
-// in LDS once (hop chunks with an odd pitch: lanes = frames hit distinct banks).
+// k_mel_power: a 400-point real FFT per frame, eight lanes to a frame, in registers and LDS.  The
+// op is HBM-bound by its definition (640 bytes of new samples in, 320 bytes out, ~10 kflop per
+// frame); a dense DFT -- even on the matrix cores -- makes it compute-bound instead.
+//   z[n] = w[2n] x[2n] + i w[2n+1] x[2n+1], n = 0..199, is the windowed frame packed as 200 complex
+//   numbers, Z = FFT_200(z), and the real transform's bins follow from pairs of Z:
+//     E = (Z[k] + conj Z[200-k]) / 2, O = -i (Z[k] - conj Z[200-k]) / 2,
+//     X[k] = E + e^{-2 pi i k / 400} O,  X[200-k] = conj(E - e^{-2 pi i k / 400} O).
+//   With n = r + 8 m and k = k1 + 25 k2:
+//     Z[k1 + 25 k2] = sum_r W_8^{r k2} ( W_200^{r k1} sum_m z[r + 8 m] W_25^{m k1} ).
+//   1. lane r of a frame loads exactly the samples n = r (mod 8), windows them and takes their
+//      25-point DFT in registers (two rounds of radix 5, constants for twiddles);
+//   2. times W_200^{r k1}, out to LDS, the only exchange of the transform;
+//   3. a lane then owns the columns k1 = u and 25 - u: two 8-point DFTs give Z[u + 25 k2] and
+//      Z[(25 - u) + 25 k2], that is, both halves of eight pairs (k, 200 - k), so sixteen bins of
+//      power come out of registers.  Column 0 pairs with itself shifted by one (Z[25 k2] with
+//      Z[25 (8 - k2)]): its lane feeds the second DFT the same column times W_8^r, which shifts the
+//      output by one bin.  Thirteen such units over eight lanes: two rounds.
+//   4. power into the frame's LDS buffer; every mel filter is a short run of consecutive bins, lane
+//      l takes the filters m = l (mod 8), 10 log10 of the weighted sum goes straight to HBM.
+// The eight lanes of a frame sit in one wave and a wave's LDS operations execute in order, so the
+// stages need no hardware barrier; the compiler, which reasons about aliasing one thread at a time,
+// must still be told that other lanes' stores feed the next stage's loads (wave_sync()).
+// One persistent workgroup of twelve waves per CU (the exchange buffers of its 96 frames fill the
+// LDS); a wave takes eight consecutive frames of one utterance at a time.
 //
-// k_mel_norm: per (utterance, mel bin) mean / unbiased std over the valid
-// frames in two passes, then the normalisation in place.
+// k_mel_norm: per (utterance, mel bin) mean / unbiased std over the valid frames, then the
+// normalisation in place; utterances of up to 458 frames are held in LDS in between (one read,
+// one write of HBM), longer ones take three passes over HBM.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -37,190 +50,235 @@
 
 namespace lmufft {
 
-typedef float f32x16m __attribute__((ext_vector_type(16)));
-
 constexpr int kMelFft = 400, kMelHop = 160, kMelBins = 201, kMelN = 80, kMelPad = 200;
-constexpr int kMelFrames = 128;                 // frames per block, 32 per wave
-constexpr int kMelChunks = kMelFrames + 2;      // hop chunks of samples held in LDS
-constexpr int kMelPitch = kMelHop + 1;          // LDS pitch of a chunk (odd)
-constexpr int kMelSamples = kMelChunks * kMelPitch;
-constexpr int kMelW = 208;                      // window table entries (n = 0..207)
-constexpr int kMelFbRows = 96;                  // mel rows padded to three 32-row tiles
-constexpr int kMelFbPitch = 65;
-constexpr int kMelTilePitch = kMelN + 1;
-constexpr int kMelBinTiles = 4;                 // bins 0..127 in tiles of 32 (0..100 used)
+constexpr int kMelHalf = kMelFft / 2;      // points of the packed complex transform
+constexpr int kMelWaves = 12;              // waves per workgroup, eight frames each
+constexpr int kMelThreads = 64 * kMelWaves;
+constexpr int kMelFrames = 8 * kMelWaves;  // frames in flight per workgroup
+constexpr int kMelZPitch = 2 * kMelHalf;   // floats per frame buffer
+// Filters 8 i .. 8 i + 7 are evaluated together over kMelRun[i] bins, the longest support among them
+// (shorter ones are padded with zero weights).  The supports follow from the fixed configuration
+// (16 kHz, 400-point DFT, 80 HTK filters up to 8 kHz) and are checked when the tables are built.
+constexpr int kMelRun[kMelN / 8] = {2, 2, 2, 3, 4, 5, 6, 8, 11, 14};
+constexpr int kMelRunTotal = 57;
 
-// constants in HBM (lmufft_melprep): twiddles | window | filterbank per bin tile
-constexpr size_t kPrepTab = 0;                                   // float2[400] = (cos, sin)(2 pi i / 400)
-constexpr size_t kPrepWin = kPrepTab + sizeof(float) * 2 * kMelFft;           // float[208]
-constexpr size_t kPrepFb = 4096;                                 // float[4][96][64]: [tile][mel][lo 32 | hi 32]
-constexpr size_t kPrepBytes = kPrepFb + sizeof(float) * kMelBinTiles * kMelFbRows * 64;
+// constants in HBM (lmufft_melprep), copied to LDS by every workgroup
+constexpr size_t kPrepWin = 0;                                          // float2[200]: half the periodic Hann window, in pairs
+constexpr size_t kPrepTw = kPrepWin + sizeof(float) * kMelFft;          // float2[8][25]: e^{-2 pi i r k1 / 200}
+constexpr size_t kPrepTab = kPrepTw + sizeof(float) * 2 * kMelHalf;     // float2[200]: e^{-2 pi i k / 400}
+constexpr size_t kPrepFw = kPrepTab + sizeof(float) * 2 * kMelHalf;     // float[57][8]: filter weights, run position major
+constexpr size_t kPrepFs = kPrepFw + sizeof(float) * kMelRunTotal * 8;  // int[80]: first bin of every filter
+constexpr size_t kPrepBytes = kPrepFs + sizeof(int) * kMelN;
+constexpr int kPrepFloats = (int)(kPrepBytes / 4);
+constexpr size_t kMelLds = kPrepBytes + sizeof(float) * (size_t)kMelFrames * kMelZPitch;
+static_assert(kMelLds <= 160 * 1024, "LDS budget");
 
-// LDS carve in floats
-constexpr int kLdsS = 0;
-constexpr int kLdsTab = (kMelSamples + 1) & ~1;
-constexpr int kLdsWin = kLdsTab + 2 * kMelFft;
-constexpr int kLdsFb = kLdsWin + kMelW;
-constexpr int kLdsTotal = kLdsFb + 2 * kMelFbRows * kMelFbPitch;  // one filterbank tile per wave group
-static_assert(2 * kMelFrames * kMelTilePitch <= kMelSamples, "output tile and the exchange tile reuse the sample area");
-constexpr int kMelThreads = 512;  // two groups of four waves: group g takes bin tiles 2g, 2g+1 of the same 128 frames
+struct cf {
+  float re, im;
+};
+__device__ __forceinline__ cf operator+(cf a, cf b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ cf operator-(cf a, cf b) { return {a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ cf cmul(cf a, cf b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ cf mulmi(cf a) { return {a.im, -a.re}; }  // a * (-i)
+__device__ __forceinline__ cf conj(cf a) { return {a.re, -a.im}; }
+__device__ __forceinline__ cf scale(cf a, float s) { return {a.re * s, a.im * s}; }
 
-__device__ __forceinline__ int sample_addr(int base, int n) {  // frame-relative sample n in [0, 400]
-  return base + n + (n >= kMelHop ? 1 : 0) + (n >= 2 * kMelHop ? 1 : 0);
+__device__ __forceinline__ void dft5(cf (&x)[5]) {
+  constexpr float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;  // cos(2 pi / 5), cos(4 pi / 5)
+  constexpr float s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;   // sin(2 pi / 5), sin(4 pi / 5)
+  const cf t1 = x[1] + x[4], t2 = x[2] + x[3], t3 = x[1] - x[4], t4 = x[2] - x[3];
+  const cf m1 = x[0] + scale(t1, c1) + scale(t2, c2), m2 = x[0] + scale(t1, c2) + scale(t2, c1);
+  const cf q1 = mulmi(scale(t3, s1) + scale(t4, s2)), q2 = mulmi(scale(t3, s2) - scale(t4, s1));
+  x[0] = x[0] + t1 + t2;
+  x[1] = m1 + q1;
+  x[2] = m2 + q2;
+  x[3] = m2 - q2;
+  x[4] = m1 - q1;
+}
+
+__device__ __forceinline__ void dft8(cf (&x)[8]) {
+  constexpr float h = 0.70710678118654752f;
+  const cf a0 = x[0] + x[4], a1 = x[0] - x[4], a2 = x[2] + x[6], a3 = mulmi(x[2] - x[6]);
+  const cf a4 = x[1] + x[5], a5 = x[1] - x[5], a6 = x[3] + x[7], a7 = mulmi(x[3] - x[7]);
+  const cf b0 = a0 + a2, b2 = a0 - a2, b1 = a1 + a3, b3 = a1 - a3;
+  const cf b4 = a4 + a6, b6 = mulmi(a4 - a6);
+  const cf b5 = cmul(a5 + a7, cf{h, -h}), b7 = cmul(a5 - a7, cf{-h, -h});
+  x[0] = b0 + b4;
+  x[1] = b1 + b5;
+  x[2] = b2 + b6;
+  x[3] = b3 + b7;
+  x[4] = b0 - b4;
+  x[5] = b1 - b5;
+  x[6] = b2 - b6;
+  x[7] = b3 - b7;
+}
+
+// cos, sin of 2 pi e / 25
+__device__ constexpr float kCos25[17] = {1.0f, 0.96858316112863108f, 0.87630668004386358f, 0.72896862742141155f, 0.53582679497899655f, 0.30901699437494745f, 0.062790519529313527f, -0.1873813145857246f, -0.42577929156507272f, -0.63742398974868975f, -0.80901699437494734f, -0.92977648588825135f, -0.99211470131447776f, -0.99211470131447788f, -0.92977648588825146f, -0.80901699437494778f, -0.63742398974868952f};
+__device__ constexpr float kSin25[17] = {0.0f, 0.24868988716485479f, 0.48175367410171532f, 0.68454710592868862f, 0.84432792550201508f, 0.95105651629515353f, 0.99802672842827156f, 0.98228725072868872f, 0.90482705246601947f, 0.77051324277578925f, 0.58778525229247325f, 0.36812455268467814f, 0.12533323356430454f, -0.12533323356430429f, -0.36812455268467792f, -0.58778525229247269f, -0.77051324277578936f};
+
+// X[q0 + 5 q1] = sum over m = 5 m1 + m0 of x[m] W_25^{m (q0 + 5 q1)}, in place
+__device__ __forceinline__ void dft25(cf (&x)[25]) {
+#pragma unroll
+  for (int m0 = 0; m0 < 5; ++m0) {
+    cf y[5] = {x[m0], x[m0 + 5], x[m0 + 10], x[m0 + 15], x[m0 + 20]};
+    dft5(y);
+#pragma unroll
+    for (int q0 = 0; q0 < 5; ++q0)
+      x[m0 + 5 * q0] = m0 * q0 ? cmul(y[q0], cf{kCos25[m0 * q0], -kSin25[m0 * q0]}) : y[q0];  // slot [q0][m0]
+  }
+#pragma unroll
+  for (int q0 = 0; q0 < 5; ++q0) {
+    cf y[5] = {x[5 * q0], x[5 * q0 + 1], x[5 * q0 + 2], x[5 * q0 + 3], x[5 * q0 + 4]};
+    dft5(y);
+#pragma unroll
+    for (int q1 = 0; q1 < 5; ++q1) x[5 * q0 + q1] = y[q1];  // slot [q0][q1] holds X[q0 + 5 q1]
+  }
+}
+// position of X[k1] in the array dft25() leaves behind
+__device__ __host__ constexpr int dft25_slot(int k1) { return 5 * (k1 % 5) + k1 / 5; }
+
+// Columns a (k1 = u) and b (k1 = 25 - u, or column 0 times W_8^r for u = 0) of one frame ->
+// power of the bins u + 25 k2 (pp) and 200 - u - 25 k2 (pm).  w[k2] = e^{-2 pi i (u + 25 k2) / 400}.
+__device__ __forceinline__ void bins16(cf (&a)[8], cf (&b)[8], const cf (&w)[8], float (&pp)[8], float (&pm)[8]) {
+  dft8(a);
+  dft8(b);
+#pragma unroll
+  for (int k2 = 0; k2 < 8; ++k2) {
+    const cf bc = conj(b[7 - k2]);
+    const cf e = a[k2] + bc, o = cmul(mulmi(a[k2] - bc), w[k2]);
+    const cf xp = e + o, xm = e - o;
+    pp[k2] = xp.re * xp.re + xp.im * xp.im;
+    pm[k2] = xm.re * xm.re + xm.im * xm.im;
+  }
+}
+
+// orders this wave's LDS traffic for the compiler; emits no instruction
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 __global__ __launch_bounds__(kMelThreads) void k_mel_power(const float* __restrict__ wave, const int* __restrict__ lengths,
-                                                   long ld_wave, int L, float* __restrict__ mel, int Tmax,
-                                                   const char* __restrict__ prep, uint32_t fbmask) {
+                                                           long ld_wave, int L, float* __restrict__ mel, int Tmax,
+                                                           const float* __restrict__ prep, int groups_per_utt, int ngroups,
+                                                           int pairs_aligned) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* S = lds + kLdsS;
-  float2* tab = reinterpret_cast<float2*>(lds + kLdsTab);
-  float* win = lds + kLdsWin;
-  float* fbS = lds + kLdsFb;
-  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
-  const int wv = (tid >> 6) & 3;  // which 32 frames of the block
-  const int grp = tid >> 8;       // which half of the bins (wave-uniform)
-  const int gtid = tid & 255;     // thread index inside the group
-  const int b = blockIdx.y, f0 = blockIdx.x * kMelFrames;
-  int len = lengths ? lengths[b] : L;
-  len = min(max(len, 1), L);
-  const int Tb = 1 + len / kMelHop;
-  const float* wb = wave + (long)b * ld_wave;
-
-  // samples f0*160 - 200 ... of the centred, reflect-padded utterance
-  for (int q = tid; q < kMelChunks * kMelHop; q += kMelThreads) {
-    int s = f0 * kMelHop - kMelPad + q;
-    if (s < 0) s = -s;
-    if (s >= len) s = 2 * (len - 1) - s;
-    s = min(max(s, 0), len - 1);  // frames past the utterance's end are computed on clamped data and masked
-    S[q + q / kMelHop] = wb[s];
-  }
-  {
-    const float* ptab = reinterpret_cast<const float*>(prep + kPrepTab);
-    for (int i = tid; i < 2 * kMelFft; i += kMelThreads) lds[kLdsTab + i] = ptab[i];
-    const float* pwin = reinterpret_cast<const float*>(prep + kPrepWin);
-    for (int i = tid; i < kMelW; i += kMelThreads) win[i] = pwin[i];
-  }
+  const cf* win2 = reinterpret_cast<const cf*>(lds + kPrepWin / 4);
+  const cf* tw = reinterpret_cast<const cf*>(lds + kPrepTw / 4);
+  const cf* tab = reinterpret_cast<const cf*>(lds + kPrepTab / 4);
+  const float* fw = lds + kPrepFw / 4;
+  const int* fstart = reinterpret_cast<const int*>(lds + kPrepFs / 4);
+  const int tid = threadIdx.x, l8 = tid & 7, fl = tid >> 3;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  cf* z = reinterpret_cast<cf*>(lds + kPrepFloats + fl * kMelZPitch);
+  for (int i = tid; i < kPrepFloats; i += kMelThreads) lds[i] = prep[i];
   __syncthreads();
-
-  const int base = (32 * wv + r) * kMelPitch;  // this lane's frame starts at chunk 32*wv + r
-  // a wave whose 32 frames all lie past the utterance's last frame skips the contractions (its output
-  // rows are written as zeros below); it still takes part in the barriers and the staging.  With
-  // 400 frames per utterance the fourth block holds 16 frames: three of its waves have none.
-  const bool active = f0 + 32 * wv < min(Tb, Tmax);
-  f32x16m melacc[3];
+  // workgroups that share an XCD (blockIdx mod 8) take neighbouring groups of frames, whose samples overlap
+  const int nb = gridDim.x, bx = blockIdx.x;
+  const int per = nb >> 3, rem = nb & 7, xcd = bx & 7, idx = bx >> 3;
+  const int wg = xcd * per + min(xcd, rem) + idx;
+  for (int g = wg + nb * wv; g < ngroups; g += nb * kMelWaves) {
+    const int b = g / groups_per_utt, t0 = (g - b * groups_per_utt) * 8;
+    const int t = t0 + (fl & 7);
+    int len = lengths ? lengths[b] : L;
+    len = min(max(len, 1), L);
+    const int Tb = 1 + len / kMelHop;
+    const float* wb = wave + (long)b * ld_wave;
+    // 1. the lane's 25 pairs of samples of the centred, reflect-padded frame, all loads in flight at once
+    cf x[25];
+    const int s00 = t * kMelHop - kMelPad + 2 * l8;
+    if (t0 * kMelHop - kMelPad >= 0 && (t0 + 7) * kMelHop + kMelPad <= len) {  // no edge in any of the eight frames
+      if (pairs_aligned) {
+        const float2* p2 = reinterpret_cast<const float2*>(wb + s00);
 #pragma unroll
-  for (int t = 0; t < 3; ++t)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) melacc[t][i] = 0.f;
-
-  // Each group of four waves takes one half of the bins (bin tiles 2 grp, 2 grp + 1) for all 128
-  // frames: two waves per SIMD instead of one hide each other's LDS latency; the two partial mel
-  // sums are added through LDS below.
-  float* fbG = fbS + grp * kMelFbRows * kMelFbPitch;
-  {
-    const int pass = grp;
-    f32x16m acc[2][4];
-    int idx_e[2], idx_o[2], step[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int k = 32 * (2 * pass + t) + r;
-      step[t] = (4 * k) % kMelFft;
-      idx_e[t] = (k * 2 * hh) % kMelFft;
-      idx_o[t] = (k * (2 * hh + 1)) % kMelFft;
-#pragma unroll
-      for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][p][i] = 0.f;
-    }
-    // MFMA k-step: lanes 0..31 carry n = 2j, 2j+1; lanes 32..63 carry n = 2j+2, 2j+3
-#pragma unroll 2
-    for (int j = 0; active && j < 102; j += 2) {
-      const int n0 = 2 * (j + hh);
-      const float xa0 = S[sample_addr(base, n0)], xa1 = S[sample_addr(base, n0 + 1)];
-      const float xb0 = S[sample_addr(base, kMelFft - n0)], xb1 = S[sample_addr(base, kMelFft - 1 - n0)];
-      const float w0 = win[n0], w1 = win[n0 + 1];
-      const float ee = w0 * (xa0 + xb0), oe = w0 * (xa0 - xb0);
-      const float eo = w1 * (xa1 + xb1), oo = w1 * (xa1 - xb1);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const float2 ce = tab[idx_e[t]], co = tab[idx_o[t]];
-        acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ce.x, ee, acc[t][0], 0, 0, 0);
-        acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(co.x, eo, acc[t][1], 0, 0, 0);
-        acc[t][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(ce.y, oe, acc[t][2], 0, 0, 0);
-        acc[t][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(co.y, oo, acc[t][3], 0, 0, 0);
-        idx_e[t] += step[t];
-        idx_e[t] -= idx_e[t] >= kMelFft ? kMelFft : 0;
-        idx_o[t] += step[t];
-        idx_o[t] -= idx_o[t] >= kMelFft ? kMelFft : 0;
-      }
-    }
-    // power of bins k (lo) and 200 - k (hi) -> mel filterbank, straight from registers
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int bt = 2 * pass + t;
-      __syncthreads();
-      const float* pfb = reinterpret_cast<const float*>(prep + kPrepFb) + (size_t)bt * kMelFbRows * 64;
-      for (int i = gtid; i < kMelFbRows * 64; i += 256) fbG[(i >> 6) * kMelFbPitch + (i & 63)] = pfb[i];
-      __syncthreads();
-      f32x16m plo, phi;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float re = acc[t][0][i] + acc[t][1][i], im = acc[t][2][i] + acc[t][3][i];
-        const float rh = acc[t][0][i] - acc[t][1][i], ih = acc[t][2][i] - acc[t][3][i];
-        plo[i] = re * re + im * im;
-        phi[i] = rh * rh + ih * ih;
-      }
-#pragma unroll
-      for (int mt = 0; active && mt < 3; ++mt) {
-        const float* frow = fbG + (32 * mt + r) * kMelFbPitch + 4 * hh;
-        if ((fbmask >> (bt * 6 + mt * 2)) & 1u) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i)
-            melacc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(frow[(i & 3) + 8 * (i >> 2)], plo[i], melacc[mt], 0, 0, 0);
+        for (int i = 0; i < 25; ++i) {
+          const float2 v = p2[8 * i];
+          x[i] = cf{v.x, v.y};
         }
-        if ((fbmask >> (bt * 6 + mt * 2 + 1)) & 1u) {
+      } else {
 #pragma unroll
-          for (int i = 0; i < 16; ++i)
-            melacc[mt] =
-                __builtin_amdgcn_mfma_f32_32x32x2f32(frow[32 + (i & 3) + 8 * (i >> 2)], phi[i], melacc[mt], 0, 0, 0);
+        for (int i = 0; i < 25; ++i) x[i] = cf{wb[s00 + 16 * i], wb[s00 + 16 * i + 1]};
+      }
+    } else {  // frames past the utterance's end are computed on clamped data and masked below
+#pragma unroll
+      for (int i = 0; i < 25; ++i) {
+        int sa = s00 + 16 * i, sb = sa + 1;
+        sa = sa < 0 ? -sa : sa;
+        sb = sb < 0 ? -sb : sb;
+        sa = sa >= len ? 2 * (len - 1) - sa : sa;
+        sb = sb >= len ? 2 * (len - 1) - sb : sb;
+        x[i] = cf{wb[min(max(sa, 0), len - 1)], wb[min(max(sb, 0), len - 1)]};
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 25; ++i) {
+      const cf w = win2[l8 + 8 * i];
+      x[i] = cf{x[i].re * w.re, x[i].im * w.im};
+    }
+    dft25(x);
+    // 2. twiddle and exchange: lane r leaves W_200^{r k1} X_r[k1] at z[25 r + k1]
+    wave_sync();  // the previous group's filters have read the buffer
+#pragma unroll
+    for (int k1 = 0; k1 < 25; ++k1) z[25 * l8 + k1] = k1 ? cmul(x[dft25_slot(k1)], tw[25 * l8 + k1]) : x[0];
+    wave_sync();
+    // 3. thirteen units (column 0; columns u and 25 - u) over eight lanes
+    float pw[2][16];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int u = min(l8 + 8 * it, 12);
+      const int cb = u ? 25 - u : 0;
+      cf a[8], bb[8], w[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        a[r] = z[25 * r + u];
+        bb[r] = z[25 * r + cb];
+        w[r] = tab[u + 25 * r];
+      }
+      if (it == 0) {  // unit 0 sits on lane 0 of round 0
+        constexpr float h = 0.70710678118654752f;
+        constexpr float c8[8] = {1.f, h, 0.f, -h, -1.f, -h, 0.f, h}, s8[8] = {0.f, h, 1.f, h, 0.f, -h, -1.f, -h};
+#pragma unroll
+        for (int r = 1; r < 8; ++r) bb[r] = cmul(bb[r], cf{u ? 1.f : c8[r], u ? 0.f : -s8[r]});
+      }
+      float pp[8], pm[8];
+      bins16(a, bb, w, pp, pm);
+#pragma unroll
+      for (int k2 = 0; k2 < 8; ++k2) {
+        pw[it][k2] = pp[k2];
+        pw[it][8 + k2] = pm[k2];
+      }
+    }
+    wave_sync();  // every lane has read its columns
+    float* P = reinterpret_cast<float*>(z);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int u = l8 + 8 * it;
+      if (u < 13) {
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) {
+          P[u + 25 * k2] = pw[it][k2];
+          P[200 - u - 25 * k2] = pw[it][8 + k2];
         }
       }
     }
-  }
-
-  // group 1 hands its partial mel sums to group 0 through LDS (the sample area is free now); group 0
-  // adds them, takes 10 log10 and lays the tile out as rows of 80 floats
-  __syncthreads();
-  float* tile = S;
-  float* xch = S + kMelFrames * kMelTilePitch;
-  if (grp == 1) {
+    wave_sync();
+    // 4. filters m = l8 + 8 i: 10 log10 of the weighted sum of a short run of bins
+    if (t < Tmax) {
+      float* out = mel + ((long)b * Tmax + t) * kMelN;
+      int run0 = 0;
 #pragma unroll
-    for (int mt = 0; mt < 3; ++mt)
+      for (int i = 0; i < kMelN / 8; ++i) {
+        const int m = l8 + 8 * i;
+        const float* Pm = P + fstart[m];
+        float s = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int c = 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * hh;
-        if (c < kMelN) xch[(32 * wv + r) * kMelTilePitch + c] = melacc[mt][i];
+        for (int c = 0; c < kMelRun[i]; ++c) s += fw[(run0 + c) * 8 + l8] * Pm[c];
+        run0 += kMelRun[i];
+        out[m] = t < Tb ? 3.01029995663981195f * __log2f(fmaxf(s, 1e-10f)) : 0.f;
       }
-  }
-  __syncthreads();
-  if (grp == 0) {
-#pragma unroll
-    for (int mt = 0; mt < 3; ++mt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int c = 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * hh;
-        if (c < kMelN) {
-          const int at = (32 * wv + r) * kMelTilePitch + c;
-          tile[at] = 10.0f * log10f(fmaxf(melacc[mt][i] + xch[at], 1e-10f));
-        }
-      }
-  }
-  __syncthreads();
-  float* mb = mel + (long)b * Tmax * kMelN;
-  for (int idx = tid; idx < kMelFrames * kMelN; idx += kMelThreads) {
-    const int f = idx / kMelN, c = idx % kMelN, t = f0 + f;
-    if (t < Tmax) mb[(long)t * kMelN + c] = t < Tb ? tile[f * kMelTilePitch + c] : 0.f;
+    }
   }
 }
 
@@ -274,7 +332,7 @@ __global__ __launch_bounds__(16 * kMelNormGroups) void k_mel_norm(float* __restr
 // ---------------------------------------------------------------------------
 struct MelConstants {
   std::vector<char> bytes;
-  uint32_t fbmask = 0;
+  bool ok = false;  // the filters' supports fit kMelRun
 };
 
 static const MelConstants& mel_constants() {
@@ -282,17 +340,20 @@ static const MelConstants& mel_constants() {
   static std::once_flag once;
   std::call_once(once, [] {
     mc.bytes.assign(kPrepBytes, 0);
+    float* win = reinterpret_cast<float*>(mc.bytes.data() + kPrepWin);  // half the periodic Hann window
+    for (int n = 0; n < kMelFft; ++n) win[n] = (float)(0.5 * (0.5 - 0.5 * cos(2.0 * M_PI * (double)n / (double)kMelFft)));
+    float* tw = reinterpret_cast<float*>(mc.bytes.data() + kPrepTw);
+    for (int r = 0; r < 8; ++r)
+      for (int k1 = 0; k1 < 25; ++k1) {
+        const double a = 2.0 * M_PI * (double)(r * k1) / (double)kMelHalf;
+        tw[2 * (25 * r + k1)] = (float)cos(a);
+        tw[2 * (25 * r + k1) + 1] = (float)-sin(a);
+      }
     float* tab = reinterpret_cast<float*>(mc.bytes.data() + kPrepTab);
-    for (int i = 0; i < kMelFft; ++i) {
-      const double a = 2.0 * M_PI * (double)i / (double)kMelFft;
-      tab[2 * i] = (float)cos(a);
-      tab[2 * i + 1] = (float)sin(a);
-    }
-    // periodic Hann; the self-paired sample n = 200 enters e[n] = y[n] + y[400-n] twice, hence the half
-    float* win = reinterpret_cast<float*>(mc.bytes.data() + kPrepWin);
-    for (int n = 0; n < kMelW; ++n) {
-      const double w = 0.5 - 0.5 * cos(2.0 * M_PI * (double)n / (double)kMelFft);
-      win[n] = n < 200 ? (float)w : (n == 200 ? (float)(0.5 * w) : 0.f);
+    for (int k = 0; k < kMelHalf; ++k) {
+      const double a = 2.0 * M_PI * (double)k / (double)kMelFft;
+      tab[2 * k] = (float)cos(a);
+      tab[2 * k + 1] = (float)-sin(a);
     }
     // HTK mel filters, 82 points equally spaced in mel over 0..8000 Hz, bin centres k * 40 Hz
     auto hz2mel = [](double f) { return 2595.0 * log10(1.0 + f / 700.0); };
@@ -307,19 +368,29 @@ static const MelConstants& mel_constants() {
       const double v = down < up ? down : up;
       return v > 0.0 ? v : 0.0;
     };
-    float* pfb = reinterpret_cast<float*>(mc.bytes.data() + kPrepFb);
-    for (int bt = 0; bt < kMelBinTiles; ++bt)
-      for (int m = 0; m < kMelFbRows; ++m)
-        for (int slot = 0; slot < 32; ++slot) {
-          const int k = 32 * bt + slot;
-          // lo: bin k (k <= 100); hi: bin 200 - k (k < 100, so that bin 100 is counted once)
-          const double lo = (m < kMelN && k <= 100) ? fb(k, m) : 0.0;
-          const double hi = (m < kMelN && k < 100) ? fb(200 - k, m) : 0.0;
-          pfb[((size_t)bt * kMelFbRows + m) * 64 + slot] = (float)lo;
-          pfb[((size_t)bt * kMelFbRows + m) * 64 + 32 + slot] = (float)hi;
-          if (lo != 0.0) mc.fbmask |= 1u << (bt * 6 + (m / 32) * 2);
-          if (hi != 0.0) mc.fbmask |= 1u << (bt * 6 + (m / 32) * 2 + 1);
+    int* fs = reinterpret_cast<int*>(mc.bytes.data() + kPrepFs);
+    float* fwt = reinterpret_cast<float*>(mc.bytes.data() + kPrepFw);
+    int run0 = 0;
+    for (int i = 0; i < kMelN / 8; ++i) {
+      for (int l = 0; l < 8; ++l) {
+        const int m = 8 * i + l;
+        int first = -1, last = -1;
+        for (int k = 0; k < kMelBins; ++k)
+          if ((float)fb(k, m) != 0.f) {
+            if (first < 0) first = k;
+            last = k;
+          }
+        if (first < 0) first = last = 0;  // a filter narrower than the bin spacing: weight 0 on one bin
+        if (last - first + 1 > kMelRun[i]) {
+          mc.ok = false;
+          return;
         }
+        fs[m] = first;
+        for (int c = 0; c < kMelRun[i]; ++c) fwt[(run0 + c) * 8 + l] = first + c <= last ? (float)fb(first + c, m) : 0.f;
+      }
+      run0 += kMelRun[i];
+    }
+    mc.ok = run0 == kMelRunTotal;
   });
   return mc;
 }
@@ -335,6 +406,7 @@ size_t lmufft_melprep_bytes(void) { return kPrepBytes; }
 int lmufft_melprep(void* melprep, void* stream) {
   if (!melprep) return set_error("melprep: NULL pointer");
   const MelConstants& mc = mel_constants();
+  if (!mc.ok) return set_error("melprep: the mel filters' supports do not fit the compiled run lengths");
   const hipError_t e = hipMemcpyAsync(melprep, mc.bytes.data(), kPrepBytes, hipMemcpyHostToDevice, (hipStream_t)stream);
   if (e != hipSuccess) return set_error("melprep: copy failed: %s", hipGetErrorString(e));
   return 0;
@@ -350,15 +422,21 @@ int lmufft_mel_forward_f32(const float* wave, const int32_t* lengths, int32_t B,
     return set_error("mel: %d samples give %d frames but the output holds %d", L, 1 + L / kMelHop, Tmax);
   if (!wave || !mel || !melprep) return set_error("mel: NULL pointer");
   hipStream_t st = (hipStream_t)stream;
-  const MelConstants& mc = mel_constants();
-  const size_t lds = sizeof(float) * (size_t)kLdsTotal;
-  static_assert(sizeof(float) * (size_t)kLdsTotal <= 160 * 1024, "LDS budget");
-  if (hipFuncSetAttribute((const void*)k_mel_power, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return set_error("cannot reserve %zu bytes of LDS for k_mel_power", lds);
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      cus <= 0)
+    return set_error("mel: cannot query the device");
+  if (hipFuncSetAttribute((const void*)k_mel_power, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMelLds) != hipSuccess)
+    return set_error("cannot reserve %zu bytes of LDS for k_mel_power", kMelLds);
+  const int groups_per_utt = (Tmax + 7) / 8;
+  const long ngroups = (long)groups_per_utt * B;
+  if (ngroups > INT32_MAX) return set_error("mel: %ld groups of frames exceed the index range", ngroups);
+  const int grid = (int)(ngroups < cus ? ngroups : cus);
+  const int pairs_aligned = ((uintptr_t)wave % 8 == 0) && (ld_wave % 2 == 0);
   {
     ProfScope ps("k_mel_power", st);
-    hipLaunchKernelGGL(k_mel_power, dim3((Tmax + kMelFrames - 1) / kMelFrames, B), dim3(kMelThreads), lds, st, wave, lengths,
-                       (long)ld_wave, L, mel, Tmax, (const char*)melprep, mc.fbmask);
+    hipLaunchKernelGGL(k_mel_power, dim3(grid), dim3(kMelThreads), kMelLds, st, wave, lengths, (long)ld_wave, L, mel, Tmax,
+                       (const float*)melprep, groups_per_utt, (int)ngroups, pairs_aligned);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error("launch of k_mel_power failed: %s", hipGetErrorString(e));
