@@ -73,15 +73,22 @@ constexpr int kPrepFloats = (int)(kPrepBytes / 4);
 constexpr size_t kMelLds = kPrepBytes + sizeof(float) * (size_t)kMelFrames * kMelZPitch;
 static_assert(kMelLds <= 160 * 1024, "LDS budget");
 
-struct cf {
-  float re, im;
-};
-__device__ __forceinline__ cf operator+(cf a, cf b) { return {a.re + b.re, a.im + b.im}; }
-__device__ __forceinline__ cf operator-(cf a, cf b) { return {a.re - b.re, a.im - b.im}; }
-__device__ __forceinline__ cf cmul(cf a, cf b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
-__device__ __forceinline__ cf mulmi(cf a) { return {a.im, -a.re}; }  // a * (-i)
-__device__ __forceinline__ cf conj(cf a) { return {a.re, -a.im}; }
-__device__ __forceinline__ cf scale(cf a, float s) { return {a.re * s, a.im * s}; }
+// a complex number as a two-lane vector, so that sums and products map onto the packed fp32 instructions
+typedef float cf __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cf mk(float re, float im) {
+  cf v;
+  v.x = re;
+  v.y = im;
+  return v;
+}
+__device__ __forceinline__ cf cmul(cf a, cf b) { return a.xx * b + a.yy * mk(-b.y, b.x); }
+__device__ __forceinline__ cf mulmi(cf a) { return mk(a.y, -a.x); }  // a * (-i)
+__device__ __forceinline__ cf conj(cf a) { return mk(a.x, -a.y); }
+__device__ __forceinline__ cf scale(cf a, float s) { return a * s; }
+__device__ __forceinline__ float norm2(cf a) {
+  const cf q = a * a;
+  return q.x + q.y;
+}
 
 __device__ __forceinline__ void dft5(cf (&x)[5]) {
   constexpr float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;  // cos(2 pi / 5), cos(4 pi / 5)
@@ -102,7 +109,7 @@ __device__ __forceinline__ void dft8(cf (&x)[8]) {
   const cf a4 = x[1] + x[5], a5 = x[1] - x[5], a6 = x[3] + x[7], a7 = mulmi(x[3] - x[7]);
   const cf b0 = a0 + a2, b2 = a0 - a2, b1 = a1 + a3, b3 = a1 - a3;
   const cf b4 = a4 + a6, b6 = mulmi(a4 - a6);
-  const cf b5 = cmul(a5 + a7, cf{h, -h}), b7 = cmul(a5 - a7, cf{-h, -h});
+  const cf b5 = cmul(a5 + a7, mk(h, -h)), b7 = cmul(a5 - a7, mk(-h, -h));
   x[0] = b0 + b4;
   x[1] = b1 + b5;
   x[2] = b2 + b6;
@@ -125,7 +132,7 @@ __device__ __forceinline__ void dft25(cf (&x)[25]) {
     dft5(y);
 #pragma unroll
     for (int q0 = 0; q0 < 5; ++q0)
-      x[m0 + 5 * q0] = m0 * q0 ? cmul(y[q0], cf{kCos25[m0 * q0], -kSin25[m0 * q0]}) : y[q0];  // slot [q0][m0]
+      x[m0 + 5 * q0] = m0 * q0 ? cmul(y[q0], mk(kCos25[m0 * q0], -kSin25[m0 * q0])) : y[q0];  // slot [q0][m0]
   }
 #pragma unroll
   for (int q0 = 0; q0 < 5; ++q0) {
@@ -148,8 +155,8 @@ __device__ __forceinline__ void bins16(cf (&a)[8], cf (&b)[8], const cf (&w)[8],
     const cf bc = conj(b[7 - k2]);
     const cf e = a[k2] + bc, o = cmul(mulmi(a[k2] - bc), w[k2]);
     const cf xp = e + o, xm = e - o;
-    pp[k2] = xp.re * xp.re + xp.im * xp.im;
-    pm[k2] = xm.re * xm.re + xm.im * xm.im;
+    pp[k2] = norm2(xp);
+    pm[k2] = norm2(xm);
   }
 }
 
@@ -158,6 +165,36 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The 25 pairs of samples n = l8 (mod 8) of frame t of utterance b (centred, reflect-padded; frames
+// past the utterance's end read clamped data and are masked by the caller), all loads in flight at once.
+__device__ __forceinline__ void mel_load(cf (&x)[25], const float* __restrict__ wb, int len, int t0, int t, int l8,
+                                         int pairs_aligned) {
+  const int s00 = t * kMelHop - kMelPad + 2 * l8;
+  if (t0 * kMelHop - kMelPad >= 0 && (t0 + 7) * kMelHop + kMelPad <= len) {  // no edge in any of the wave's eight frames
+    if (pairs_aligned) {
+      const float2* p2 = reinterpret_cast<const float2*>(wb + s00);
+#pragma unroll
+      for (int i = 0; i < 25; ++i) {
+        const float2 v = p2[8 * i];
+        x[i] = mk(v.x, v.y);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 25; ++i) x[i] = mk(wb[s00 + 16 * i], wb[s00 + 16 * i + 1]);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 25; ++i) {
+      int sa = s00 + 16 * i, sb = sa + 1;
+      sa = sa < 0 ? -sa : sa;
+      sb = sb < 0 ? -sb : sb;
+      sa = sa >= len ? 2 * (len - 1) - sa : sa;
+      sb = sb >= len ? 2 * (len - 1) - sb : sb;
+      x[i] = mk(wb[min(max(sa, 0), len - 1)], wb[min(max(sb, 0), len - 1)]);
+    }
+  }
 }
 
 __global__ __launch_bounds__(kMelThreads) void k_mel_power(const float* __restrict__ wave, const int* __restrict__ lengths,
@@ -173,49 +210,23 @@ __global__ __launch_bounds__(kMelThreads) void k_mel_power(const float* __restri
   const int tid = threadIdx.x, l8 = tid & 7, fl = tid >> 3;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   cf* z = reinterpret_cast<cf*>(lds + kPrepFloats + fl * kMelZPitch);
-  for (int i = tid; i < kPrepFloats; i += kMelThreads) lds[i] = prep[i];
-  __syncthreads();
   // workgroups that share an XCD (blockIdx mod 8) take neighbouring groups of frames, whose samples overlap
   const int nb = gridDim.x, bx = blockIdx.x;
   const int per = nb >> 3, rem = nb & 7, xcd = bx & 7, idx = bx >> 3;
   const int wg = xcd * per + min(xcd, rem) + idx;
+  for (int i = tid; i < kPrepFloats; i += kMelThreads) lds[i] = prep[i];
+  __syncthreads();
   for (int g = wg + nb * wv; g < ngroups; g += nb * kMelWaves) {
     const int b = g / groups_per_utt, t0 = (g - b * groups_per_utt) * 8;
     const int t = t0 + (fl & 7);
-    int len = lengths ? lengths[b] : L;
-    len = min(max(len, 1), L);
-    const int Tb = 1 + len / kMelHop;
-    const float* wb = wave + (long)b * ld_wave;
-    // 1. the lane's 25 pairs of samples of the centred, reflect-padded frame, all loads in flight at once
+    const int len = min(max(lengths ? lengths[b] : L, 1), L), Tb = 1 + len / kMelHop;
+    float* out = mel + ((long)b * Tmax + t) * kMelN;
     cf x[25];
-    const int s00 = t * kMelHop - kMelPad + 2 * l8;
-    if (t0 * kMelHop - kMelPad >= 0 && (t0 + 7) * kMelHop + kMelPad <= len) {  // no edge in any of the eight frames
-      if (pairs_aligned) {
-        const float2* p2 = reinterpret_cast<const float2*>(wb + s00);
-#pragma unroll
-        for (int i = 0; i < 25; ++i) {
-          const float2 v = p2[8 * i];
-          x[i] = cf{v.x, v.y};
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 25; ++i) x[i] = cf{wb[s00 + 16 * i], wb[s00 + 16 * i + 1]};
-      }
-    } else {  // frames past the utterance's end are computed on clamped data and masked below
-#pragma unroll
-      for (int i = 0; i < 25; ++i) {
-        int sa = s00 + 16 * i, sb = sa + 1;
-        sa = sa < 0 ? -sa : sa;
-        sb = sb < 0 ? -sb : sb;
-        sa = sa >= len ? 2 * (len - 1) - sa : sa;
-        sb = sb >= len ? 2 * (len - 1) - sb : sb;
-        x[i] = cf{wb[min(max(sa, 0), len - 1)], wb[min(max(sb, 0), len - 1)]};
-      }
-    }
+    mel_load(x, wave + (long)b * ld_wave, len, t0, t, l8, pairs_aligned);
+    // 1. window, 25-point transform of the lane's residue class
 #pragma unroll
     for (int i = 0; i < 25; ++i) {
-      const cf w = win2[l8 + 8 * i];
-      x[i] = cf{x[i].re * w.re, x[i].im * w.im};
+      x[i] = x[i] * win2[l8 + 8 * i];
     }
     dft25(x);
     // 2. twiddle and exchange: lane r leaves W_200^{r k1} X_r[k1] at z[25 r + k1]
@@ -240,7 +251,7 @@ __global__ __launch_bounds__(kMelThreads) void k_mel_power(const float* __restri
         constexpr float h = 0.70710678118654752f;
         constexpr float c8[8] = {1.f, h, 0.f, -h, -1.f, -h, 0.f, h}, s8[8] = {0.f, h, 1.f, h, 0.f, -h, -1.f, -h};
 #pragma unroll
-        for (int r = 1; r < 8; ++r) bb[r] = cmul(bb[r], cf{u ? 1.f : c8[r], u ? 0.f : -s8[r]});
+        for (int r = 1; r < 8; ++r) bb[r] = cmul(bb[r], mk(u ? 1.f : c8[r], u ? 0.f : -s8[r]));
       }
       float pp[8], pm[8];
       bins16(a, bb, w, pp, pm);
@@ -266,7 +277,6 @@ __global__ __launch_bounds__(kMelThreads) void k_mel_power(const float* __restri
     wave_sync();
     // 4. filters m = l8 + 8 i: 10 log10 of the weighted sum of a short run of bins
     if (t < Tmax) {
-      float* out = mel + ((long)b * Tmax + t) * kMelN;
       int run0 = 0;
 #pragma unroll
       for (int i = 0; i < kMelN / 8; ++i) {
@@ -325,6 +335,67 @@ __global__ __launch_bounds__(16 * kMelNormGroups) void k_mel_norm(float* __restr
   __syncthreads();
   const float sd = stat[1][c];
   for (int t = g; t < Tb; t += kMelNormGroups) mb[(long)t * kMelN] = (mb[(long)t * kMelN] - mean) / sd;
+}
+
+// One workgroup per utterance, its valid frames held in LDS between the passes: thread = (group of four
+// bins q, row group rg), 51 row groups.  Sums run over rows rg, rg + 51, ... and then over the row groups
+// in a fixed order.
+constexpr int kMelNormRg = 51;
+constexpr int kMelNormLdsRows = 458;  // 458 * 320 + 51 * 320 + 640 bytes <= 160 KB
+__global__ __launch_bounds__(1024) void k_mel_norm_lds(float* __restrict__ mel, const int* __restrict__ lengths, int L, int Tmax) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  int len = lengths ? lengths[b] : L;
+  len = min(max(len, 1), L);
+  const int Tb = min(1 + len / kMelHop, Tmax);
+  float4* tile = reinterpret_cast<float4*>(lds);          // [Tb][20]
+  float4* red = tile + (size_t)Tb * 20;                   // [51][20]
+  float* stat = reinterpret_cast<float*>(red + kMelNormRg * 20);  // mean[80], std[80]
+  float4* mb = reinterpret_cast<float4*>(mel + (long)b * Tmax * kMelN);
+  const int q = tid % 20, rg = tid / 20;
+  const bool on = rg < kMelNormRg;
+  float4 s = {0.f, 0.f, 0.f, 0.f};
+  if (on)
+    for (int r = rg; r < Tb; r += kMelNormRg) {
+      const float4 v = mb[r * 20 + q];
+      tile[r * 20 + q] = v;
+      s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+    }
+  if (on) red[rg * 20 + q] = s;
+  __syncthreads();
+  if (tid < kMelN) {
+    const float* rf = reinterpret_cast<const float*>(red);
+    float tot = 0.f;
+    for (int i = 0; i < kMelNormRg; ++i) tot += rf[i * kMelN + tid];
+    stat[tid] = tot / (float)Tb;
+  }
+  __syncthreads();
+  const float4 mean = on ? reinterpret_cast<const float4*>(stat)[q] : s;
+  s = {0.f, 0.f, 0.f, 0.f};
+  if (on) {
+    for (int r = rg; r < Tb; r += kMelNormRg) {
+      const float4 v = tile[r * 20 + q];
+      const float dx = v.x - mean.x, dy = v.y - mean.y, dz = v.z - mean.z, dw = v.w - mean.w;
+      s.x += dx * dx, s.y += dy * dy, s.z += dz * dz, s.w += dw * dw;
+    }
+    red[rg * 20 + q] = s;
+  }
+  __syncthreads();
+  if (tid < kMelN) {
+    const float* rf = reinterpret_cast<const float*>(red);
+    float tot = 0.f;
+    for (int i = 0; i < kMelNormRg; ++i) tot += rf[i * kMelN + tid];
+    const float sd = sqrtf(tot / (float)(Tb - 1));  // unbiased, as torch.std (NaN for a single frame, as there)
+    stat[kMelN + tid] = sd == 0.f ? 1.f : sd;
+  }
+  __syncthreads();
+  if (on) {
+    const float4 sd = reinterpret_cast<const float4*>(stat + kMelN)[q];
+    for (int r = rg; r < Tb; r += kMelNormRg) {
+      const float4 v = tile[r * 20 + q];
+      mb[r * 20 + q] = float4{(v.x - mean.x) / sd.x, (v.y - mean.y) / sd.y, (v.z - mean.z) / sd.z, (v.w - mean.w) / sd.w};
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -441,7 +512,14 @@ int lmufft_mel_forward_f32(const float* wave, const int32_t* lengths, int32_t B,
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error("launch of k_mel_power failed: %s", hipGetErrorString(e));
   if (normalize) {
-    {
+    // one workgroup per utterance pays off once there are enough utterances to fill a good part of the chip
+    if (Tmax <= kMelNormLdsRows && (uintptr_t)mel % 16 == 0 && 4 * B >= cus) {
+      const size_t nlds = sizeof(float) * ((size_t)(Tmax + kMelNormRg) * kMelN + 2 * kMelN);
+      if (hipFuncSetAttribute((const void*)k_mel_norm_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nlds) != hipSuccess)
+        return set_error("cannot reserve %zu bytes of LDS for k_mel_norm", nlds);
+      ProfScope ps("k_mel_norm", st);
+      hipLaunchKernelGGL(k_mel_norm_lds, dim3(B), dim3(1024), nlds, st, mel, lengths, L, Tmax);
+    } else {
       ProfScope ps("k_mel_norm", st);
       hipLaunchKernelGGL(k_mel_norm, dim3(kMelN / 16, B), dim3(16 * kMelNormGroups), 0, st, mel, lengths, L, Tmax);
     }
