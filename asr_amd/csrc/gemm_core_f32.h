@@ -272,4 +272,29 @@ __device__ __forceinline__ void preload_rows(float (&r)[T::TM][16], const WavePo
     for (int i = 0; i < 16; ++i) r[tm][i] = g(w.wm0 + tm * 32 + (i & 3) + 8 * (i >> 2) + 4 * w.hh);
 }
 
+// Adds every element of a workgroup's accumulator tile P[mm][nn] to the diagonal
+// s = s_origin + mm - nn it belongs to: the tile goes to LDS (`P`, BM * (BN + 1) floats), then one
+// thread per diagonal sums it top to bottom -- a fixed order, unlike LDS atomics.  Rows mm > mm_last
+// and diagonals s < 0 are left out.  All threads of the workgroup call it; `diag` is theirs alone
+// between the two barriers it contains.
+template <class T>
+__device__ __forceinline__ void add_tile_diagonals(const f32x16 (&acc)[T::TM][T::TN], const WavePos<T>& w, float* P,
+                                                   float* diag, int s_origin, int mm_last) {
+  constexpr int LDP = T::BN + 1;
+  static_assert(T::BM + T::BN - 1 <= kThreads, "one thread per diagonal");
+  tile_epilogue<T>(acc, w, [&](int mm, int nn, float v) { P[mm * LDP + nn] = v; });
+  __syncthreads();
+  const int off = (int)threadIdx.x - (T::BN - 1);  // mm - nn of this thread's diagonal
+  const int s = s_origin + off;
+  if (off < T::BM && s >= 0) {
+    const int lo = off > 0 ? off : 0;
+    int hi = T::BN - 1 + off < T::BM - 1 ? T::BN - 1 + off : T::BM - 1;
+    hi = hi < mm_last ? hi : mm_last;
+    float sum = 0.f;
+    for (int mm = lo; mm <= hi; ++mm) sum += P[mm * LDP + mm - off];
+    if (lo <= hi) diag[s] += sum;
+  }
+  __syncthreads();
+}
+
 }  // namespace lmufft

@@ -625,7 +625,7 @@ using DgradXGldsTile = TileB<128, 384, 64, 2, 4>;  // input columns, LDS-DMA for
 
 // ---------------------------------------------------------------------------
 // gu partial slabs: P[i][tau] = sum_k gm[t0+i][k] H[k][tau], summed along the
-// diagonals s = t0 + i - tau (fp32 LDS atomics), one slab per (batch, t tile)
+// diagonals s = t0 + i - tau (through LDS, in a fixed order), one slab per (batch, t tile)
 // ---------------------------------------------------------------------------
 using ConvBwdTileB = TileB<64, 128, 64, 2, 2>;
 
@@ -651,6 +651,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_bwd_bf16(const bf16_t* __rest
   typedef LdsOperandKC<TL::BM, TL::BK, decltype(la)> OpA;
   constexpr int kBElems = TL::BN * (TL::BK + 8);
   float* gu_acc = reinterpret_cast<float*>(smem + OpA::ELEMS + kBElems);
+  float* ptile = gu_acc + ntt * TL::BM;
   for (int s = threadIdx.x; s < send; s += kThreads) gu_acc[s] = 0.f;
 
   WavePos<TL> w;
@@ -666,12 +667,8 @@ __global__ __launch_bounds__(kThreads) void k_conv_bwd_bf16(const bf16_t* __rest
     f32x16 acc[TL::TM][TL::TN];
     tileb_zero<TL>(acc);
     gemm_loop_kc<TL>(oa, ob, acc, 0, M, w);
-    tileb_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
-      const int s = t0 + mm - (tau0 + nn);
-      if (s >= 0 && t0 + mm < T) atomicAdd(&gu_acc[s], v);
-    });
+    add_tile_diagonals<TL>(acc, w, ptile, gu_acc, t0 - tau0, T - 1 - t0);
   }
-  __syncthreads();
   float* out = gu_part + ((long)b * ntt + tb) * T;
   for (int s = threadIdx.x; s < send; s += kThreads) out[s] = gu_acc[s];
 }
@@ -1399,7 +1396,8 @@ static int conv_backward_bf16_any(const lmufft_shape& sh, const bf16_t* gm, cons
   } else {
     using TL = ConvBwdTileB;
     const dim3 grid(1, s->B, p.ntt);
-    const size_t lds = sizeof(bf16_t) * (size_t)(TL::BM + TL::BN) * (TL::BK + 8) + sizeof(float) * (size_t)p.ntt * TL::BM;
+    const size_t lds = sizeof(bf16_t) * (size_t)(TL::BM + TL::BN) * (TL::BK + 8) +
+                       sizeof(float) * ((size_t)p.ntt * TL::BM + (size_t)TL::BM * (TL::BN + 1));
     if (lds > 160 * 1024) return set_error("sequence too long for the Toeplitz backward kernel (T=%d)", s->T);
     const bool vec = (s->M % 8 == 0) && al16(gm);
     const void* fn = vec ? (const void*)k_conv_bwd_bf16<true> : (const void*)k_conv_bwd_bf16<false>;

@@ -365,8 +365,7 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(const float* __restrict__ h,
 // gu[b,s] = sum_{t>=s} sum_k gm[b,t,k] H[k,t-s]
 // Per (batch, t tile): P[i][tau] = sum_k gm[t0+i][k] H[k][tau] on MFMA, then
 // every P element is added to the diagonal s = t0 + i - tau it belongs to
-// (LDS float atomics, conflict-free: one accumulator register is one P row,
-// i.e. 32 distinct diagonals per half-wave).  Each workgroup writes its partial
+// (through LDS, one thread per diagonal, in a fixed order).  Each workgroup writes its partial
 // gu for s < t0+BM; k_gu_reduce sums the partials in a fixed order.
 // ---------------------------------------------------------------------------
 using ConvBwdTile = Tile<64, 128, 32, 2, 2, KC, NC>;
@@ -380,13 +379,14 @@ __global__ __launch_bounds__(kThreads) void k_conv_bwd(const float* __restrict__
   float* gu_acc = smem + TL::SMEM_FLOATS;  // [t0 + BM] diagonals
   const int b = blockIdx.y;
   const int ntt = gridDim.z;
+  float* ptile = gu_acc + ntt * TL::BM;
   const int tb = ntt - 1 - blockIdx.z;
   const int t0 = tb * TL::BM;
   const int send = min(T, t0 + TL::BM);  // diagonals 0 .. send-1
   const float* gmb = gm + (long)b * T * M;
 
   for (int s = threadIdx.x; s < send; s += kThreads) gu_acc[s] = 0.f;
-  // (the first barrier inside gemm_tile orders this against the atomics)
+  // (the barriers inside gemm_tile order this against the diagonal sums)
 
   auto la = plain_load([=](int r, int k) -> f32x4 {
     const int t = t0 + r;
@@ -402,12 +402,8 @@ __global__ __launch_bounds__(kThreads) void k_conv_bwd(const float* __restrict__
     f32x16 acc[TL::TM][TL::TN];
     tile_zero<TL>(acc);
     gemm_tile<TL>(smem, acc, la, lb, 0, M, w);
-    tile_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
-      const int s = t0 + mm - (tau0 + nn);
-      if (s >= 0 && t0 + mm < T) atomicAdd(&gu_acc[s], v);
-    });
+    add_tile_diagonals<TL>(acc, w, ptile, gu_acc, t0 - tau0, T - 1 - t0);
   }
-  __syncthreads();
   float* out = gu_part + ((long)b * ntt + tb) * T;
   for (int s = threadIdx.x; s < send; s += kThreads) out[s] = gu_acc[s];
 }
@@ -744,7 +740,7 @@ static int conv_backward_toeplitz(const lmufft_shape& s, const float* gm, const 
   using TL = ConvBwdTile;
   const int ntt = cdiv(s.T, TL::BM);
   const dim3 grid(1, s.B, ntt);
-  const size_t lds = (TL::SMEM_FLOATS + (size_t)ntt * TL::BM) * sizeof(float);
+  const size_t lds = (TL::SMEM_FLOATS + (size_t)ntt * TL::BM + (size_t)TL::BM * (TL::BN + 1)) * sizeof(float);
   if (lds > 160 * 1024) return set_error("sequence too long for the Toeplitz backward kernel (T=%d)", s.T);
   const bool vec = (s.ldH % 4 == 0) && (s.T % 4 == 0) && (s.M % 4 == 0) && aligned16(H) && aligned16(gm);
   if (lds > 64 * 1024) {

@@ -89,6 +89,19 @@ def test_conv_backward_matches_oracle(B, T, M, ldH):
     _close(got, orc.anticausal_corr_direct(gm, H[:, :T]), "gu")
 
 
+def test_conv_backward_toeplitz_is_deterministic():
+    """The diagonal sums of the Toeplitz adjoint run in a fixed order: repeated calls agree bit for bit."""
+    from asr_amd import causal_conv_adjoint
+
+    dev = _dev()
+    rng = np.random.default_rng(77)
+    gm = _t(rng.standard_normal((8, 400, 192)).astype(np.float32), dev)
+    H = _t(_rand_H(rng, 192, 400), dev)
+    first = causal_conv_adjoint(gm, H, "toeplitz")
+    for _ in range(5):
+        assert torch.equal(causal_conv_adjoint(gm, H, "toeplitz"), first)
+
+
 def test_conv_long_utterance_3000_frames():
     """The long-utterance shape (30 s audio: T = 3000, memory 192) on the Toeplitz kernels, against
     the oracle's FFT evaluation of the same sums (the direct double sum is O(T^2) on the CPU)."""
