@@ -19,7 +19,7 @@ CONV_AUTO = 0
 CONV_TOEPLITZ = 1
 CONV_FFT = 2
 NOALLOC_SCRATCH_BYTES = 8 << 20
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class Shape(ctypes.Structure):
@@ -112,6 +112,15 @@ def _load():
     lib.lmufft_conv_backward_bf16.argtypes = [sp, vp, vp, vp, vp, sz, vp]
     lib.lmufft_backward_bf16.restype = ci
     lib.lmufft_backward_bf16.argtypes = [sp] + [vp] * 15 + [ci, vp, sz, vp]
+    lib.lmufft_ctc_pack_targets.restype = ci
+    lib.lmufft_ctc_pack_targets.argtypes = [vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, vp, vp, vp]
+    lib.lmufft_grad_norm_workspace_bytes.restype = sz
+    lib.lmufft_grad_norm_workspace_bytes.argtypes = []
+    lib.lmufft_grad_norm2_f32.restype = ci
+    lib.lmufft_grad_norm2_f32.argtypes = [vp, ctypes.c_int64, vp, vp, sz, vp]
+    lib.lmufft_adamw_step_f32.restype = ci
+    lib.lmufft_adamw_step_f32.argtypes = [vp, vp, vp, vp, ctypes.c_int64] + [ctypes.c_float] * 5 + [
+        ctypes.c_int32, vp, ctypes.c_float, vp]
     lib.lmufft_profile_enable.restype = ci
     lib.lmufft_profile_enable.argtypes = [ci]
     lib.lmufft_profile_reset.restype = None
@@ -154,6 +163,10 @@ EXPORTS = (
     "lmufft_linear_ln_bf16",
     "lmufft_ctc_workspace_bytes",
     "lmufft_ctc_greedy",
+    "lmufft_ctc_pack_targets",
+    "lmufft_grad_norm_workspace_bytes",
+    "lmufft_grad_norm2_f32",
+    "lmufft_adamw_step_f32",
     "lmufft_hprep_bytes",
     "lmufft_hprep_bf16",
     "lmufft_wprep_bytes",

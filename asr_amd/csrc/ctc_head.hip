@@ -319,6 +319,47 @@ static int launch_collapse(const int* best, const int32_t* lengths, int B, int T
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Target packing for the CTC loss: the padded [B][Lmax] label matrix -> the labels of all utterances
+// back to back, as LMUASRModel.compute_loss builds them with one .tolist() per utterance
+// (src/models/asr_model.py:145-151).  offsets[b] = first packed position of utterance b,
+// offsets[B] = total.
+// ---------------------------------------------------------------------------
+constexpr int kPackThreads = 256;
+__global__ __launch_bounds__(kPackThreads) void k_ctc_target_offsets(const int32_t* __restrict__ lengths, int B, int Lmax,
+                                                                    int32_t* __restrict__ offsets) {
+  __shared__ int part[kPackThreads];
+  const int per = (B + kPackThreads - 1) / kPackThreads;
+  const int b0 = threadIdx.x * per, b1 = min(B, b0 + per);
+  int s = 0;
+  for (int b = b0; b < b1; ++b) s += min(max(lengths[b], 0), Lmax);
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int i = 0; i < kPackThreads; ++i) {
+      const int v = part[i];
+      part[i] = run;
+      run += v;
+    }
+    offsets[B] = run;
+  }
+  __syncthreads();
+  int run = part[threadIdx.x];
+  for (int b = b0; b < b1; ++b) {
+    offsets[b] = run;
+    run += min(max(lengths[b], 0), Lmax);
+  }
+}
+
+__global__ __launch_bounds__(kPackThreads) void k_ctc_pack_targets(const int64_t* __restrict__ targets, long ld,
+                                                                  const int32_t* __restrict__ offsets,
+                                                                  int64_t* __restrict__ packed) {
+  const int b = blockIdx.x;
+  const int o = offsets[b], len = offsets[b + 1] - o;
+  for (int i = threadIdx.x; i < len; i += kPackThreads) packed[o + i] = targets[(long)b * ld + i];
+}
+
 }  // namespace lmufft
 
 using namespace lmufft;
@@ -396,6 +437,22 @@ int lmufft_ctc_greedy(const void* enc, int dtype, const float* W, const float* b
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error("launch of k_ctc_logits failed: %s", hipGetErrorString(e));
   return launch_collapse(best, lengths, B, T, blank, tokens, counts, st);
+}
+
+int lmufft_ctc_pack_targets(const int64_t* targets, const int32_t* target_lengths, int32_t B, int32_t Lmax, int64_t ld,
+                            int64_t* packed, int32_t* offsets, void* stream) {
+  if (B <= 0 || Lmax <= 0 || ld < Lmax) return set_error("ctc pack: bad shape (B=%d, Lmax=%d, ld=%lld)", B, Lmax, (long long)ld);
+  if ((long)B * Lmax > INT32_MAX) return set_error("ctc pack: %ld labels exceed the index range", (long)B * Lmax);
+  if (!targets || !target_lengths || !packed || !offsets) return set_error("ctc pack: NULL pointer");
+  hipStream_t st = (hipStream_t)stream;
+  {
+    ProfScope ps("k_ctc_pack_targets", st);
+    hipLaunchKernelGGL(k_ctc_target_offsets, dim3(1), dim3(kPackThreads), 0, st, target_lengths, B, Lmax, offsets);
+    hipLaunchKernelGGL(k_ctc_pack_targets, dim3(B), dim3(kPackThreads), 0, st, targets, (long)ld, offsets, packed);
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error("launch of k_ctc_pack_targets failed: %s", hipGetErrorString(e));
+  return 0;
 }
 
 }  // extern "C"

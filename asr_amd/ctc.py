@@ -68,3 +68,35 @@ class CTCDecoder(nn.Module):
         tokens, counts = self.greedy(encoder_output, input_lengths)
         tokens, counts = tokens.cpu(), counts.cpu()
         return [tokens[i, : int(counts[i])].tolist() for i in range(tokens.shape[0])]
+
+
+def pack_targets(targets: torch.Tensor, target_lengths: torch.Tensor, total: Optional[int] = None):
+    """Padded labels [batch, max_len] -> (all labels back to back, offsets [batch + 1]), on the device.
+
+    What LMUASRModel.compute_loss builds before torch's CTC loss (src/models/asr_model.py:145-151) with one
+    `.tolist()` per utterance.  `total` = sum of the lengths when the caller knows it (e.g. from the data loader);
+    otherwise it is read back from the device once, because the packed tensor's size must equal it.
+    """
+    if not targets.is_cuda:
+        raise RuntimeError(f"pack_targets: targets live on {targets.device}; this runs only as a HIP kernel on a GPU "
+                           "(there is no CPU fallback)")
+    if targets.dim() != 2:
+        raise RuntimeError(f"pack_targets: expected [batch, max_len], got {tuple(targets.shape)}")
+    dev = targets.device
+    B, L = targets.shape
+    if target_lengths.numel() != B:
+        raise RuntimeError(f"pack_targets: {target_lengths.numel()} lengths for {B} utterances")
+    t = targets.to(torch.int64)
+    if t.stride(1) != 1:
+        t = t.contiguous()
+    lengths = target_lengths.to(device=dev, dtype=torch.int32).contiguous()
+    packed = torch.empty(B * L, dtype=torch.int64, device=dev)
+    offsets = torch.empty(B + 1, dtype=torch.int32, device=dev)
+    p = lambda x: ctypes.c_void_p(x.data_ptr())  # noqa: E731
+    with torch.cuda.device(dev):
+        rc = _lib.lib.lmufft_ctc_pack_targets(p(t), p(lengths), B, L, t.stride(0), p(packed), p(offsets),
+                                              ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    _lib.check(rc, "lmufft_ctc_pack_targets")
+    if total is None:
+        total = int(offsets[B].item())
+    return packed[:total], offsets

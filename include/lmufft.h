@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMUFFT_ABI_VERSION 7
+#define LMUFFT_ABI_VERSION 8
 
 /* element types of the activations (x, h, gh, gx, m) */
 #define LMUFFT_F32 0
@@ -243,6 +243,42 @@ int lmufft_ctc_greedy(const void* enc, int dtype, const float* W, const float* b
                       const int32_t* lengths, int32_t B, int32_t T, int32_t Hd, int32_t V,
                       int32_t blank, float* log_probs, int32_t* tokens, int32_t* counts,
                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * CTC target packing.  Replaces the label concatenation at the head of
+ * LMUASRModel.compute_loss, src/models/asr_model.py:145-151 (a Python loop with one
+ * device-to-host .tolist() per utterance):
+ *   targets [B][ld] int64 labels, utterance b holds target_lengths[b] <= Lmax of them
+ *   (lengths are clamped to 0..Lmax); packed [sum of lengths] (B * Lmax always
+ *   suffices); offsets [B + 1] int32: first packed position of every utterance,
+ *   offsets[B] = the total.  Everything stays on the device.
+ * ---------------------------------------------------------------------- */
+int lmufft_ctc_pack_targets(const int64_t* targets, const int32_t* target_lengths, int32_t B,
+                            int32_t Lmax, int64_t ld, int64_t* packed, int32_t* offsets,
+                            void* stream);
+
+/* ------------------------------------------------------------------------
+ * Optimizer step of the training loop on flat fp32 arenas.  Replaces the per-parameter
+ * gradient-norm loop, the NaN check, clip_grad_norm_ and torch.optim.AdamW.step of
+ * DistributedTrainer.train_epoch, src/training/distributed.py:207-231 (optimizer
+ * built at :92-98; clipping in src/training/utils.py:653-665).
+ *   lmufft_grad_norm2_f32: norm2[0] (device) = sum of squares of grads[0..n), summed in
+ *   a fixed order; workspace of lmufft_grad_norm_workspace_bytes().
+ *   lmufft_adamw_step_f32: decoupled weight decay, bias-corrected moments, eps 1e-8
+ *   style denominator sqrt(v)/sqrt(1 - beta2^step) + eps, as torch.optim.AdamW;
+ *   step counts from 1.  norm2 != NULL: the gradients are scaled by
+ *   min(1, max_norm / (sqrt(norm2[0]) + 1e-6)) on the fly, and the whole update is
+ *   skipped when the norm is NaN (the reference skips such a batch); norm2 == NULL:
+ *   no clipping.  params, grads, exp_avg, exp_avg_sq: n floats each, 16-byte aligned,
+ *   same element order.
+ * ---------------------------------------------------------------------- */
+size_t lmufft_grad_norm_workspace_bytes(void);
+int lmufft_grad_norm2_f32(const float* grads, int64_t n, float* norm2, void* workspace,
+                          size_t workspace_bytes, void* stream);
+int lmufft_adamw_step_f32(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                          int64_t n, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, int32_t step, const float* norm2, float max_norm,
+                          void* stream);
 
 /* ------------------------------------------------------------------------
  * Masked self-attention core for inference.  Replaces the score / softmax /
