@@ -368,7 +368,6 @@ def conv_pair_runner(u, H, conv_algo, dtype):
     B, T = u.shape
     M, ldH = H.shape
     shp = _shape(B, T, 1, M, 1, ldH)
-    st = _stream(dev)
     if dtype == "bf16":
         hprep = prepare_impulse_bf16(H)
         m = torch.empty((B, T, M), dtype=torch.bfloat16, device=dev)
@@ -376,6 +375,7 @@ def conv_pair_runner(u, H, conv_algo, dtype):
         ws = _workspace(_lib.lib.lmufft_conv_workspace_bytes(ctypes.byref(shp), _lib.BF16, _lib.CONV_AUTO), dev)
 
         def run():
+            st = _stream(dev)  # the stream current at the call (a capturing stream under graph capture)
             _lib.check(_lib.lib.lmufft_conv_forward_bf16(ctypes.byref(shp), _ptr(u), _ptr(hprep), _ptr(m), st),
                        "lmufft_conv_forward_bf16")
             _lib.check(_lib.lib.lmufft_conv_backward_bf16(ctypes.byref(shp), _ptr(m), _ptr(hprep), _ptr(gu), _ptr(ws),
@@ -390,6 +390,7 @@ def conv_pair_runner(u, H, conv_algo, dtype):
     ws = _workspace(_lib.lib.lmufft_conv_workspace_bytes(ctypes.byref(shp), _lib.F32, algo), dev)
 
     def run():
+        st = _stream(dev)
         _lib.check(_lib.lib.lmufft_conv_forward_f32(ctypes.byref(shp), _ptr(u), _ptr(H), _ptr(fftprep), _ptr(m), algo,
                                                    _ptr(ws), ws.numel(), st), "lmufft_conv_forward_f32")
         _lib.check(_lib.lib.lmufft_conv_backward_f32(ctypes.byref(shp), _ptr(m), _ptr(H), _ptr(fftprep), _ptr(gu), algo,

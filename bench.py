@@ -225,11 +225,27 @@ def bench_conv(args, dev):
         for _ in range(args.warmup):
             run()
         torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
+        # ten pairs per HIP graph, so that the wall clock sees the kernels and their boundaries, not the host's
+        # launch latency (the pair is three to four launches of 5-30 us)
+        reps = 10
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
             run()
+            with torch.cuda.graph(graph, stream=side):
+                for _ in range(reps):
+                    run()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        n_replays = max(1, args.steps // reps)
+        for _ in range(3):
+            graph.replay()
         torch.cuda.synchronize(dev)
-        wall = (time.perf_counter() - t0) / args.steps
+        t0 = time.perf_counter()
+        for _ in range(n_replays):
+            graph.replay()
+        torch.cuda.synchronize(dev)
+        wall = (time.perf_counter() - t0) / (n_replays * reps)
         _lib.profile_reset()
         _lib.profile_enable(True)
         for _ in range(10):
@@ -239,14 +255,17 @@ def bench_conv(args, dev):
         per_kernel = read_profile(_lib, 10)
         t_k = sum(v["total_ms_per_step"] for v in per_kernel.values()) * 1e-3
         nbytes = B * T * (2 * M + 2) * esize  # u in, m out; gm in, gu out
+        per_kernel = {k: v for k, v in per_kernel.items() if v["launches_per_step"] > 0}
+        # priced on the wall clock of the replayed pairs; the event-bracketed kernel times (eager launches, each
+        # bracket includes its dispatch) are listed beside it
         out[route] = {"wall_us": wall * 1e6, "kernels_us": t_k * 1e6, "algorithmic_bytes": nbytes,
-                      "achieved_GBs": nbytes / t_k / 1e9, "frac": nbytes / t_k / 1e9 / HBM_PEAK_GBS,
+                      "achieved_GBs": nbytes / wall / 1e9, "frac": nbytes / wall / 1e9 / HBM_PEAK_GBS,
                       "kernels": per_kernel}
     best = max(out, key=lambda r: out[r]["frac"])
     return {
-        "metric": "LMU causal convolution fwd+adjoint frames/sec", "value": B * T / (out[best]["kernels_us"] * 1e-6),
+        "metric": "LMU causal convolution fwd+adjoint frames/sec", "value": B * T / (out[best]["wall_us"] * 1e-6),
         "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": out[best]["kernels_us"] * 1e-3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": out[best]["wall_us"] * 1e-3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"conv-only unit: u[{B},{T}] * H[{M},{T}] -> m and its adjoint, {args.dtype}",
                    "route": best},

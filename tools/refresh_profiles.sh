@@ -14,4 +14,14 @@ for dt in bf16 f32; do
     timeout -s KILL 180 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$dt/$c -o p -- python3 bench.py --dtype $dt --steps 5 --warmup 1 --no-graph > $O/pmc_${dt}_$c.log 2>&1
   done
 done
+export PYTHONPATH=$PWD
+for shape in "64 400" "16 400" "32 3000"; do
+  set -- $shape
+  for dt in bf16 f32; do
+    timeout -k 10 240 python3 bench.py --unit conv --dtype $dt --batch $1 --frames $2 >> $O/bench_conv.jsonl 2>> $O/bench_conv.err
+  done
+done
+timeout -k 10 240 python3 tools/mel_bench.py > $O/mel_bench.txt 2>&1
+timeout -k 10 240 python3 tools/infer_bench.py > $O/infer_bench.json 2> $O/infer_bench.err
+timeout -k 10 240 python3 tools/t3000.py > $O/t3000.txt 2>&1
 echo done > $O/DONE
