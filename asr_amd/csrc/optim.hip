@@ -54,12 +54,21 @@ __global__ __launch_bounds__(kOptThreads) void k_grad_sumsq(const float* __restr
   if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
 
-// norm2[0] = sum of the partials, in order, in double
-__global__ __launch_bounds__(64) void k_grad_sumsq_final(const float* __restrict__ partial, int nb, float* __restrict__ norm2) {
+// norm2[0] = sum of the partials in double, in a fixed tree order: thread t adds partials t, t + 256, ...,
+// then the xor tree of each wave, then the four wave sums in order
+__global__ __launch_bounds__(kOptThreads) void k_grad_sumsq_final(const float* __restrict__ partial, int nb,
+                                                                  float* __restrict__ norm2) {
+  __shared__ double red[kOptThreads / 64];
+  double t = 0.0;
+  for (int i = threadIdx.x; i < nb; i += kOptThreads) t += (double)partial[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+  __syncthreads();
   if (threadIdx.x == 0) {
-    double t = 0.0;
-    for (int i = 0; i < nb; ++i) t += (double)partial[i];
-    norm2[0] = (float)t;
+    double tot = 0.0;
+    for (int w = 0; w < kOptThreads / 64; ++w) tot += red[w];
+    norm2[0] = (float)tot;
   }
 }
 
@@ -134,7 +143,7 @@ int lmufft_grad_norm2_f32(const float* grads, int64_t n, float* norm2, void* wor
   {
     ProfScope ps("k_grad_sumsq", st);
     hipLaunchKernelGGL(k_grad_sumsq, dim3(nb), dim3(kOptThreads), 0, st, grads, (long)n, partial);
-    hipLaunchKernelGGL(k_grad_sumsq_final, dim3(1), dim3(64), 0, st, partial, nb, norm2);
+    hipLaunchKernelGGL(k_grad_sumsq_final, dim3(1), dim3(kOptThreads), 0, st, partial, nb, norm2);
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error("launch of k_grad_sumsq failed: %s", hipGetErrorString(e));

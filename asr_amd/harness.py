@@ -138,11 +138,12 @@ class _MultiHeadAttention(nn.Module):
     """softmax(Q K^T / sqrt(d_k), masked) V, output projection, residual, layer norm
     (reference: src/models/lmu_encoder.py:48-99)."""
 
-    def __init__(self, d_model: int, num_heads: int):
+    def __init__(self, d_model: int, num_heads: int, dropout: float = 0.0):
         super().__init__()
         if d_model % num_heads:
             raise ValueError("d_model must be a multiple of num_heads")
         self.num_heads, self.d_k = num_heads, d_model // num_heads
+        self.dropout = nn.Dropout(dropout)  # on the attention weights (src/models/lmu_encoder.py:45, 86); identity in eval
         self.w_q = nn.Linear(d_model, d_model)
         self.w_k = nn.Linear(d_model, d_model)
         self.w_v = nn.Linear(d_model, d_model)
@@ -152,7 +153,8 @@ class _MultiHeadAttention(nn.Module):
     def forward(self, x: torch.Tensor, lengths: Optional[torch.Tensor],
                 out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
         B, T, C = x.shape
-        if x.is_cuda and self.d_k in SUPPORTED_HEAD_WIDTHS and not torch.is_grad_enabled():
+        if (x.is_cuda and self.d_k in SUPPORTED_HEAD_WIDTHS and not torch.is_grad_enabled()
+                and not (self.training and self.dropout.p > 0)):
             # HIP kernel: no [B, heads, T, T] score tensor, no per-utterance mask loop
             _took("hip", "attention")
             if all(l.bias is not None for l in (self.w_q, self.w_k, self.w_v)):
@@ -172,14 +174,14 @@ class _MultiHeadAttention(nn.Module):
             valid = torch.arange(T, device=x.device)[None, :] < lengths.to(x.device)[:, None]
             mask = valid[:, :, None] & valid[:, None, :]
             scores = scores.masked_fill(~mask[:, None], -1e9)
-        ctx = (torch.softmax(scores, dim=-1) @ v).transpose(1, 2).reshape(B, T, C)
+        ctx = (self.dropout(torch.softmax(scores, dim=-1)) @ v).transpose(1, 2).reshape(B, T, C)
         return _layer_norm(self.layer_norm, self.w_o(ctx), x, out_dtype)
 
 
 class _SelfAttention(nn.Module):
-    def __init__(self, d_model: int, num_heads: int):
+    def __init__(self, d_model: int, num_heads: int, dropout: float = 0.0):
         super().__init__()
-        self.attention = _MultiHeadAttention(d_model, num_heads)
+        self.attention = _MultiHeadAttention(d_model, num_heads, dropout)
 
     def forward(self, x, lengths, out_dtype=None):
         return self.attention(x, lengths, out_dtype)
@@ -199,12 +201,13 @@ class LMUEncoder(nn.Module):
         self.hidden_size, self.use_attention = hidden_size, use_attention
         self.input_projection = nn.Linear(input_size, hidden_size)
         self.attention_layers = nn.ModuleList(
-            [_SelfAttention(hidden_size, num_attention_heads) if use_attention else nn.Identity()
+            [_SelfAttention(hidden_size, num_attention_heads, dropout) if use_attention else nn.Identity()
              for _ in range(num_lmu_layers)])
         self.lmu_layers = nn.ModuleList(
             [LMUFFT(hidden_size, hidden_size, memory_size, seq_len, theta) for _ in range(num_lmu_layers)])
         self.layer_norms = nn.ModuleList([nn.LayerNorm(hidden_size) for _ in range(num_lmu_layers)])
         self.output_projection = nn.Linear(hidden_size, hidden_size)
+        self.dropout_layer = nn.Dropout(dropout)  # after every layer norm (src/models/lmu_encoder.py:232, 277); identity in eval
         # Under autocast torch's layer_norm returns fp32, and every consumer (three projections, the
         # LMU layer) casts that tensor to bf16 again.  With bf16_stream the layer norms write bf16
         # directly: the casts disappear and the residual is the bf16-rounded activation -- a
@@ -220,13 +223,14 @@ class LMUEncoder(nn.Module):
         for att, lmu, ln in zip(self.attention_layers, self.lmu_layers, self.layer_norms):
             if self.use_attention:
                 x = att(x, lengths, stream)
-            if ln.elementwise_affine and ln.bias is not None and lmu.supports_fused_layer_norm(x):
+            drop = self.training and self.dropout_layer.p > 0
+            if not drop and ln.elementwise_affine and ln.bias is not None and lmu.supports_fused_layer_norm(x):
                 # the layer norm rides on the projection kernel's epilogue: h never goes to HBM
                 x, h_n = lmu.forward_layer_norm(
                     x, ln, stream or (torch.float32 if torch.is_autocast_enabled() else x.dtype))
             else:
                 x, h_n = lmu(x)
-                x = _layer_norm(ln, x, None, stream)
+                x = self.dropout_layer(_layer_norm(ln, x, None, stream))
             states.append(h_n)
         return _linear(self.output_projection, x), states
 
@@ -238,9 +242,9 @@ class LMUASRModel(nn.Module):
     """Encoder + CTC head with the reference model's state_dict layout (src/models/asr_model.py:53-128)."""
 
     def __init__(self, input_size, hidden_size, memory_size, num_lmu_layers, theta, seq_len, vocab_size,
-                 num_attention_heads=8, use_attention=True):
+                 num_attention_heads=8, use_attention=True, dropout=0.0):
         super().__init__()
-        self.encoder = LMUEncoder(input_size, hidden_size, memory_size, num_lmu_layers, theta, 0.0, True, seq_len,
+        self.encoder = LMUEncoder(input_size, hidden_size, memory_size, num_lmu_layers, theta, dropout, True, seq_len,
                                   use_attention, num_attention_heads)
         self.decoder = CTCDecoder(hidden_size, vocab_size)
         self.vocab_size = vocab_size
@@ -255,3 +259,21 @@ class LMUASRModel(nn.Module):
         """Greedy CTC token lists (the reference's decode(log_probs, input_lengths, beam_width=1))."""
         encoded, _ = self.encoder(spectrograms, input_lengths)
         return self.decoder.decode(encoded, input_lengths)
+
+    def log_probs_for_training(self, spectrograms: torch.Tensor, input_lengths: Optional[torch.Tensor] = None):
+        """Log-probabilities with an autograd graph (the reference's LMUASRModel.forward in training,
+        src/models/asr_model.py:110-128).  The LMUFFT layers run their HIP forward and backward; attention, layer
+        norms, projections and the head are torch ops here (their HIP kernels are inference-only)."""
+        encoded, _ = self.encoder(spectrograms, input_lengths)
+        logits = torch.nn.functional.linear(encoded, self.decoder.ctc_projection.weight, self.decoder.ctc_projection.bias)
+        return torch.log_softmax(logits.float(), dim=-1)
+
+    def compute_loss(self, log_probs: torch.Tensor, targets: torch.Tensor, input_lengths: torch.Tensor,
+                     target_lengths: torch.Tensor, total_targets: Optional[int] = None) -> torch.Tensor:
+        """CTC loss as the reference builds it (src/models/asr_model.py:130-156; nn.CTCLoss(blank=vocab_size-1,
+        reduction='mean', zero_infinity=True), :105), with the labels packed on the device."""
+        from .ctc import pack_targets
+
+        packed, _ = pack_targets(targets, target_lengths, total_targets)
+        return torch.nn.functional.ctc_loss(log_probs.transpose(0, 1), packed, input_lengths, target_lengths,
+                                            blank=self.vocab_size - 1, reduction="mean", zero_infinity=True)

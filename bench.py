@@ -40,9 +40,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c2_lmu", choices=["c2_lmu", "c3"],
+    ap.add_argument("--workload", default="c2_lmu", choices=["c2_lmu", "c3", "c2_full"],
                     help="c2_lmu: batch 64 per GPU (single-GPU training configuration); c3: batch 96 per GPU "
-                         "(the 8-GPU data-parallel configuration)")
+                         "(the 8-GPU data-parallel configuration); c2_full: the whole model's train step at batch 64 "
+                         "(LMUFFT layers, optimizer and target packing as HIP kernels, the rest torch ops)")
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (overrides --workload)")
     ap.add_argument("--frames", type=int, default=400)
     ap.add_argument("--layers", type=int, default=3)
@@ -275,6 +276,108 @@ def bench_conv(args, dev):
     }
 
 
+def bench_full_step(args, dev, rank, world):
+    """The reference's whole training step at its single-GPU configuration: mel-shaped input -> 3-layer encoder
+    (attention, LMUFFT, layer norm, dropout 0.1) -> CTC head and loss -> backward -> clip 10 -> AdamW -> scheduler
+    (configs/base_config.yaml:3-15, 29-36; src/training/distributed.py:139-234), bf16 autocast.  This package's
+    kernels run the LMUFFT layers, the gradient norm / clipping / AdamW step and the target packing; attention,
+    layer norms, projections, dropout and the CTC loss are torch ops (their HIP kernels here are inference-only),
+    so this line measures the model with the hot path swapped in, not a roofline."""
+    import torch
+    import torch.distributed as dist
+
+    from asr_amd import FlatAdamW, LearningRateScheduler, _lib
+    from asr_amd.harness import LMUASRModel
+    from asr_amd.parallel import GradBuckets
+
+    B, T = args.batch, args.frames
+    torch.manual_seed(1234)
+    model = LMUASRModel(80, args.hidden, args.memory, args.layers, args.theta, T, 34, num_attention_heads=6,
+                        dropout=0.1).to(dev).train()
+    for mod in model.modules():  # src/models/asr_model.py:271-276
+        if isinstance(mod, torch.nn.Linear):
+            torch.nn.init.xavier_uniform_(mod.weight)
+            torch.nn.init.zeros_(mod.bias)
+    enc = model.encoder
+    groups = [[*model.decoder.parameters(), *enc.output_projection.parameters()]]
+    for i in reversed(range(args.layers)):  # the order in which the backward completes them
+        groups += [list(enc.layer_norms[i].parameters()), enc.lmu_layers[i], list(enc.attention_layers[i].parameters())]
+    groups.append(list(enc.input_projection.parameters()))
+    buckets = GradBuckets(groups, bucket_mb=args.bucket_mb if args.bucket_mb is not None else 4.0,
+                          overlap=not args.no_overlap)
+    opt = FlatAdamW(buckets=buckets, lr=1.5e-3, betas=(0.9, 0.999), weight_decay=0.01, max_grad_norm=10.0)
+    sched = LearningRateScheduler(opt, warmup_steps=1500, max_lr=1.5e-3)
+    g = torch.Generator(device=dev).manual_seed(1234 + 2 + rank)
+    spec = torch.randn(B, T, 80, device=dev, generator=g)
+    in_len = torch.full((B,), T, dtype=torch.long, device=dev)
+    tgt_len = torch.randint(20, 61, (B,), device=dev, generator=g)
+    targets = torch.randint(0, 33, (B, 60), device=dev, generator=g)
+    total = int(tgt_len.sum().item())  # a data loader knows this; keeps the step free of read-backs
+    losses = []
+
+    def step():
+        buckets.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            lp = model.log_probs_for_training(spec, in_len)
+        loss = model.compute_loss(lp, targets, in_len, tgt_len, total)
+        loss.backward()
+        buckets.finish()
+        opt.step()
+        sched.step()
+        return loss
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        losses.append(step())
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses.append(step())
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    per_kernel = {}
+    psteps = min(args.steps, 5)
+    if rank == 0:
+        _lib.profile_reset()
+        _lib.profile_enable(True)
+    for _ in range(psteps):
+        step()
+    torch.cuda.synchronize(dev)
+    if rank == 0:
+        _lib.profile_enable(False)
+        per_kernel = read_profile(_lib, psteps)
+    if rank != 0:
+        return None
+    hip_ms = sum(v["total_ms_per_step"] for v in per_kernel.values())
+    first, last = float(losses[0].detach()), float(losses[-1].detach())
+    return {
+        "metric": "full train step frames/sec (whole model, hot path swapped in)",
+        "value": world * B * T / (elapsed / args.steps), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"3-layer LMU ASR model (80 -> {args.hidden}/{args.memory}, 6 heads, vocab 34, dropout 0.1, "
+                               f"seq_len {T}), batch {B} per GPU, bf16 autocast: forward + CTC loss + backward + clip 10 + "
+                               "AdamW(1.5e-3, wd 0.01) + warm-up scheduler, eager launches",
+                   "batch_per_gpu": B, "frames": T, "parallelism": f"dp{world}", "world_size": world,
+                   "hip_kernels": "LMUFFT forward/backward, gradient norm + clip + AdamW, CTC target packing",
+                   "torch_ops": "attention, layer norms, Linear projections, dropout, log-softmax, CTC loss",
+                   "gradient_buckets": len(buckets.buckets)},
+        "roofline": None,
+        "hip_kernel_ms_per_step": hip_ms,
+        "loss_first_last": [first, last],
+        "kernels": per_kernel,
+    }
+
+
 def main():
     args = parse_args()
     world_env = os.environ.get("WORLD_SIZE")
@@ -301,6 +404,15 @@ def main():
         if dist.get_world_size() != args.gpus or dist.get_backend() != "nccl":
             raise SystemExit(f"process group has {dist.get_world_size()} ranks on {dist.get_backend()}, "
                              f"expected {args.gpus} on nccl")
+
+    if args.workload == "c2_full":
+        out = bench_full_step(args, dev, rank, world)
+        if rank == 0:
+            print(json.dumps(out))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from asr_amd import LMUFFT, _lib
     from asr_amd.parallel import GradBuckets
