@@ -19,7 +19,7 @@ CONV_AUTO = 0
 CONV_TOEPLITZ = 1
 CONV_FFT = 2
 NOALLOC_SCRATCH_BYTES = 8 << 20
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class Shape(ctypes.Structure):
@@ -112,6 +112,12 @@ def _load():
     lib.lmufft_conv_backward_bf16.argtypes = [sp, vp, vp, vp, vp, sz, vp]
     lib.lmufft_backward_bf16.restype = ci
     lib.lmufft_backward_bf16.argtypes = [sp] + [vp] * 15 + [ci, vp, sz, vp]
+    u32, i32, i64, f32 = ctypes.c_uint32, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+    lib.lmufft_attention_fwd_train.restype = ci
+    lib.lmufft_attention_fwd_train.argtypes = [vp, vp, vp, ci, i64, vp, i32, i32, i32, i32, f32, u32, u32, vp, vp, vp]
+    lib.lmufft_attention_bwd.restype = ci
+    lib.lmufft_attention_bwd.argtypes = [vp, vp, vp, vp, vp, vp, ci, i64, vp, i32, i32, i32, i32, f32, u32, u32,
+                                         vp, vp, vp, i64, vp, vp]
     lib.lmufft_ctc_pack_targets.restype = ci
     lib.lmufft_ctc_pack_targets.argtypes = [vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, vp, vp, vp]
     lib.lmufft_grad_norm_workspace_bytes.restype = sz
@@ -158,6 +164,8 @@ EXPORTS = (
     "lmufft_mel_forward_f32",
     "lmufft_attention_fwd",
     "lmufft_attention_fwd_ld",
+    "lmufft_attention_fwd_train",
+    "lmufft_attention_bwd",
     "lmufft_add_layernorm",
     "lmufft_linear_bf16",
     "lmufft_linear_ln_bf16",

@@ -1,4 +1,5 @@
-"""Masked self-attention core on the GPU (HIP kernel k_attention_fwd; inference, no autograd).
+"""Masked self-attention core on the GPU (HIP kernels k_attention_fwd for inference; k_attention_fwd with
+dropout + k_attention_bwd_dq / k_attention_bwd_dkv behind an autograd function for training).
 
 Mirrors the score / softmax / context part of the reference's MultiHeadAttention.forward
 (src/models/lmu_encoder.py:68-91) with the length mask of LMUEncoder.forward (:247-252), on the
@@ -73,3 +74,80 @@ def masked_attention_packed(qkv: torch.Tensor, num_heads: int, lengths: Optional
             vp(torch.cuda.current_stream(qkv.device).cuda_stream))
     _lib.check(rc, "lmufft_attention_fwd_ld")
     return ctx
+
+
+class _AttentionTrain(torch.autograd.Function):
+    """q, k, v [B, T, heads * d_k] -> context, with dropout on the attention weights; the backward recomputes
+    the weights tile by tile from the saved row statistics and the dropout decisions from the seeds."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, lengths, num_heads, p_drop, seed0, seed1):
+        B, T, C = q.shape
+        dk = C // num_heads
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        out = torch.empty_like(q)
+        stats = torch.empty((B, num_heads, T, 2), dtype=torch.float32, device=q.device)
+        p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        with torch.cuda.device(q.device):
+            rc = _lib.lib.lmufft_attention_fwd_train(
+                p(q), p(k), p(v), _DTYPES[q.dtype], C, p(lengths), B, T, num_heads, dk, float(p_drop), seed0, seed1,
+                p(out), p(stats), ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream))
+        _lib.check(rc, "lmufft_attention_fwd_train")
+        ctx.save_for_backward(q, k, v, out, stats, lengths)
+        ctx.conf = (num_heads, float(p_drop), seed0, seed1)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, stats, lengths = ctx.saved_tensors
+        num_heads, p_drop, seed0, seed1 = ctx.conf
+        B, T, C = q.shape
+        dk = C // num_heads
+        dout = dout.contiguous()
+        if dout.dtype != q.dtype:
+            dout = dout.to(q.dtype)
+        dq, dkk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        dsum = torch.empty((B, num_heads, T), dtype=torch.float32, device=q.device)
+        p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        with torch.cuda.device(q.device):
+            rc = _lib.lib.lmufft_attention_bwd(
+                p(q), p(k), p(v), p(out), p(dout), p(stats), _DTYPES[q.dtype], C, p(lengths), B, T, num_heads, dk, p_drop,
+                seed0, seed1, p(dq), p(dkk), p(dv), C, p(dsum),
+                ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream))
+        _lib.check(rc, "lmufft_attention_bwd")
+        return dq, dkk, dv, None, None, None, None, None
+
+
+_dropout_calls = 0
+
+
+def masked_attention_train(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int,
+                           lengths: Optional[torch.Tensor] = None, p_drop: float = 0.0, seeds=None) -> torch.Tensor:
+    """masked_attention with autograd and dropout on the attention weights (what MultiHeadAttention.forward does
+    in training, src/models/lmu_encoder.py:72-90).  `seeds` = (seed0, seed1), two 32-bit integers naming the
+    dropout mask of this call; by default torch's seed and a per-process call counter, so runs that start from
+    the same torch.manual_seed and make the same calls draw the same masks."""
+    global _dropout_calls
+    for name, t in (("q", q), ("k", k), ("v", v)):
+        if not t.is_cuda:
+            raise RuntimeError(f"masked_attention_train: `{name}` lives on {t.device}; the kernels run only on a GPU "
+                               "(there is no CPU fallback)")
+    if q.dim() != 3 or q.shape != k.shape or q.shape != v.shape:
+        raise RuntimeError(f"masked_attention_train: q, k, v must share one [batch, frames, channels] shape, got "
+                           f"{tuple(q.shape)}, {tuple(k.shape)}, {tuple(v.shape)}")
+    if q.dtype not in _DTYPES or k.dtype != q.dtype or v.dtype != q.dtype:
+        raise RuntimeError(f"masked_attention_train: dtypes {q.dtype}, {k.dtype}, {v.dtype}; supported: all float32 or "
+                           "all bfloat16")
+    C = q.shape[2]
+    if C % num_heads or C // num_heads not in SUPPORTED_HEAD_WIDTHS:
+        raise RuntimeError(f"masked_attention_train: {C} channels over {num_heads} heads; head widths supported: "
+                           f"{SUPPORTED_HEAD_WIDTHS}")
+    if not 0.0 <= p_drop < 1.0:
+        raise ValueError(f"dropout probability has to be in [0, 1), got {p_drop}")
+    if lengths is not None:
+        lengths = lengths.to(device=q.device, dtype=torch.int32).contiguous()
+    if seeds is None:
+        _dropout_calls += 1
+        seeds = (torch.initial_seed() & 0xFFFFFFFF, _dropout_calls & 0xFFFFFFFF)
+    return _AttentionTrain.apply(q, k, v, lengths, num_heads, p_drop, int(seeds[0]) & 0xFFFFFFFF,
+                                 int(seeds[1]) & 0xFFFFFFFF)

@@ -1,4 +1,5 @@
-// Masked multi-head self-attention core for inference on gfx950:
+// Masked multi-head self-attention core on gfx950 (inference kernels; training forward with dropout and
+// the backward further down):
 //   ctx[b, i, h*dk + d] = sum_j softmax_j( q_i . k_j / sqrt(dk), masked )[j] * v[b, j, h*dk + d]
 // without materialising the [B, H, T, T] score and weight tensors.
 //
@@ -34,12 +35,37 @@ constexpr int kAttnKeys = 32;       // keys per tile
 template <class T>
 __device__ __forceinline__ float attn_ld(const T* p) { return (float)*p; }
 
-template <int DK, class TIO, int NW>
-__global__ __launch_bounds__(64 * NW, DK <= 64 ? 4 : 1) void k_attention_fwd(const TIO* __restrict__ q, const TIO* __restrict__ k,
+// Dropout of the attention weights (src/models/lmu_encoder.py:45, 86) without a stored mask: element
+// (b, h, query, key) is kept when a counter-based hash of its index and the call's two seeds reaches the
+// threshold; the backward kernels evaluate the same function.  fmix32 is the 32-bit avalanche finaliser of
+// MurmurHash3, applied to the low word and again after folding in the high word.
+struct AttnDropout {
+  uint32_t seed0, seed1, threshold;  // keep <=> hash >= threshold; threshold = p * 2^32
+  float inv_keep;                    // 1 / (1 - p)
+};
+__device__ __forceinline__ uint32_t attn_fmix32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x85EBCA6Bu;
+  x ^= x >> 13;
+  x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ bool attn_keep(const AttnDropout& dr, unsigned long long idx) {
+  const uint32_t x = attn_fmix32(attn_fmix32((uint32_t)idx ^ dr.seed0) ^ (uint32_t)(idx >> 32) ^ dr.seed1);
+  return x >= dr.threshold;
+}
+
+// TRAIN: dropout on the weights, and the row statistics (running maximum m, 1 / sum exp(s - m)) are saved for
+// the backward as stats[b][h][query][2] (the pair, not m + log l: a fully masked row has m = -1e9, where
+// fp32 cannot hold the logarithm beside it).
+template <int DK, class TIO, int NW, bool TRAIN = false>
+__global__ __launch_bounds__(64 * NW, DK <= 64 ? (TRAIN ? 2 : 4) : 1) void k_attention_fwd(const TIO* __restrict__ q, const TIO* __restrict__ k,
                                                                 const TIO* __restrict__ v,
                                                                 const int* __restrict__ lengths,
                                                                 TIO* __restrict__ ctx, int T, int H, int ld,
-                                                                float scale) {
+                                                                float scale, AttnDropout dr = AttnDropout{0, 0, 0, 1.f},
+                                                                float* __restrict__ stats = nullptr) {
   static_assert(DK % 32 == 0 && DK <= 128, "head width: 32, 64, 96 or 128");
   constexpr int KP = DK + 1;   // K tile pitch: lane = key, banks (key + d) distinct
   constexpr int VP = DK + 8;   // V tile pitch: lane = d, the two lane halves 4 rows apart land 32 banks apart
@@ -137,6 +163,14 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 4 : 1) void k_attention_fwd(con
     psum += __shfl_xor(psum, 32);
     l_run = l_run * alpha + psum;
     m_run = m_new;
+    if (TRAIN && dr.threshold) {  // the normaliser keeps every weight; the context only the surviving ones
+      const unsigned long long row0 = (((unsigned long long)b * H + h) * T + qi) * T;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int j = j0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        st[i] = attn_keep(dr, row0 + j) ? st[i] * dr.inv_keep : 0.f;
+      }
+    }
 #pragma unroll
     for (int t = 0; t < DT; ++t)
 #pragma unroll
@@ -154,6 +188,11 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 4 : 1) void k_attention_fwd(con
   // O^T / l -> ctx rows (through LDS: lanes hold queries, rows of ctx want lanes along d)
   __syncthreads();
   const float inv = 1.0f / l_run;
+  if (TRAIN && hh == 0 && q_in) {
+    float* sp = stats + 2 * ((((long)b * H + h) * T) + qi);
+    sp[0] = m_run;
+    sp[1] = inv;
+  }
   // each wave owns a strip of 8 queries x KP floats of the (now free) K tile and empties its 32
   // queries in four passes
   constexpr int STRIP = 8 * KP;  // 4 waves x 8 x KP = the K tile; waves 4..7 use the V tile (VP > KP) likewise
@@ -176,6 +215,285 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 4 : 1) void k_attention_fwd(con
       if (qq < T) ctx[base + (long)qq * C + d] = (TIO)ws[ql * KP + d];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Backward of the attention core (training).  With P = softmax(S), S = Q K^T / sqrt(dk) where it is not
+// masked, W = dropout(P), O = W V:
+//   dV = W^T dO;  dW = dO V^T;  dP = dropout'(dW);  dS = P * (dP - D),  D_i = sum_j P_ij dP_ij = dO_i . O_i;
+//   dS = 0 where the score was overwritten by the mask value (masked_fill passes no gradient);
+//   dQ = dS K / sqrt(dk);  dK = dS^T Q / sqrt(dk).
+// Two kernels, no atomics, each a transposed-tile sweep like the forward: k_attention_bwd_dq gives a lane
+// one QUERY (sweeping key tiles: S^T and dW^T tiles by MFMA, P from the saved row statistics, dQ^T accumulated
+// like the forward's O^T) and also writes D; k_attention_bwd_dkv gives a lane one KEY (sweeping query tiles:
+// S and dW tiles with the lane's K and V rows as B operands, dV^T and dK^T accumulated).  fp32 arithmetic on
+// the exact-fp32 MFMA for fp32 and bf16 tensors alike.  The dropout mask is recomputed from the element
+// index (attn_keep), nothing [T x T] is ever stored.
+// ---------------------------------------------------------------------------
+template <int DK, class TIO, int NW>
+__global__ __launch_bounds__(64 * NW) void k_attention_bwd_dq(const TIO* __restrict__ q, const TIO* __restrict__ k,
+                                                              const TIO* __restrict__ v, const TIO* __restrict__ ctx,
+                                                              const TIO* __restrict__ dctx, const float* __restrict__ stats,
+                                                              const int* __restrict__ lengths, TIO* __restrict__ dq,
+                                                              float* __restrict__ dsum, int T, int H, int ld, int ldg,
+                                                              float scale, AttnDropout dr) {
+  constexpr int KP = DK + 1, DT = DK / 32, NS = DK / 2;
+  __shared__ float Ks[kAttnKeys * KP];
+  __shared__ float Vs[kAttnKeys * KP];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int C = H * DK;
+  const int len = lengths ? min(max(lengths[b], 0), T) : T;
+  const long base = (long)b * T * C + (long)h * DK;    // ctx, dctx rows are dense
+  const long ibase = (long)b * T * ld + (long)h * DK;  // q, k, v rows are ld elements apart
+  const long gbase = (long)b * T * ldg + (long)h * DK; // dq rows are ldg elements apart
+  const long bh = (long)b * H + h;
+  const int qi = blockIdx.x * (32 * NW) + wave * 32 + r;
+  const bool q_in = qi < T, q_valid = qi < len;
+
+  float qreg[NS], doreg[NS], D = 0.f;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    qreg[s] = q_in ? attn_ld(q + ibase + (long)qi * ld + s + hh * NS) * scale : 0.f;
+    doreg[s] = q_in ? attn_ld(dctx + base + (long)qi * C + s + hh * NS) : 0.f;
+    D += q_in ? doreg[s] * attn_ld(ctx + base + (long)qi * C + s + hh * NS) : 0.f;
+  }
+  D += __shfl_xor(D, 32);
+  if (hh == 0 && q_in) dsum[bh * T + qi] = D;
+  const float m = q_in ? stats[2 * (bh * T + qi)] : 0.f, invl = q_in ? stats[2 * (bh * T + qi) + 1] : 0.f;
+
+  attn_f16v dqa[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dqa[t][i] = 0.f;
+
+  constexpr int CH = DK / 4;
+  constexpr int NV = (kAttnKeys * CH + 64 * NW - 1) / (64 * NW);
+  attn_f4 kst[NV], vst[NV];
+  auto fetch = [&](int j0) {
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const int idx = tid + n * (64 * NW), row = idx / CH, c = (idx % CH) * 4;
+      if (idx >= kAttnKeys * CH) continue;
+      const int j = min(j0 + row, T - 1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        kst[n][e] = attn_ld(k + ibase + (long)j * ld + c + e);
+        vst[n][e] = attn_ld(v + ibase + (long)j * ld + c + e);
+      }
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const int idx = tid + n * (64 * NW), row = idx / CH, c = (idx % CH) * 4;
+      if (idx >= kAttnKeys * CH) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        Ks[row * KP + c + e] = kst[n][e];
+        Vs[row * KP + c + e] = vst[n][e];
+      }
+    }
+  };
+  const unsigned long long row0 = ((unsigned long long)bh * T + qi) * T;
+
+  fetch(0);
+  for (int j0 = 0; j0 < T; j0 += kAttnKeys) {
+    __syncthreads();
+    stage();
+    __syncthreads();
+    if (j0 + kAttnKeys < T) fetch(j0 + kAttnKeys);
+
+    attn_f16v st, dp;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st[i] = 0.f, dp[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      st = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[r * KP + s + hh * NS], qreg[s], st, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[r * KP + s + hh * NS], doreg[s], dp, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int j = j0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+      const bool inside = q_valid && j < len;
+      const float pv = j < T ? __expf((inside ? st[i] : -1e9f) - m) * invl : 0.f;
+      float dw = dp[i];
+      if (dr.threshold) dw = attn_keep(dr, row0 + j) ? dw * dr.inv_keep : 0.f;
+      st[i] = inside ? pv * (dw - D) * scale : 0.f;
+    }
+    // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+        dqa[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[row * KP + 32 * t + r], st[i], dqa[t], 0, 0, 0);
+    }
+  }
+
+  __syncthreads();
+  constexpr int STRIP = 8 * KP;
+  static_assert(NW <= 8, "two tiles hold eight strips");
+  float* ws = (wave < 4 ? Ks : Vs) + (wave & 3) * STRIP;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int d = 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        if ((r >> 3) == pass) ws[(r & 7) * KP + d] = dqa[t][i];
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private strip: program order suffices
+    for (int idx = lane; idx < 8 * DK; idx += 64) {
+      const int ql = idx / DK, d = idx % DK;
+      const int qq = blockIdx.x * (32 * NW) + wave * 32 + pass * 8 + ql;
+      if (qq < T) dq[gbase + (long)qq * ldg + d] = (TIO)ws[ql * KP + d];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+template <int DK, class TIO, int NW>
+__global__ __launch_bounds__(64 * NW) void k_attention_bwd_dkv(const TIO* __restrict__ q, const TIO* __restrict__ k,
+                                                               const TIO* __restrict__ v, const TIO* __restrict__ dctx,
+                                                               const float* __restrict__ stats, const float* __restrict__ dsum,
+                                                               const int* __restrict__ lengths, TIO* __restrict__ dk,
+                                                               TIO* __restrict__ dv, int T, int H, int ld, int ldg,
+                                                               float scale, AttnDropout dr) {
+  constexpr int KP = DK + 1, DT = DK / 32, NS = DK / 2;
+  __shared__ float Qs[kAttnKeys * KP];
+  __shared__ float Gs[kAttnKeys * KP];  // dO tile
+  __shared__ float Ms[kAttnKeys], Ls[kAttnKeys], Ds[kAttnKeys];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int C = H * DK;
+  const int len = lengths ? min(max(lengths[b], 0), T) : T;
+  const long base = (long)b * T * C + (long)h * DK;
+  const long ibase = (long)b * T * ld + (long)h * DK;
+  const long gbase = (long)b * T * ldg + (long)h * DK;
+  const long bh = (long)b * H + h;
+  const int kj = blockIdx.x * (32 * NW) + wave * 32 + r;  // this lane's key
+  const bool k_in = kj < T, k_valid = kj < len;
+
+  float kreg[NS], vreg[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    kreg[s] = k_in ? attn_ld(k + ibase + (long)kj * ld + s + hh * NS) : 0.f;
+    vreg[s] = k_in ? attn_ld(v + ibase + (long)kj * ld + s + hh * NS) : 0.f;
+  }
+  attn_f16v dka[DT], dva[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dka[t][i] = 0.f, dva[t][i] = 0.f;
+
+  constexpr int CH = DK / 4;
+  constexpr int NV = (kAttnKeys * CH + 64 * NW - 1) / (64 * NW);
+  attn_f4 qst[NV], gst[NV];
+  float mst = 0.f, lst = 0.f, dst = 0.f;
+  auto fetch = [&](int i0) {
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const int idx = tid + n * (64 * NW), row = idx / CH, c = (idx % CH) * 4;
+      if (idx >= kAttnKeys * CH) continue;
+      const int qq = min(i0 + row, T - 1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        qst[n][e] = attn_ld(q + ibase + (long)qq * ld + c + e);
+        gst[n][e] = attn_ld(dctx + base + (long)qq * C + c + e);
+      }
+    }
+    if (tid < kAttnKeys) {  // rows past T get weight 0 through 1/l = 0
+      const int qq = i0 + tid;
+      mst = qq < T ? stats[2 * (bh * T + qq)] : 0.f;
+      lst = qq < T ? stats[2 * (bh * T + qq) + 1] : 0.f;
+      dst = qq < T ? dsum[bh * T + qq] : 0.f;
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const int idx = tid + n * (64 * NW), row = idx / CH, c = (idx % CH) * 4;
+      if (idx >= kAttnKeys * CH) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        Qs[row * KP + c + e] = qst[n][e];
+        Gs[row * KP + c + e] = gst[n][e];
+      }
+    }
+    if (tid < kAttnKeys) {
+      Ms[tid] = mst;
+      Ls[tid] = lst;
+      Ds[tid] = dst;
+    }
+  };
+
+  fetch(0);
+  for (int i0 = 0; i0 < T; i0 += kAttnKeys) {
+    __syncthreads();
+    stage();
+    __syncthreads();
+    if (i0 + kAttnKeys < T) fetch(i0 + kAttnKeys);
+
+    // S[query r'][key] and dW[query r'][key]: lane supplies Q / dO of query r and its own K / V values
+    attn_f16v st, dp;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st[i] = 0.f, dp[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      st = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[r * KP + s + hh * NS], kreg[s], st, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Gs[r * KP + s + hh * NS], vreg[s], dp, 0, 0, 0);
+    }
+    // register i of this lane: query i0 + rho_i + 4*hh, key kj
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * hh, qq = i0 + row;
+      const bool inside = qq < len && k_valid;
+      const float pv = __expf((inside ? st[i] * scale : -1e9f) - Ms[row]) * Ls[row];
+      const bool keep = dr.threshold ? attn_keep(dr, ((unsigned long long)bh * T + qq) * T + kj) : true;
+      const float dw = keep ? dp[i] * dr.inv_keep : 0.f;
+      st[i] = keep ? pv * dr.inv_keep : 0.f;                 // W[query][key]
+      dp[i] = inside ? pv * (dw - Ds[row]) * scale : 0.f;    // dS[query][key] / sqrt(dk)
+    }
+    // dV^T[d][key] += dO^T[d][query] W[query][key];  dK^T[d][key] += Q^T[d][query] dS[query][key]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        dva[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Gs[row * KP + 32 * t + r], st[i], dva[t], 0, 0, 0);
+        dka[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[row * KP + 32 * t + r], dp[i], dka[t], 0, 0, 0);
+      }
+    }
+  }
+
+  __syncthreads();
+  constexpr int STRIP = 8 * KP;
+  static_assert(NW <= 8, "two tiles hold eight strips");
+  float* ws = (wave < 4 ? Qs : Gs) + (wave & 3) * STRIP;
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    TIO* out = which ? dv : dk;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int d = 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          if ((r >> 3) == pass) ws[(r & 7) * KP + d] = which ? dva[t][i] : dka[t][i];
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private strip: program order suffices
+      for (int idx = lane; idx < 8 * DK; idx += 64) {
+        const int kl = idx / DK, d = idx % DK;
+        const int kk = blockIdx.x * (32 * NW) + wave * 32 + pass * 8 + kl;
+        if (kk < T) out[gbase + (long)kk * ldg + d] = (TIO)ws[kl * KP + d];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
   }
 }
 
@@ -437,6 +755,96 @@ int lmufft_attention_fwd_ld(const void* q, const void* k, const void* v, int dty
 #undef ATTN_LAUNCH_W
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error("launch of k_attention_fwd failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
+static AttnDropout attn_dropout(float p_drop, uint32_t seed0, uint32_t seed1) {
+  AttnDropout dr;
+  dr.seed0 = seed0;
+  dr.seed1 = seed1;
+  const double t = (double)p_drop * 4294967296.0;
+  dr.threshold = p_drop > 0.f ? (uint32_t)(t < 1.0 ? 1.0 : (t > 4294967295.0 ? 4294967295.0 : t)) : 0u;
+  dr.inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+  return dr;
+}
+static int attn_train_check(const char* what, int64_t ld, int64_t ld_grad, int32_t B, int32_t T, int32_t H, int32_t DK,
+                            int dtype, float p_drop) {
+  if (B <= 0 || T <= 0 || H <= 0) return set_error("%s: bad shape (B=%d T=%d H=%d)", what, B, T, H);
+  if (ld < (int64_t)H * DK || ld > 0x7fffffff || ld_grad < (int64_t)H * DK || ld_grad > 0x7fffffff)
+    return set_error("%s: row strides %lld / %lld", what, (long long)ld, (long long)ld_grad);
+  if (DK != 32 && DK != 64 && DK != 128) return set_error("%s: head width %d; supported: 32, 64, 128", what, DK);
+  if (dtype != LMUFFT_F32 && dtype != LMUFFT_BF16) return set_error("%s: unknown dtype %d", what, dtype);
+  if (H > 65535 || B > 65535) return set_error("%s: H and B must fit a grid dimension", what);
+  if (!(p_drop >= 0.f && p_drop < 1.f)) return set_error("%s: dropout probability %g outside [0, 1)", what, (double)p_drop);
+  return 0;
+}
+
+int lmufft_attention_fwd_train(const void* q, const void* k, const void* v, int dtype, int64_t ld, const int32_t* lengths,
+                               int32_t B, int32_t T, int32_t H, int32_t DK, float p_drop, uint32_t seed0, uint32_t seed1,
+                               void* ctx, float* stats, void* stream) {
+  if (int rc = attn_train_check("attention forward (training)", ld, ld, B, T, H, DK, dtype, p_drop)) return rc;
+  if (!q || !k || !v || !ctx || !stats) return set_error("attention forward (training): NULL pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const AttnDropout dr = attn_dropout(p_drop, seed0, seed1);
+  constexpr int NWV = 4;
+  const dim3 grid((T + 32 * NWV - 1) / (32 * NWV), H, B);
+  const float scale = 1.0f / sqrtf((float)DK);
+#define ATTN_TRAIN_FWD(DKV, TY)                                                                                   \
+  hipLaunchKernelGGL((k_attention_fwd<DKV, TY, NWV, true>), grid, dim3(64 * NWV), 0, st, (const TY*)q, (const TY*)k, \
+                     (const TY*)v, lengths, (TY*)ctx, T, H, (int)ld, scale, dr, stats)
+  {
+    ProfScope ps("k_attention_fwd_train", st);
+    if (dtype == LMUFFT_F32) {
+      if (DK == 32) ATTN_TRAIN_FWD(32, float);
+      else if (DK == 64) ATTN_TRAIN_FWD(64, float);
+      else ATTN_TRAIN_FWD(128, float);
+    } else {
+      if (DK == 32) ATTN_TRAIN_FWD(32, attn_bf16);
+      else if (DK == 64) ATTN_TRAIN_FWD(64, attn_bf16);
+      else ATTN_TRAIN_FWD(128, attn_bf16);
+    }
+  }
+#undef ATTN_TRAIN_FWD
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error("launch of k_attention_fwd (training) failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
+int lmufft_attention_bwd(const void* q, const void* k, const void* v, const void* ctx, const void* dctx, const float* stats,
+                         int dtype, int64_t ld, const int32_t* lengths, int32_t B, int32_t T, int32_t H, int32_t DK,
+                         float p_drop, uint32_t seed0, uint32_t seed1, void* dq, void* dk, void* dv, int64_t ld_grad,
+                         float* dsum, void* stream) {
+  if (int rc = attn_train_check("attention backward", ld, ld_grad, B, T, H, DK, dtype, p_drop)) return rc;
+  if (!q || !k || !v || !ctx || !dctx || !stats || !dq || !dk || !dv || !dsum) return set_error("attention backward: NULL pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const AttnDropout dr = attn_dropout(p_drop, seed0, seed1);
+  constexpr int NWV = 4;
+  const dim3 grid((T + 32 * NWV - 1) / (32 * NWV), H, B);
+  const float scale = 1.0f / sqrtf((float)DK);
+#define ATTN_BWD(DKV, TY)                                                                                           \
+  do {                                                                                                              \
+    hipLaunchKernelGGL((k_attention_bwd_dq<DKV, TY, NWV>), grid, dim3(64 * NWV), 0, st, (const TY*)q, (const TY*)k,  \
+                       (const TY*)v, (const TY*)ctx, (const TY*)dctx, stats, lengths, (TY*)dq, dsum, T, H, (int)ld,  \
+                       (int)ld_grad, scale, dr);                                                                    \
+    hipLaunchKernelGGL((k_attention_bwd_dkv<DKV, TY, NWV>), grid, dim3(64 * NWV), 0, st, (const TY*)q, (const TY*)k, \
+                       (const TY*)v, (const TY*)dctx, stats, (const float*)dsum, lengths, (TY*)dk, (TY*)dv, T, H,    \
+                       (int)ld, (int)ld_grad, scale, dr);                                                           \
+  } while (0)
+  {
+    ProfScope ps("k_attention_bwd", st);
+    if (dtype == LMUFFT_F32) {
+      if (DK == 32) ATTN_BWD(32, float);
+      else if (DK == 64) ATTN_BWD(64, float);
+      else ATTN_BWD(128, float);
+    } else {
+      if (DK == 32) ATTN_BWD(32, attn_bf16);
+      else if (DK == 64) ATTN_BWD(64, attn_bf16);
+      else ATTN_BWD(128, attn_bf16);
+    }
+  }
+#undef ATTN_BWD
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error("launch of k_attention_bwd failed: %s", hipGetErrorString(e));
   return 0;
 }
 

@@ -20,7 +20,7 @@ from typing import List, Optional, Tuple
 import torch
 from torch import nn
 
-from .attention import SUPPORTED_HEAD_WIDTHS, masked_attention, masked_attention_packed
+from .attention import SUPPORTED_HEAD_WIDTHS, masked_attention, masked_attention_packed, masked_attention_train
 from .layernorm import MAX_WIDTH as _LN_MAX_WIDTH, add_layer_norm
 from .linear import linear_bf16, supported as linear_supported
 from .ctc import CTCDecoder
@@ -164,6 +164,13 @@ class _MultiHeadAttention(nn.Module):
                 ctx = masked_attention(_linear(self.w_q, x), _linear(self.w_k, x), _linear(self.w_v, x),
                                        self.num_heads, lengths)
             return _linear_layer_norm(self.w_o, ctx, self.layer_norm, x, out_dtype)
+        if x.is_cuda and self.d_k in SUPPORTED_HEAD_WIDTHS:
+            # training: HIP forward with dropout and HIP backward behind an autograd function; the projections
+            # and the layer norm stay torch ops (autograd)
+            _took("hip", "attention")
+            q, k, v = self.w_q(x), self.w_k(x), self.w_v(x)
+            ctx = masked_attention_train(q, k, v, self.num_heads, lengths, self.dropout.p if self.training else 0.0)
+            return _layer_norm(self.layer_norm, self.w_o(ctx), x, out_dtype)
         _took("torch", "attention")
         split = lambda t: t.view(B, T, self.num_heads, self.d_k).transpose(1, 2)  # noqa: E731
         q, k, v = split(self.w_q(x)), split(self.w_k(x)), split(self.w_v(x))

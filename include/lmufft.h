@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMUFFT_ABI_VERSION 8
+#define LMUFFT_ABI_VERSION 9
 
 /* element types of the activations (x, h, gh, gx, m) */
 #define LMUFFT_F32 0
@@ -243,6 +243,30 @@ int lmufft_ctc_greedy(const void* enc, int dtype, const float* W, const float* b
                       const int32_t* lengths, int32_t B, int32_t T, int32_t Hd, int32_t V,
                       int32_t blank, float* log_probs, int32_t* tokens, int32_t* counts,
                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Attention core for training: forward with dropout on the attention weights and the backward.
+ * Replaces MultiHeadAttention.forward's score / mask / softmax / dropout / context part,
+ * src/models/lmu_encoder.py:72-90 (self.dropout at :45, :86), and what autograd derives from it.
+ *   lmufft_attention_fwd_train: as lmufft_attention_fwd_ld; additionally element (b, h, query, key) of
+ *   the weights is dropped with probability p_drop (kept weights scaled by 1/(1 - p_drop)), decided by a
+ *   counter-based hash of the element's index and (seed0, seed1) -- no mask is stored -- and
+ *   stats [B][H][T][2] f32 receives per query row the maximum score and 1 / sum exp(score - max).
+ *   lmufft_attention_bwd: dq, dk, dv ([B][T][H*DK] with row stride ld_grad, dtype as the inputs) from
+ *   q, k, v, the forward's ctx and stats, the upstream gradient dctx ([B][T][H*DK] dense) and the same
+ *   (p_drop, seed0, seed1); dsum [B][H][T] f32 is scratch (receives dctx . ctx per row).
+ *   Masked positions pass no gradient to q and k (masked_fill); rows past an utterance's end, which
+ *   attend uniformly to all T positions, still pass gradient to v, as in the reference.
+ * fp32 arithmetic for fp32 and bf16 tensors.  DK in {32, 64, 128}.
+ * ---------------------------------------------------------------------- */
+int lmufft_attention_fwd_train(const void* q, const void* k, const void* v, int dtype, int64_t ld,
+                               const int32_t* lengths, int32_t B, int32_t T, int32_t H, int32_t DK,
+                               float p_drop, uint32_t seed0, uint32_t seed1, void* ctx, float* stats,
+                               void* stream);
+int lmufft_attention_bwd(const void* q, const void* k, const void* v, const void* ctx, const void* dctx,
+                         const float* stats, int dtype, int64_t ld, const int32_t* lengths, int32_t B,
+                         int32_t T, int32_t H, int32_t DK, float p_drop, uint32_t seed0, uint32_t seed1,
+                         void* dq, void* dk, void* dv, int64_t ld_grad, float* dsum, void* stream);
 
 /* ------------------------------------------------------------------------
  * CTC target packing.  Replaces the label concatenation at the head of

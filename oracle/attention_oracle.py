@@ -26,3 +26,73 @@ def attention_core(q, k, v, lengths, num_heads):
     w = np.exp(scores)
     w /= w.sum(axis=-1, keepdims=True)
     return (w @ V).transpose(0, 2, 1, 3).reshape(B, T, C)
+
+
+# ---------------------------------------------------------------------------------------------
+# Training form: dropout on the attention weights (src/models/lmu_encoder.py:45, 86) and the backward
+# that autograd derives from src/models/lmu_encoder.py:72-90.  The dropout decision of element
+# (b, h, query, key) is the counter-based hash the HIP kernels evaluate (fmix32 = MurmurHash3's
+# 32-bit finaliser); torch's own dropout stream cannot be reproduced bit for bit by any other
+# implementation, so parity for p > 0 is: same semantics on the SAME mask (this function), and the
+# keep rate.  With p = 0 the functions below are pinned to torch autograd of the reference's
+# formula by tests/test_attention_oracle.py.
+# ---------------------------------------------------------------------------------------------
+def _fmix32(x):
+    x = x.astype(np.uint32)
+    x ^= x >> np.uint32(16)
+    x = (x * np.uint32(0x85EBCA6B)).astype(np.uint32)
+    x ^= x >> np.uint32(13)
+    x = (x * np.uint32(0xC2B2AE35)).astype(np.uint32)
+    x ^= x >> np.uint32(16)
+    return x
+
+
+def dropout_keep_mask(B, H, T, p_drop, seed0, seed1):
+    """keep[b, h, i, j] (bool) for dropout probability p_drop and the call's two 32-bit seeds."""
+    if p_drop <= 0:
+        return np.ones((B, H, T, T), dtype=bool)
+    thr = np.uint32(min(max(p_drop * 4294967296.0, 1.0), 4294967295.0))
+    idx = np.arange(B * H * T * T, dtype=np.uint64).reshape(B, H, T, T)
+    lo = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    hi = (idx >> np.uint64(32)).astype(np.uint32)
+    with np.errstate(over="ignore"):
+        x = _fmix32(_fmix32(lo ^ np.uint32(seed0)) ^ hi ^ np.uint32(seed1))
+    return x >= thr
+
+
+def attention_train(q, k, v, lengths, num_heads, keep=None, p_drop=0.0):
+    """Forward with the weights multiplied by keep / (1 - p_drop); returns (context, cache for the backward)."""
+    q, k, v = (np.asarray(a, dtype=np.float64) for a in (q, k, v))
+    B, T, C = q.shape
+    dk = C // num_heads
+    split = lambda a: a.reshape(B, T, num_heads, dk).transpose(0, 2, 1, 3)  # noqa: E731
+    Q, K, V = split(q), split(k), split(v)
+    scores = Q @ K.transpose(0, 1, 3, 2) / np.sqrt(dk)
+    inside = np.ones((B, 1, T, T), dtype=bool)
+    if lengths is not None:
+        valid = np.arange(T)[None, :] < np.asarray(lengths)[:, None]
+        inside = (valid[:, :, None] & valid[:, None, :])[:, None]
+        scores = np.where(inside, scores, -1e9)
+    scores = scores - scores.max(axis=-1, keepdims=True)
+    P = np.exp(scores)
+    P /= P.sum(axis=-1, keepdims=True)
+    scale = 1.0 / (1.0 - p_drop)
+    W = P if keep is None else P * keep * scale
+    ctx = (W @ V).transpose(0, 2, 1, 3).reshape(B, T, C)
+    return ctx, (Q, K, V, P, W, inside, keep, scale, dk)
+
+
+def attention_backward(dctx, cache):
+    """(dq, dk, dv) [B, T, C] from the upstream gradient of the context."""
+    Q, K, V, P, W, inside, keep, scale, dk = cache
+    B, H, T, _ = Q.shape
+    dO = np.asarray(dctx, dtype=np.float64).reshape(B, T, H, dk).transpose(0, 2, 1, 3)
+    dV = W.transpose(0, 1, 3, 2) @ dO
+    dW = dO @ V.transpose(0, 1, 3, 2)
+    dP = dW if keep is None else dW * keep * scale
+    dS = P * (dP - (P * dP).sum(axis=-1, keepdims=True))
+    dS = np.where(inside, dS, 0.0)  # masked_fill passes no gradient to the overwritten scores
+    dQ = dS @ K / np.sqrt(dk)
+    dK = dS.transpose(0, 1, 3, 2) @ Q / np.sqrt(dk)
+    merge = lambda a: a.transpose(0, 2, 1, 3).reshape(B, T, H * dk)  # noqa: E731
+    return merge(dQ), merge(dK), merge(dV)
