@@ -510,13 +510,17 @@ __global__ __launch_bounds__(64 * NW) void k_attention_bwd_dkv(const TIO* __rest
 typedef __bf16 attn_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 attn_bf16x4 __attribute__((ext_vector_type(4)));
 
-template <int DK, int NW>
-__global__ __launch_bounds__(64 * NW, DK <= 64 ? 4 : 1) void k_attention_fwd_bf16(const attn_bf16* __restrict__ q,
+// TRAIN: dropout on the weights and saved row statistics as in k_attention_fwd, the maximum in the base-2
+// domain this kernel works in (stats[..][0] = max of score * log2 e).
+template <int DK, int NW, bool TRAIN = false>
+__global__ __launch_bounds__(64 * NW, DK <= 64 ? (TRAIN ? 3 : 4) : 1) void k_attention_fwd_bf16(const attn_bf16* __restrict__ q,
                                                                      const attn_bf16* __restrict__ k,
                                                                      const attn_bf16* __restrict__ v,
                                                                      const int* __restrict__ lengths,
                                                                      attn_bf16* __restrict__ ctx, int T, int H,
-                                                                     int ld, float scale) {
+                                                                     int ld, float scale,
+                                                                     AttnDropout dr = AttnDropout{0, 0, 0, 1.f},
+                                                                     float* __restrict__ stats = nullptr) {
   static_assert(DK % 32 == 0 && DK <= 128, "head width: 32, 64, 96 or 128");
   constexpr int KP = DK + 8;          // K tile [key][d], 16-byte padded rows: conflict-free b128 fragments
   constexpr int NKT = 1;              // 32-key score tiles per round (2 was measured slower: 0.31 against 0.26 ms at
@@ -629,12 +633,17 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 4 : 1) void k_attention_fwd_bf1
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float psum = 0.f;
     attn_bf16x8 pf[NKT][2];
+    [[maybe_unused]] const unsigned long long row0 = (((unsigned long long)b * H + h) * T + qi) * T;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float pv = __builtin_amdgcn_exp2f(st[kt][i] - m_new);
+        float pv = __builtin_amdgcn_exp2f(st[kt][i] - m_new);
         psum += pv;
+        if (TRAIN && dr.threshold) {  // the normaliser keeps every weight; the context only the surviving ones
+          const int j = j0 + 32 * kt + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          pv = attn_keep(dr, row0 + j) ? pv * dr.inv_keep : 0.f;
+        }
         pf[kt][i >> 3][i & 7] = (attn_bf16)pv;
       }
     psum += __shfl_xor(psum, 32);
@@ -669,6 +678,11 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 4 : 1) void k_attention_fwd_bf1
   }
 
   const float inv = 1.0f / l_run;
+  if (TRAIN && hh == 0 && qi < T) {
+    float* sp = stats + 2 * ((((long)b * H + h) * T) + qi);
+    sp[0] = m_run;
+    sp[1] = inv;
+  }
   float* ws = Os + wave * 8 * OP;  // wave-private strip of 8 queries
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
@@ -686,6 +700,304 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 4 : 1) void k_attention_fwd_bf1
       if (qq < T) ctx[base + (long)qq * C + d] = (attn_bf16)ws[ql * OP + d];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+// ---------------------------------------------------------------------------
+// bf16 backward: the two sweeps of k_attention_bwd_dq / k_attention_bwd_dkv on v_mfma_f32_32x32x16_bf16
+// (fp32 scores, statistics and accumulation; W and dS rounded to bf16 for the second contractions, as the
+// forward rounds its probabilities).  A tile that serves both as the A operand of a score-type product
+// (16-byte fragments along d) and, transposed, of an accumulation-type product (ds_read_b64_tr_b16) is
+// kept in LDS in both pitches.
+// ---------------------------------------------------------------------------
+template <int DK>
+__device__ __forceinline__ attn_bf16x8 attn_tr_frag(const attn_bf16* tile, int VP, int key0, int col) {
+  typedef attn_bf16x4 __attribute__((address_space(3))) * lds4;
+  const attn_bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)&tile[key0 * VP + col]);
+  const attn_bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)&tile[(key0 + 8) * VP + col]);
+  attn_bf16x8 f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f[j] = lo[j];
+    f[4 + j] = hi[j];
+  }
+  return f;
+}
+
+template <int DK, int NW>
+__global__ __launch_bounds__(64 * NW) void k_attention_bwd_dq_bf16(const attn_bf16* __restrict__ q, const attn_bf16* __restrict__ k,
+                                                                   const attn_bf16* __restrict__ v, const attn_bf16* __restrict__ ctx,
+                                                                   const attn_bf16* __restrict__ dctx, const float* __restrict__ stats,
+                                                                   const int* __restrict__ lengths, attn_bf16* __restrict__ dq,
+                                                                   float* __restrict__ dsum, int T, int H, int ld, int ldg,
+                                                                   float scale, AttnDropout dr) {
+  constexpr int KP = DK + 8, VP = DK <= 96 ? 96 : 160, DT = DK / 32, NS = DK / 16, OP = DK + 1;
+  __shared__ __attribute__((aligned(16))) attn_bf16 Ks[32 * KP];
+  __shared__ __attribute__((aligned(16))) attn_bf16 Vs[32 * KP];
+  __shared__ __attribute__((aligned(16))) attn_bf16 Kt[32 * VP];
+  __shared__ float Os[NW * 8 * OP];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int C = H * DK;
+  const int len = lengths ? min(max(lengths[b], 0), T) : T;
+  const long base = (long)b * T * C + (long)h * DK;
+  const long ibase = (long)b * T * ld + (long)h * DK;
+  const long gbase = (long)b * T * ldg + (long)h * DK;
+  const long bh = (long)b * H + h;
+  const int qi = blockIdx.x * (32 * NW) + wave * 32 + r;
+  const bool q_valid = qi < len;
+  const int qc = min(qi, T - 1);
+
+  attn_bf16x8 qf[NS], dof[NS];
+  float D = 0.f;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    qf[s] = *reinterpret_cast<const attn_bf16x8*>(q + ibase + (long)qc * ld + 16 * s + 8 * hh);
+    dof[s] = *reinterpret_cast<const attn_bf16x8*>(dctx + base + (long)qc * C + 16 * s + 8 * hh);
+    const attn_bf16x8 of = *reinterpret_cast<const attn_bf16x8*>(ctx + base + (long)qc * C + 16 * s + 8 * hh);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) D += (float)dof[s][e] * (float)of[e];
+  }
+  D += __shfl_xor(D, 32);
+  if (hh == 0 && qi < T) dsum[bh * T + qi] = D;
+  const float m2 = stats[2 * (bh * T + qc)], invl = stats[2 * (bh * T + qc) + 1];
+  const float scale2 = scale * 1.4426950408889634f;
+  constexpr float kMasked2 = -1e9f * 1.4426950408889634f;
+  const int tq = (lane & 15) >> 2, tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+
+  attn_f16v dqa[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dqa[t][i] = 0.f;
+
+  constexpr int CH = DK / 8;
+  constexpr int NV = (32 * CH + (64 * NW) - 1) / (64 * NW);
+  attn_bf16x8 kst[NV], vst[NV];
+  auto fetch = [&](int j0) {
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const int idx = tid + n * (64 * NW);
+      if (idx < 32 * CH) {
+        const int row = idx / CH, c = (idx % CH) * 8;
+        const int j = min(j0 + row, T - 1);
+        kst[n] = *reinterpret_cast<const attn_bf16x8*>(k + ibase + (long)j * ld + c);
+        vst[n] = *reinterpret_cast<const attn_bf16x8*>(v + ibase + (long)j * ld + c);
+      }
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const int idx = tid + n * (64 * NW);
+      if (idx < 32 * CH) {
+        const int row = idx / CH, c = (idx % CH) * 8;
+        *reinterpret_cast<attn_bf16x8*>(&Ks[row * KP + c]) = kst[n];
+        *reinterpret_cast<attn_bf16x8*>(&Vs[row * KP + c]) = vst[n];
+        *reinterpret_cast<attn_bf16x8*>(&Kt[row * VP + c]) = kst[n];
+      }
+    }
+  };
+  const unsigned long long row0 = ((unsigned long long)bh * T + qi) * T;
+
+  fetch(0);
+  for (int j0 = 0; j0 < T; j0 += 32) {
+    __syncthreads();
+    stage();
+    __syncthreads();
+    if (j0 + 32 < T) fetch(j0 + 32);
+
+    attn_f16v st, dp;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st[i] = 0.f, dp[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const attn_bf16x8 kf = *reinterpret_cast<const attn_bf16x8*>(&Ks[r * KP + 16 * s + 8 * hh]);
+      const attn_bf16x8 vf = *reinterpret_cast<const attn_bf16x8*>(&Vs[r * KP + 16 * s + 8 * hh]);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[s], dp, 0, 0, 0);
+    }
+    attn_bf16x8 dsf[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int j = j0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+      const bool inside = q_valid && j < len;
+      const float pv = j < T ? __builtin_amdgcn_exp2f((inside ? st[i] * scale2 : kMasked2) - m2) * invl : 0.f;
+      float dw = dp[i];
+      if (dr.threshold) dw = attn_keep(dr, row0 + j) ? dw * dr.inv_keep : 0.f;
+      dsf[i >> 3][i & 7] = (attn_bf16)(inside ? pv * (dw - D) * scale : 0.f);
+    }
+    // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+        dqa[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(attn_tr_frag<DK>(Kt, VP, 16 * half + 4 * hh + tq, 32 * t + tcol),
+                                                         dsf[half], dqa[t], 0, 0, 0);
+  }
+
+  float* ws = Os + wave * 8 * OP;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int d = 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        if ((r >> 3) == pass) ws[(r & 7) * OP + d] = dqa[t][i];
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int idx = lane; idx < 8 * DK; idx += 64) {
+      const int ql = idx / DK, d = idx % DK;
+      const int qq = blockIdx.x * (32 * NW) + wave * 32 + pass * 8 + ql;
+      if (qq < T) dq[gbase + (long)qq * ldg + d] = (attn_bf16)ws[ql * OP + d];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+template <int DK, int NW>
+__global__ __launch_bounds__(64 * NW) void k_attention_bwd_dkv_bf16(const attn_bf16* __restrict__ q, const attn_bf16* __restrict__ k,
+                                                                    const attn_bf16* __restrict__ v, const attn_bf16* __restrict__ dctx,
+                                                                    const float* __restrict__ stats, const float* __restrict__ dsum,
+                                                                    const int* __restrict__ lengths, attn_bf16* __restrict__ dk,
+                                                                    attn_bf16* __restrict__ dv, int T, int H, int ld, int ldg,
+                                                                    float scale, AttnDropout dr) {
+  constexpr int KP = DK + 8, VP = DK <= 96 ? 96 : 160, DT = DK / 32, NS = DK / 16, OP = DK + 1;
+  __shared__ __attribute__((aligned(16))) attn_bf16 Qs[32 * KP];
+  __shared__ __attribute__((aligned(16))) attn_bf16 Gs[32 * KP];
+  __shared__ __attribute__((aligned(16))) attn_bf16 Qt[32 * VP];
+  __shared__ __attribute__((aligned(16))) attn_bf16 Gt[32 * VP];
+  __shared__ float Ms[32], Ls[32], Ds[32];
+  __shared__ float Os[NW * 8 * OP];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int C = H * DK;
+  const int len = lengths ? min(max(lengths[b], 0), T) : T;
+  const long base = (long)b * T * C + (long)h * DK;
+  const long ibase = (long)b * T * ld + (long)h * DK;
+  const long gbase = (long)b * T * ldg + (long)h * DK;
+  const long bh = (long)b * H + h;
+  const int kj = blockIdx.x * (32 * NW) + wave * 32 + r;
+  const bool k_valid = kj < len;
+  const int kc = min(kj, T - 1);
+
+  attn_bf16x8 kf[NS], vf[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    kf[s] = *reinterpret_cast<const attn_bf16x8*>(k + ibase + (long)kc * ld + 16 * s + 8 * hh);
+    vf[s] = *reinterpret_cast<const attn_bf16x8*>(v + ibase + (long)kc * ld + 16 * s + 8 * hh);
+  }
+  const float scale2 = scale * 1.4426950408889634f;
+  constexpr float kMasked2 = -1e9f * 1.4426950408889634f;
+  const int tq = (lane & 15) >> 2, tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  attn_f16v dka[DT], dva[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dka[t][i] = 0.f, dva[t][i] = 0.f;
+
+  constexpr int CH = DK / 8;
+  constexpr int NV = (32 * CH + (64 * NW) - 1) / (64 * NW);
+  attn_bf16x8 qst[NV], gst[NV];
+  float mst = 0.f, lst = 0.f, dst = 0.f;
+  auto fetch = [&](int i0) {
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const int idx = tid + n * (64 * NW);
+      if (idx < 32 * CH) {
+        const int row = idx / CH, c = (idx % CH) * 8;
+        const int qq = min(i0 + row, T - 1);
+        qst[n] = *reinterpret_cast<const attn_bf16x8*>(q + ibase + (long)qq * ld + c);
+        gst[n] = *reinterpret_cast<const attn_bf16x8*>(dctx + base + (long)qq * C + c);
+      }
+    }
+    if (tid < 32) {  // rows past T get weight 0 through 1/l = 0
+      const int qq = i0 + tid;
+      mst = qq < T ? stats[2 * (bh * T + qq)] : 0.f;
+      lst = qq < T ? stats[2 * (bh * T + qq) + 1] : 0.f;
+      dst = qq < T ? dsum[bh * T + qq] : 0.f;
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const int idx = tid + n * (64 * NW);
+      if (idx < 32 * CH) {
+        const int row = idx / CH, c = (idx % CH) * 8;
+        *reinterpret_cast<attn_bf16x8*>(&Qs[row * KP + c]) = qst[n];
+        *reinterpret_cast<attn_bf16x8*>(&Gs[row * KP + c]) = gst[n];
+        *reinterpret_cast<attn_bf16x8*>(&Qt[row * VP + c]) = qst[n];
+        *reinterpret_cast<attn_bf16x8*>(&Gt[row * VP + c]) = gst[n];
+      }
+    }
+    if (tid < 32) {
+      Ms[tid] = mst;
+      Ls[tid] = lst;
+      Ds[tid] = dst;
+    }
+  };
+
+  fetch(0);
+  for (int i0 = 0; i0 < T; i0 += 32) {
+    __syncthreads();
+    stage();
+    __syncthreads();
+    if (i0 + 32 < T) fetch(i0 + 32);
+
+    attn_f16v st, dp;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st[i] = 0.f, dp[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const attn_bf16x8 qa = *reinterpret_cast<const attn_bf16x8*>(&Qs[r * KP + 16 * s + 8 * hh]);
+      const attn_bf16x8 ga = *reinterpret_cast<const attn_bf16x8*>(&Gs[r * KP + 16 * s + 8 * hh]);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[s], st, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, vf[s], dp, 0, 0, 0);
+    }
+    attn_bf16x8 wf[2], dsf[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * hh, qq = i0 + row;
+      const bool inside = qq < len && k_valid;
+      const float pv = __builtin_amdgcn_exp2f((inside ? st[i] * scale2 : kMasked2) - Ms[row]) * Ls[row];
+      const bool keep = dr.threshold ? attn_keep(dr, ((unsigned long long)bh * T + qq) * T + kj) : true;
+      const float dw = keep ? dp[i] * dr.inv_keep : 0.f;
+      wf[i >> 3][i & 7] = (attn_bf16)(keep ? pv * dr.inv_keep : 0.f);
+      dsf[i >> 3][i & 7] = (attn_bf16)(inside ? pv * (dw - Ds[row]) * scale : 0.f);
+    }
+    // dV^T[d][key] += dO^T[d][query] W[query][key];  dK^T[d][key] += Q^T[d][query] dS[query][key]
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const int row0 = 16 * half + 4 * hh + tq, col = 32 * t + tcol;
+        dva[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(attn_tr_frag<DK>(Gt, VP, row0, col), wf[half], dva[t], 0, 0, 0);
+        dka[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(attn_tr_frag<DK>(Qt, VP, row0, col), dsf[half], dka[t], 0, 0, 0);
+      }
+  }
+
+  float* ws = Os + wave * 8 * OP;
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    attn_bf16* out = which ? dv : dk;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int d = 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          if ((r >> 3) == pass) ws[(r & 7) * OP + d] = which ? dva[t][i] : dka[t][i];
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int idx = lane; idx < 8 * DK; idx += 64) {
+        const int kl = idx / DK, d = idx % DK;
+        const int kk = blockIdx.x * (32 * NW) + wave * 32 + pass * 8 + kl;
+        if (kk < T) out[gbase + (long)kk * ldg + d] = (attn_bf16)ws[kl * OP + d];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
   }
 }
 
@@ -767,6 +1079,12 @@ static AttnDropout attn_dropout(float p_drop, uint32_t seed0, uint32_t seed1) {
   dr.inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
   return dr;
 }
+// the bf16 MFMA kernels load 16 bytes at a time: row strides in multiples of 8 elements, 16-byte aligned tensors
+static bool attn_bf16_fast(int64_t ld, int64_t ld2, const void* a, const void* b, const void* c, const void* d,
+                           const void* e, const void* f) {
+  const uintptr_t bits = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d | (uintptr_t)e | (uintptr_t)f;
+  return ld % 8 == 0 && ld2 % 8 == 0 && (bits & 15) == 0;
+}
 static int attn_train_check(const char* what, int64_t ld, int64_t ld_grad, int32_t B, int32_t T, int32_t H, int32_t DK,
                             int dtype, float p_drop) {
   if (B <= 0 || T <= 0 || H <= 0) return set_error("%s: bad shape (B=%d T=%d H=%d)", what, B, T, H);
@@ -798,6 +1116,14 @@ int lmufft_attention_fwd_train(const void* q, const void* k, const void* v, int 
       if (DK == 32) ATTN_TRAIN_FWD(32, float);
       else if (DK == 64) ATTN_TRAIN_FWD(64, float);
       else ATTN_TRAIN_FWD(128, float);
+    } else if (attn_bf16_fast(ld, ld, q, k, v, ctx, nullptr, nullptr)) {
+#define ATTN_TRAIN_FWD_B(DKV)                                                                                      \
+  hipLaunchKernelGGL((k_attention_fwd_bf16<DKV, NWV, true>), grid, dim3(64 * NWV), 0, st, (const attn_bf16*)q,     \
+                     (const attn_bf16*)k, (const attn_bf16*)v, lengths, (attn_bf16*)ctx, T, H, (int)ld, scale, dr, stats)
+      if (DK == 32) ATTN_TRAIN_FWD_B(32);
+      else if (DK == 64) ATTN_TRAIN_FWD_B(64);
+      else ATTN_TRAIN_FWD_B(128);
+#undef ATTN_TRAIN_FWD_B
     } else {
       if (DK == 32) ATTN_TRAIN_FWD(32, attn_bf16);
       else if (DK == 64) ATTN_TRAIN_FWD(64, attn_bf16);
@@ -836,6 +1162,20 @@ int lmufft_attention_bwd(const void* q, const void* k, const void* v, const void
       if (DK == 32) ATTN_BWD(32, float);
       else if (DK == 64) ATTN_BWD(64, float);
       else ATTN_BWD(128, float);
+    } else if (attn_bf16_fast(ld, ld_grad, q, k, v, ctx, dctx, dq) && (((uintptr_t)dk | (uintptr_t)dv) & 15) == 0) {
+#define ATTN_BWD_B(DKV)                                                                                              \
+  do {                                                                                                               \
+    typedef const attn_bf16* cb;                                                                                     \
+    hipLaunchKernelGGL((k_attention_bwd_dq_bf16<DKV, NWV>), grid, dim3(64 * NWV), 0, st, (cb)q, (cb)k, (cb)v, (cb)ctx, \
+                       (cb)dctx, stats, lengths, (attn_bf16*)dq, dsum, T, H, (int)ld, (int)ld_grad, scale, dr);      \
+    hipLaunchKernelGGL((k_attention_bwd_dkv_bf16<DKV, NWV>), grid, dim3(64 * NWV), 0, st, (cb)q, (cb)k, (cb)v,        \
+                       (cb)dctx, stats, (const float*)dsum, lengths, (attn_bf16*)dk, (attn_bf16*)dv, T, H, (int)ld,   \
+                       (int)ld_grad, scale, dr);                                                                     \
+  } while (0)
+      if (DK == 32) ATTN_BWD_B(32);
+      else if (DK == 64) ATTN_BWD_B(64);
+      else ATTN_BWD_B(128);
+#undef ATTN_BWD_B
     } else {
       if (DK == 32) ATTN_BWD(32, attn_bf16);
       else if (DK == 64) ATTN_BWD(64, attn_bf16);
