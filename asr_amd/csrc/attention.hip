@@ -725,7 +725,7 @@ __device__ __forceinline__ attn_bf16x8 attn_tr_frag(const attn_bf16* tile, int V
 }
 
 template <int DK, int NW>
-__global__ __launch_bounds__(64 * NW) void k_attention_bwd_dq_bf16(const attn_bf16* __restrict__ q, const attn_bf16* __restrict__ k,
+__global__ __launch_bounds__(64 * NW, DK <= 64 ? 2 : 1) void k_attention_bwd_dq_bf16(const attn_bf16* __restrict__ q, const attn_bf16* __restrict__ k,
                                                                    const attn_bf16* __restrict__ v, const attn_bf16* __restrict__ ctx,
                                                                    const attn_bf16* __restrict__ dctx, const float* __restrict__ stats,
                                                                    const int* __restrict__ lengths, attn_bf16* __restrict__ dq,
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(64 * NW) void k_attention_bwd_dq_bf16(const attn_bf
 }
 
 template <int DK, int NW>
-__global__ __launch_bounds__(64 * NW) void k_attention_bwd_dkv_bf16(const attn_bf16* __restrict__ q, const attn_bf16* __restrict__ k,
+__global__ __launch_bounds__(64 * NW, DK <= 64 ? 2 : 1) void k_attention_bwd_dkv_bf16(const attn_bf16* __restrict__ q, const attn_bf16* __restrict__ k,
                                                                     const attn_bf16* __restrict__ v, const attn_bf16* __restrict__ dctx,
                                                                     const float* __restrict__ stats, const float* __restrict__ dsum,
                                                                     const int* __restrict__ lengths, attn_bf16* __restrict__ dk,
