@@ -19,7 +19,7 @@ CONV_AUTO = 0
 CONV_TOEPLITZ = 1
 CONV_FFT = 2
 NOALLOC_SCRATCH_BYTES = 8 << 20
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class Shape(ctypes.Structure):
@@ -118,6 +118,10 @@ def _load():
     lib.lmufft_attention_bwd.restype = ci
     lib.lmufft_attention_bwd.argtypes = [vp, vp, vp, vp, vp, vp, ci, i64, vp, i32, i32, i32, i32, f32, u32, u32,
                                          vp, vp, vp, i64, vp, vp]
+    lib.lmufft_linear_wgrad_workspace_bytes.restype = sz
+    lib.lmufft_linear_wgrad_workspace_bytes.argtypes = [i64, i32, i32]
+    lib.lmufft_linear_wgrad_bf16.restype = ci
+    lib.lmufft_linear_wgrad_bf16.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp, sz, vp]
     lib.lmufft_ctc_pack_targets.restype = ci
     lib.lmufft_ctc_pack_targets.argtypes = [vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, vp, vp, vp]
     lib.lmufft_grad_norm_workspace_bytes.restype = sz
@@ -169,6 +173,8 @@ EXPORTS = (
     "lmufft_add_layernorm",
     "lmufft_linear_bf16",
     "lmufft_linear_ln_bf16",
+    "lmufft_linear_wgrad_workspace_bytes",
+    "lmufft_linear_wgrad_bf16",
     "lmufft_ctc_workspace_bytes",
     "lmufft_ctc_greedy",
     "lmufft_ctc_pack_targets",

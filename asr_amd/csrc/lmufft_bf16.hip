@@ -936,7 +936,7 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
         rb[set][i] = lb.fetch((idx % (TL::BN / 8)) * 8, k0 + kr);
       }
     }
-    if (tid < TL::BK) ga_reg[set] = (k0 + tid < kend) ? ga[k0 + tid] : 0.f;
+    if (tid < TL::BK) ga_reg[set] = (ga && k0 + tid < kend) ? ga[k0 + tid] : 0.f;
   };
   auto store = [&](auto set_c, int st) __attribute__((always_inline)) {
     constexpr int set = decltype(set_c)::value;
@@ -1554,6 +1554,65 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
     if (int rc = launch_reduce_slabs(wslab, p.S, wgrad_outputs(*s, gW_h, gb_h, gw_u, gb_u), st)) return rc;
   }
   return 0;
+}
+
+// Weight and bias gradient of a Linear layer, dW[out][in] = sum_rows dy[row][out] x[row][in], db[out] = sum_rows
+// dy[row][out]: the layer's weight-gradient kernel with an empty memory block (M = 0) and no encoder gradient.
+struct LinWgradPlan {
+  int S, rps, tiles_j, tiles_n;
+  long slab_floats;
+  size_t off_scratch, total;
+};
+static LinWgradPlan plan_linear_wgrad(long rows, int in, int out) {
+  using TL = WgradTileB;
+  LinWgradPlan p;
+  p.tiles_j = cdivb(in, TL::BN);
+  p.tiles_n = cdivb(out, TL::BM);
+  const int tiles = p.tiles_j * p.tiles_n;
+  const int S = 8 * std::max(1, 32 / tiles);
+  int rps = cdivb(rows, S);
+  rps = cdivb(rps, TL::BK) * TL::BK;
+  p.S = cdivb(rows, rps);
+  p.rps = rps;
+  const SlabOutputs o{{nullptr, nullptr, nullptr, nullptr}, {(long)out * in, out, in, 1}, {1, p.tiles_j * TL::WGN, p.tiles_n * TL::WGM, 1}};
+  p.slab_floats = slab_stride(o);
+  p.off_scratch = align256b(sizeof(float) * (size_t)p.S * (size_t)p.slab_floats);
+  p.total = p.off_scratch + align256b(sizeof(float) * ((size_t)in + (size_t)out + 8));
+  return p;
+}
+
+size_t lmufft_linear_wgrad_workspace_bytes(int64_t rows, int32_t in, int32_t out) {
+  if (rows <= 0 || in <= 0 || out <= 0) return 0;
+  return plan_linear_wgrad(rows, in, out).total;
+}
+
+int lmufft_linear_wgrad_bf16(const void* x, const void* dy, int64_t rows, int32_t in, int32_t out, float* dW, float* db,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+  using TL = WgradTileB;
+  if (rows <= 0 || rows > 0x7fffffff || in <= 0 || out <= 0) return set_error("linear wgrad: bad shape (rows=%lld in=%d out=%d)", (long long)rows, in, out);
+  if (in % 8 || out % 8) return set_error("linear wgrad: in and out must be multiples of 8 (got %d, %d)", in, out);
+  if (!x || !dy || !dW || !workspace) return set_error("linear wgrad: NULL pointer");
+  if (!al16(x) || !al16(dy) || !al16(workspace)) return set_error("linear wgrad: x, dy and the workspace must be 16-byte aligned");
+  const LinWgradPlan p = plan_linear_wgrad(rows, in, out);
+  if (workspace_bytes < p.total) return set_error("linear wgrad: workspace of %zu bytes needed, %zu given", p.total, workspace_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  float* wslab = (float*)workspace;
+  float* scratch = (float*)((char*)workspace + p.off_scratch);  // gw_u (in) | gb_u (1) | db when the layer has no bias
+  const dim3 grid(xcd_grid(p.S, p.tiles_j * p.tiles_n));
+  const size_t lds = std::max(2 * (sizeof(bf16_t) * (size_t)TL::BK * ((TL::BM + 32) + (TL::BN + 32)) + sizeof(float) * TL::BK),
+                              sizeof(float) * (size_t)TL::BM * (TL::BN + 4));
+  if (hipFuncSetAttribute((const void*)k_wgrad_bf16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return set_error("cannot reserve %zu bytes of LDS for k_wgrad_bf16", lds);
+  {
+    PROFB("k_linear_wgrad_bf16");
+    hipLaunchKernelGGL(k_wgrad_bf16<true>, grid, dim3(kThreads), lds, st, (const bf16_t*)dy, (const bf16_t*)nullptr,
+                       (const bf16_t*)x, (const float*)nullptr, wslab, (int)rows, p.rps, 0, in, out);
+  }
+  LAUNCH_CHECKB("k_linear_wgrad_bf16");
+  const SlabOutputs o{{dW, db ? db : scratch + in + 4, scratch, scratch + in},
+                      {(long)out * in, out, in, 1},
+                      {1, p.tiles_j * TL::WGN, p.tiles_n * TL::WGM, 1}};
+  return launch_reduce_slabs(wslab, p.S, o, st);
 }
 
 int lmufft_conv_forward_bf16(const lmufft_shape* s, const float* u, const void* hprep, void* m, void* stream) {

@@ -22,7 +22,7 @@ from torch import nn
 
 from .attention import SUPPORTED_HEAD_WIDTHS, masked_attention, masked_attention_packed, masked_attention_train
 from .layernorm import MAX_WIDTH as _LN_MAX_WIDTH, add_layer_norm
-from .linear import linear_bf16, supported as linear_supported
+from .linear import linear_bf16, linear_train, supported as linear_supported, train_supported as linear_train_supported
 from .ctc import CTCDecoder
 from .lmu import LMUFFT
 
@@ -87,6 +87,11 @@ def _linear(layer: nn.Linear, x: torch.Tensor) -> torch.Tensor:
             return linear_bf16(xb, w16, b32)
         _took("torch", "linear")
         return torch.nn.functional.linear(xb, w16, b16)
+    if (torch.is_grad_enabled() and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+            and linear_train_supported(x, layer.weight)):
+        # training under bf16 autocast: forward, input gradient and weight gradient on this package's kernels
+        _took("hip", "linear")
+        return linear_train(x, layer.weight, layer.bias)
     _took("torch", "linear")
     return layer(x)
 
@@ -168,9 +173,9 @@ class _MultiHeadAttention(nn.Module):
             # training: HIP forward with dropout and HIP backward behind an autograd function; the projections
             # and the layer norm stay torch ops (autograd)
             _took("hip", "attention")
-            q, k, v = self.w_q(x), self.w_k(x), self.w_v(x)
+            q, k, v = _linear(self.w_q, x), _linear(self.w_k, x), _linear(self.w_v, x)
             ctx = masked_attention_train(q, k, v, self.num_heads, lengths, self.dropout.p if self.training else 0.0)
-            return _layer_norm(self.layer_norm, self.w_o(ctx), x, out_dtype)
+            return _layer_norm(self.layer_norm, _linear(self.w_o, ctx), x, out_dtype)
         _took("torch", "attention")
         split = lambda t: t.view(B, T, self.num_heads, self.d_k).transpose(1, 2)  # noqa: E731
         q, k, v = split(self.w_q(x)), split(self.w_k(x)), split(self.w_v(x))

@@ -99,3 +99,70 @@ def linear_add_layer_norm_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Opti
             _DTYPES[out_dtype], ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
     _lib.check(rc, "lmufft_linear_ln_bf16")
     return (y, proj) if return_projection else y
+
+
+def linear_weight_grad_bf16(x: torch.Tensor, dy: torch.Tensor, want_bias: bool = True):
+    """(dW [N, K] fp32, db [N] fp32 or None) of y = x W^T + b from x [..., K] and dy [..., N], both bf16:
+    dW = sum over rows of dy^T x, db = sum over rows of dy (HIP kernel k_wgrad_bf16, fp32 accumulation in a
+    fixed order).  K and N must be multiples of 8."""
+    for name, t in (("x", x), ("dy", dy)):
+        if not t.is_cuda:
+            raise RuntimeError(f"linear_weight_grad_bf16: `{name}` lives on {t.device}; the kernel runs only on a GPU "
+                               "(there is no CPU fallback)")
+        if t.dtype != torch.bfloat16:
+            raise RuntimeError("linear_weight_grad_bf16: x and dy must be bfloat16")
+    K, N = x.shape[-1], dy.shape[-1]
+    rows = x.numel() // K
+    if dy.numel() // N != rows or K % 8 or N % 8:
+        raise RuntimeError(f"linear_weight_grad_bf16: x {tuple(x.shape)} and dy {tuple(dy.shape)} must share their rows "
+                           "and have widths that are multiples of 8")
+    x, dy = x.detach().contiguous(), dy.detach().contiguous()
+    dW = torch.empty((N, K), dtype=torch.float32, device=x.device)
+    db = torch.empty((N,), dtype=torch.float32, device=x.device) if want_bias else None
+    ws = torch.empty(_lib.lib.lmufft_linear_wgrad_workspace_bytes(rows, K, N), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib.lmufft_linear_wgrad_bf16(_ptr(x), _ptr(dy), rows, K, N, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(),
+                                               ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    _lib.check(rc, "lmufft_linear_wgrad_bf16")
+    return dW, db
+
+
+class _LinearTrain(torch.autograd.Function):
+    """nn.Linear under bf16 autocast with this package's kernels in both directions: y = bf16(x) bf16(W)^T + b
+    (fp32 accumulation, one rounding); dx = dy bf16(W) in bf16; dW, db in fp32 straight from bf16 x and dy."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        xb = x.to(torch.bfloat16)
+        w16 = weight.detach().to(torch.bfloat16)
+        b32 = None if bias is None else bias.detach().to(torch.bfloat16).float()
+        ctx.save_for_backward(xb, w16)
+        ctx.has_bias = bias is not None
+        ctx.x_dtype = x.dtype
+        return linear_bf16(xb, w16, b32)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, w16 = ctx.saved_tensors
+        dyb = dy.to(torch.bfloat16).contiguous()
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = linear_bf16(dyb, w16.t().contiguous()).to(ctx.x_dtype)   # dy W: the same kernel on W^T
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dW, db = linear_weight_grad_bf16(xb, dyb, ctx.has_bias)
+        return dx, dW, db
+
+
+def train_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """True when linear_train can take this call (GPU, fp32 master weight, widths multiples of 8)."""
+    return (x.is_cuda and weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 2
+            and x.dtype in (torch.float32, torch.bfloat16) and x.shape[-1] == weight.shape[1]
+            and weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0)
+
+
+def linear_train(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """torch.nn.functional.linear(x, weight, bias) as bf16 autocast computes it, with autograd, on HIP kernels."""
+    if not train_supported(x, weight):
+        raise RuntimeError("linear_train: needs GPU tensors, a float32 weight [N, K] with N and K multiples of 8 and a "
+                           "float32 or bfloat16 input [..., K]")
+    return _LinearTrain.apply(x, weight, bias)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMUFFT_ABI_VERSION 9
+#define LMUFFT_ABI_VERSION 10
 
 /* element types of the activations (x, h, gh, gx, m) */
 #define LMUFFT_F32 0
@@ -267,6 +267,17 @@ int lmufft_attention_bwd(const void* q, const void* k, const void* v, const void
                          const float* stats, int dtype, int64_t ld, const int32_t* lengths, int32_t B,
                          int32_t T, int32_t H, int32_t DK, float p_drop, uint32_t seed0, uint32_t seed1,
                          void* dq, void* dk, void* dv, int64_t ld_grad, float* dsum, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Weight and bias gradient of a Linear layer under bf16 autocast (training).  Replaces what autograd runs
+ * for the reference's nn.Linear layers (src/models/lmu_encoder.py:40-43, 184, 229):
+ *   dW[out][in] = sum_rows dy[row][out] x[row][in],  db[out] = sum_rows dy[row][out]   (db may be NULL)
+ * with x [rows][in] and dy [rows][out] bf16 (16-byte aligned, in and out multiples of 8), fp32 results,
+ * fp32 accumulation in a fixed order.  It is the layer's own weight-gradient kernel with an empty memory block.
+ * ---------------------------------------------------------------------- */
+size_t lmufft_linear_wgrad_workspace_bytes(int64_t rows, int32_t in, int32_t out);
+int lmufft_linear_wgrad_bf16(const void* x, const void* dy, int64_t rows, int32_t in, int32_t out,
+                             float* dW, float* db, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * CTC target packing.  Replaces the label concatenation at the head of

@@ -31,3 +31,14 @@ def linear_bf16(x, weight, bias=None):
 
 def linear_add_layer_norm(x, weight, bias, residual, ln_weight, ln_bias, eps=1e-5):
     return add_layer_norm(linear_bf16(x, weight, bias), residual, ln_weight, ln_bias, eps)
+
+
+def linear_backward_bf16(x, weight, dy):
+    """Gradients of y = x W^T + b as bf16 autocast training computes them here: operands rounded to bf16, exact
+    accumulation; dx rounded to bf16 (it is an activation gradient), dW and db kept in fp64 (the kernels return
+    fp32).  What autograd derives for the reference's nn.Linear layers (src/models/lmu_encoder.py:40-43, 184, 229)."""
+    xb = round_bf16(x).astype(np.float64).reshape(-1, np.shape(x)[-1])
+    wb = round_bf16(weight).astype(np.float64)
+    gb = round_bf16(dy).astype(np.float64).reshape(-1, np.shape(dy)[-1])
+    dx = round_bf16((gb @ wb).astype(np.float32)).reshape(np.shape(x))
+    return dx, gb.T @ xb, gb.sum(axis=0)

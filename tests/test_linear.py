@@ -167,3 +167,51 @@ def test_errors():
     ones = torch.ones(392, device=dev)
     with pytest.raises(RuntimeError, match="exceeds"):
         linear_add_layer_norm_bf16(x, Wide, None, None, ones, ones)
+
+
+def test_oracle_backward_matches_torch_autograd():
+    """The backward restatement against torch autograd on the CPU (fp64 on the bf16-rounded operands)."""
+    rng = np.random.default_rng(4)
+    x, w, dy = rng.standard_normal((37, 24)), rng.standard_normal((16, 24)), rng.standard_normal((37, 16))
+    dx, dW, db = lo.linear_backward_bf16(x, w, dy)
+    tx = torch.tensor(lo.round_bf16(x), dtype=torch.float64, requires_grad=True)
+    tw = torch.tensor(lo.round_bf16(w), dtype=torch.float64, requires_grad=True)
+    tb = torch.zeros(16, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.linear(tx, tw, tb).backward(torch.tensor(lo.round_bf16(dy), dtype=torch.float64))
+    np.testing.assert_allclose(dW, tw.grad.numpy(), rtol=1e-12)
+    np.testing.assert_allclose(db, tb.grad.numpy(), rtol=1e-12)
+    assert np.abs(dx - tx.grad.numpy()).max() <= 2.0 ** -8 * np.abs(tx.grad.numpy()).max()  # one bf16 rounding
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,K,N,with_bias", [(64, 8, 8, True), (25600, 384, 384, True), (1000, 80, 384, False),
+                                                (777, 384, 1152, True), (130, 200, 40, True)])
+def test_training_linear_matches_oracle(rows, K, N, with_bias):
+    """linear_train (forward, input gradient, weight and bias gradient through the HIP kernels) against the oracle:
+    y and dx at the bf16 bar of the forward tests, dW and db (fp32 results of bf16 operands) to 1e-4 of their
+    scale."""
+    from asr_amd.linear import linear_train
+
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(rows + K)
+    x = rng.standard_normal((rows, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32) if with_bias else None
+    dy = rng.standard_normal((rows, N)).astype(np.float32)
+    xt = torch.from_numpy(x).to(dev).requires_grad_(True)
+    wt = torch.nn.Parameter(torch.from_numpy(w).to(dev))
+    bt = torch.nn.Parameter(torch.from_numpy(b).to(dev)) if with_bias else None
+    y = linear_train(xt, wt, bt)
+    assert y.dtype == torch.bfloat16
+    y.backward(torch.from_numpy(dy).to(dev).to(torch.bfloat16))
+    ref_y = lo.linear_bf16(x, w, b)
+    dx, dW, db = lo.linear_backward_bf16(x, w, dy)
+    got_y = y.detach().float().cpu().numpy()
+    assert (np.abs(got_y - ref_y) <= 2.0 ** -7 * np.abs(ref_y) + 1e-6).all()
+    got_dx = xt.grad.cpu().numpy()
+    assert xt.grad.dtype == torch.float32
+    assert (np.abs(got_dx - dx) <= 2.0 ** -7 * np.abs(dx) + 1e-6 * np.abs(dx).max()).all()
+    got_dW = wt.grad.cpu().double().numpy()
+    assert wt.grad.dtype == torch.float32 and np.abs(got_dW - dW).max() <= 1e-4 * np.abs(dW).max()
+    if with_bias:
+        assert np.abs(bt.grad.cpu().double().numpy() - db).max() <= 1e-4 * np.abs(db).max()
