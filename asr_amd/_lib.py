@@ -19,7 +19,7 @@ CONV_AUTO = 0
 CONV_TOEPLITZ = 1
 CONV_FFT = 2
 NOALLOC_SCRATCH_BYTES = 8 << 20
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class Shape(ctypes.Structure):
@@ -118,6 +118,10 @@ def _load():
     lib.lmufft_attention_bwd.restype = ci
     lib.lmufft_attention_bwd.argtypes = [vp, vp, vp, vp, vp, vp, ci, i64, vp, i32, i32, i32, i32, f32, u32, u32,
                                          vp, vp, vp, i64, vp, vp]
+    lib.lmufft_layernorm_bwd_workspace_bytes.restype = sz
+    lib.lmufft_layernorm_bwd_workspace_bytes.argtypes = [i32]
+    lib.lmufft_layernorm_bwd.restype = ci
+    lib.lmufft_layernorm_bwd.argtypes = [vp, ci, vp, ci, vp, ci, vp, f32, i64, i32, vp, vp, vp, vp, vp, sz, vp]
     lib.lmufft_linear_wgrad_workspace_bytes.restype = sz
     lib.lmufft_linear_wgrad_workspace_bytes.argtypes = [i64, i32, i32]
     lib.lmufft_linear_wgrad_bf16.restype = ci
@@ -171,6 +175,8 @@ EXPORTS = (
     "lmufft_attention_fwd_train",
     "lmufft_attention_bwd",
     "lmufft_add_layernorm",
+    "lmufft_layernorm_bwd_workspace_bytes",
+    "lmufft_layernorm_bwd",
     "lmufft_linear_bf16",
     "lmufft_linear_ln_bf16",
     "lmufft_linear_wgrad_workspace_bytes",

@@ -1,5 +1,5 @@
-// Residual add + LayerNorm for inference on gfx950: one pass over HBM instead of the
-// reference's add kernel followed by a LayerNorm kernel.
+// Residual add + LayerNorm on gfx950: one pass over HBM instead of the reference's add kernel
+// followed by a LayerNorm kernel; and its backward for training (k_layernorm_bwd, further down).
 //
 // Reference arithmetic: MultiHeadAttention.forward, src/models/lmu_encoder.py:97
 //   (output = layer_norm(output + residual)) and LMUEncoder.forward,
@@ -128,6 +128,138 @@ static void launch_ln(int ng, dim3 grid, hipStream_t st, const void* x, const vo
 #undef LN_CASE
 }
 
+// ---------------------------------------------------------------------------
+// Backward of y = LayerNorm(x + res) * gamma + beta (what autograd derives for src/models/lmu_encoder.py:97, 274):
+//   xhat = (x + res - mean) * rstd;  gy = dy * gamma;
+//   ds = rstd * (gy - mean_c(gy) - xhat * mean_c(gy * xhat))     (gradient of the sum: of x and of res alike)
+//   dgamma = sum_rows dy * xhat;  dbeta = sum_rows dy.
+// Row layout as in the forward (32 lanes own a row held in registers); mean and rstd are recomputed from
+// x (+ res) with the forward's arithmetic, so nothing but its inputs has to be kept.  A lane accumulates
+// dgamma / dbeta of its columns over the rows it visits; the eight row slots of a workgroup are summed through
+// LDS and every workgroup leaves one partial [2][C] in the workspace, which k_layernorm_param_reduce adds in
+// workgroup order: deterministic.  dtypes are run-time flags (the kernel is HBM-bound).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ ln_f32x4 ln_load4_rt(const void* base, long idx, bool bf16) {
+  return bf16 ? ln_load4<true>(base, idx) : ln_load4<false>(base, idx);
+}
+__device__ __forceinline__ void ln_store4_rt(void* base, long idx, const ln_f32x4& v, bool bf16) {
+  if (bf16) ln_store4<true>(base, idx, v);
+  else ln_store4<false>(base, idx, v);
+}
+
+constexpr int kLnBwdMaxBlocks = 512;
+
+template <int NG>
+__global__ __launch_bounds__(kLnThreads) void k_layernorm_bwd(const void* x, int xb, const void* res, int rb, const void* dy,
+                                                              int gb, const float* __restrict__ gamma, float eps, long rows,
+                                                              int C, void* dx, void* dres, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [8 row slots][2][C]
+  const int sub = threadIdx.x & 31, slot = threadIdx.x >> 5;
+  const long row0 = (long)blockIdx.x * (kLnThreads / 32) + slot;
+  const long row_step = (long)gridDim.x * (kLnThreads / 32);
+  const int groups = C / 4;
+  ln_f32x4 g[NG], dg[NG], db[NG];
+#pragma unroll
+  for (int j = 0; j < NG; ++j) {
+    const int c = sub + 32 * j;
+    if (c < groups) g[j] = *reinterpret_cast<const ln_f32x4*>(gamma + 4 * c);
+    dg[j] = ln_f32x4(0.f);
+    db[j] = ln_f32x4(0.f);
+  }
+  const float inv_c = 1.f / (float)C;
+  for (long row = row0; row < rows; row += row_step) {
+    ln_f32x4 v[NG], gy[NG];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      const int c = sub + 32 * j;
+      if (c < groups) {
+        v[j] = ln_load4_rt(x, row * C + 4 * c, xb);
+        if (res) v[j] += ln_load4_rt(res, row * C + 4 * c, rb);
+        gy[j] = ln_load4_rt(dy, row * C + 4 * c, gb);
+        s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+      }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s * inv_c;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      const int c = sub + 32 * j;
+      if (c < groups) {
+        v[j] -= mean;
+        q += (v[j][0] * v[j][0] + v[j][1] * v[j][1]) + (v[j][2] * v[j][2] + v[j][3] * v[j][3]);
+      }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q * inv_c + eps);
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      const int c = sub + 32 * j;
+      if (c < groups) {
+        v[j] *= rstd;  // xhat
+        db[j] += gy[j];
+        dg[j] += gy[j] * v[j];
+        gy[j] *= g[j];
+        a += (gy[j][0] + gy[j][1]) + (gy[j][2] + gy[j][3]);
+        const ln_f32x4 t = gy[j] * v[j];
+        b += (t[0] + t[1]) + (t[2] + t[3]);
+      }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      a += __shfl_xor(a, o);
+      b += __shfl_xor(b, o);
+    }
+    a *= inv_c;
+    b *= inv_c;
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      const int c = sub + 32 * j;
+      if (c < groups) {
+        const ln_f32x4 d = (gy[j] - a - v[j] * b) * rstd;
+        ln_store4_rt(dx, row * C + 4 * c, d, xb);
+        if (dres) ln_store4_rt(dres, row * C + 4 * c, d, rb);
+      }
+    }
+  }
+  // the workgroup's partial sums of dgamma, dbeta
+#pragma unroll
+  for (int j = 0; j < NG; ++j) {
+    const int c = sub + 32 * j;
+    if (c < groups) {
+      *reinterpret_cast<ln_f32x4*>(&red[(slot * 2 + 0) * C + 4 * c]) = dg[j];
+      *reinterpret_cast<ln_f32x4*>(&red[(slot * 2 + 1) * C + 4 * c]) = db[j];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += kLnThreads) {
+    float t = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < kLnThreads / 32; ++sl) t += red[sl * 2 * C + i];
+    partial[(long)blockIdx.x * 2 * C + i] = t;
+  }
+}
+
+// out[i] = sum over the workgroups' partials; i < C: dgamma, else dbeta.  One wave per column: lane l adds the
+// partials l, l + 64, ... (all loads in flight together), then the xor tree -- a fixed order.
+__global__ __launch_bounds__(kLnThreads) void k_layernorm_param_reduce(const float* __restrict__ partial, int nblocks, int C,
+                                                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int i = blockIdx.x * (kLnThreads / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= 2 * C) return;
+  float t = 0.f;
+  for (int b = lane; b < nblocks; b += 64) t += partial[(long)b * 2 * C + i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+  if (lane == 0) {
+    if (i < C) dgamma[i] = t;
+    else dbeta[i - C] = t;
+  }
+}
+
 }  // namespace lmufft
 
 using namespace lmufft;
@@ -175,5 +307,54 @@ extern "C" int lmufft_add_layernorm(const void* x, int x_dtype, const void* res,
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error("launch of k_add_layernorm failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
+extern "C" size_t lmufft_layernorm_bwd_workspace_bytes(int32_t C) {
+  return C > 0 ? sizeof(float) * 2 * (size_t)C * kLnBwdMaxBlocks : 0;
+}
+
+extern "C" int lmufft_layernorm_bwd(const void* x, int x_dtype, const void* res, int res_dtype, const void* dy, int dy_dtype,
+                                    const float* gamma, float eps, int64_t rows, int32_t C, void* dx, void* dres,
+                                    float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
+  if (rows <= 0 || C <= 0) return set_error("layernorm backward: bad shape (rows=%lld C=%d)", (long long)rows, C);
+  if (C % 4 != 0 || C > 32 * 4 * kLnMaxGroups)
+    return set_error("layernorm backward: width %d (needs a multiple of 4, at most %d)", C, 32 * 4 * kLnMaxGroups);
+  auto known = [](int d) { return d == LMUFFT_F32 || d == LMUFFT_BF16; };
+  if (!known(x_dtype) || !known(dy_dtype) || (res && !known(res_dtype))) return set_error("layernorm backward: unknown dtype");
+  if (!x || !dy || !gamma || !dx || !dgamma || !dbeta || !workspace) return set_error("layernorm backward: NULL pointer");
+  if (dres && !res) return set_error("layernorm backward: dres without res");
+  if (workspace_bytes < lmufft_layernorm_bwd_workspace_bytes(C))
+    return set_error("layernorm backward: workspace of %zu bytes needed, %zu given", lmufft_layernorm_bwd_workspace_bytes(C),
+                     workspace_bytes);
+  auto aligned = [](const void* p, int dtype) {
+    return (reinterpret_cast<uintptr_t>(p) & (dtype == LMUFFT_F32 ? 15 : 7)) == 0;
+  };
+  if (!aligned(x, x_dtype) || !aligned(dx, x_dtype) || !aligned(dy, dy_dtype) || (res && !aligned(res, res_dtype)) ||
+      (dres && !aligned(dres, res_dtype)) || !aligned(gamma, LMUFFT_F32) || !aligned(workspace, LMUFFT_F32))
+    return set_error("layernorm backward: rows must start on 16-byte (f32) / 8-byte (bf16) boundaries");
+  hipStream_t st = (hipStream_t)stream;
+  const int ng = (C / 4 + 31) / 32;
+  const long blocks = (rows + kLnThreads / 32 - 1) / (kLnThreads / 32);
+  const int nb = (int)std::min<long>(blocks, kLnBwdMaxBlocks);
+  const size_t lds = sizeof(float) * (kLnThreads / 32) * 2 * (size_t)C;
+  float* partial = (float*)workspace;
+  {
+    ProfScope ps("k_layernorm_bwd", st);
+#define LN_BWD(NGV)                                                                                                    \
+  hipLaunchKernelGGL((k_layernorm_bwd<NGV>), dim3(nb), dim3(kLnThreads), lds, st, x, x_dtype == LMUFFT_BF16, res,         \
+                     res_dtype == LMUFFT_BF16, dy, dy_dtype == LMUFFT_BF16, gamma, eps, (long)rows, C, dx, dres, partial)
+    if (ng <= 1) LN_BWD(1);
+    else if (ng <= 2) LN_BWD(2);
+    else if (ng <= 3) LN_BWD(3);
+    else if (ng <= 4) LN_BWD(4);
+    else if (ng <= 6) LN_BWD(6);
+    else LN_BWD(8);
+#undef LN_BWD
+    hipLaunchKernelGGL(k_layernorm_param_reduce, dim3((2 * C + kLnThreads / 64 - 1) / (kLnThreads / 64)), dim3(kLnThreads), 0, st,
+                       (const float*)partial, nb, C, dgamma, dbeta);
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error("launch of k_layernorm_bwd failed: %s", hipGetErrorString(e));
   return 0;
 }

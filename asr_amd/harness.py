@@ -21,7 +21,7 @@ import torch
 from torch import nn
 
 from .attention import SUPPORTED_HEAD_WIDTHS, masked_attention, masked_attention_packed, masked_attention_train
-from .layernorm import MAX_WIDTH as _LN_MAX_WIDTH, add_layer_norm
+from .layernorm import MAX_WIDTH as _LN_MAX_WIDTH, add_layer_norm, add_layer_norm_train
 from .linear import linear_bf16, linear_train, supported as linear_supported, train_supported as linear_train_supported
 from .ctc import CTCDecoder
 from .lmu import LMUFFT
@@ -134,6 +134,11 @@ def _layer_norm(ln: nn.LayerNorm, x: torch.Tensor, residual: Optional[torch.Tens
             and (residual is None or residual.dtype in (torch.float32, torch.bfloat16))):
         _took("hip", "layer_norm")
         return add_layer_norm(x, residual, ln.weight, ln.bias, ln.eps, out_dtype=out_dtype)
+    if (x.is_cuda and torch.is_grad_enabled() and ln.elementwise_affine and ln.bias is not None and C % 4 == 0
+            and C <= _LN_MAX_WIDTH and x.dtype in (torch.float32, torch.bfloat16) and ln.weight.dtype == torch.float32
+            and (residual is None or residual.dtype in (torch.float32, torch.bfloat16))):
+        _took("hip", "layer_norm")  # training: the same forward kernel, and its backward, behind an autograd function
+        return add_layer_norm_train(x, residual, ln.weight, ln.bias, ln.eps, out_dtype)
     _took("torch", "layer_norm")
     y = ln(x if residual is None else x + residual)
     return y if out_dtype is None else y.to(out_dtype)

@@ -57,3 +57,63 @@ def add_layer_norm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: to
             ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
     _lib.check(rc, "lmufft_add_layernorm")
     return out
+
+
+def add_layer_norm_backward(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor, dy: torch.Tensor,
+                            eps: float = 1e-5):
+    """(dx, dresidual or None, dweight, dbias) of add_layer_norm: dx / dresidual carry the same values in the dtype
+    of x / residual (one tensor when the dtypes agree); dweight, dbias float32.  HIP kernel k_layernorm_bwd."""
+    for name, t in (("x", x), ("residual", residual), ("weight", weight), ("dy", dy)):
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(f"add_layer_norm_backward: `{name}` lives on {t.device}; the kernel runs only on a GPU "
+                               "(there is no CPU fallback)")
+    C = x.shape[-1]
+    if dy.shape != x.shape or (residual is not None and residual.shape != x.shape) or weight.shape != (C,):
+        raise RuntimeError("add_layer_norm_backward: x, residual and dy must share one shape [..., C], weight [C]")
+    if x.dtype not in _DTYPES or dy.dtype not in _DTYPES or (residual is not None and residual.dtype not in _DTYPES):
+        raise RuntimeError("add_layer_norm_backward: supported dtypes are float32 and bfloat16")
+    x, dy = x.detach().contiguous(), dy.detach().contiguous()
+    residual = None if residual is None else residual.detach().contiguous()
+    weight = weight.detach().float().contiguous()
+    dx = torch.empty_like(x)
+    dres = None
+    if residual is not None and residual.dtype != x.dtype:
+        dres = torch.empty_like(residual)
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = torch.empty(_lib.lib.lmufft_layernorm_bwd_workspace_bytes(C), dtype=torch.uint8, device=x.device)
+    rows = x.numel() // C
+    p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    with torch.cuda.device(x.device):
+        rc = _lib.lib.lmufft_layernorm_bwd(
+            p(x), _DTYPES[x.dtype], p(residual), _DTYPES[residual.dtype] if residual is not None else 0, p(dy),
+            _DTYPES[dy.dtype], p(weight), float(eps), rows, C, p(dx), p(dres), p(dgamma), p(dbeta), p(ws), ws.numel(),
+            ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    _lib.check(rc, "lmufft_layernorm_bwd")
+    if residual is None:
+        return dx, None, dgamma, dbeta
+    return dx, (dx if dres is None else dres), dgamma, dbeta
+
+
+class _AddLayerNormTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, eps, out_dtype):
+        ctx.save_for_backward(x, residual, weight)
+        ctx.eps = eps
+        return add_layer_norm(x, residual, weight, bias, eps, out_dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, residual, weight = ctx.saved_tensors
+        dx, dres, dgamma, dbeta = add_layer_norm_backward(x, residual, weight, dy, ctx.eps)
+        return (dx if ctx.needs_input_grad[0] else None, dres if ctx.needs_input_grad[1] else None,
+                dgamma.to(weight.dtype), dbeta.to(weight.dtype), None, None)
+
+
+def add_layer_norm_train(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor, bias: torch.Tensor,
+                         eps: float = 1e-5, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """add_layer_norm with autograd (forward k_add_layernorm, backward k_layernorm_bwd)."""
+    if out_dtype is None:
+        out_dtype = torch.float32 if torch.is_autocast_enabled() else (
+            x.dtype if residual is None else torch.promote_types(x.dtype, residual.dtype))
+    return _AddLayerNormTrain.apply(x, residual, weight, bias, eps, out_dtype)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMUFFT_ABI_VERSION 10
+#define LMUFFT_ABI_VERSION 11
 
 /* element types of the activations (x, h, gh, gx, m) */
 #define LMUFFT_F32 0
@@ -267,6 +267,19 @@ int lmufft_attention_bwd(const void* q, const void* k, const void* v, const void
                          const float* stats, int dtype, int64_t ld, const int32_t* lengths, int32_t B,
                          int32_t T, int32_t H, int32_t DK, float p_drop, uint32_t seed0, uint32_t seed1,
                          void* dq, void* dk, void* dv, int64_t ld_grad, float* dsum, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Backward of the residual add + LayerNorm (training).  Replaces what autograd derives for
+ * layer_norm(output + residual), src/models/lmu_encoder.py:97, and layer_norm(x), :274:
+ *   ds = rstd (gy - mean(gy) - xhat mean(gy xhat)), gy = dy gamma, xhat = (x + res - mean) rstd  -> dx (dtype of x)
+ *   and, when dres != NULL, the same values in the dtype of res; dgamma = sum_rows dy xhat, dbeta = sum_rows dy (f32).
+ * x, res (may be NULL), dy: [rows][C] f32 or bf16 each; mean and rstd are recomputed from x (+ res) with the
+ * forward's arithmetic.  C a multiple of 4, at most 1024.  Sums in a fixed order.
+ * ---------------------------------------------------------------------- */
+size_t lmufft_layernorm_bwd_workspace_bytes(int32_t C);
+int lmufft_layernorm_bwd(const void* x, int x_dtype, const void* res, int res_dtype, const void* dy, int dy_dtype,
+                         const float* gamma, float eps, int64_t rows, int32_t C, void* dx, void* dres,
+                         float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Weight and bias gradient of a Linear layer under bf16 autocast (training).  Replaces what autograd runs

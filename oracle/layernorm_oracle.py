@@ -21,3 +21,20 @@ def add_layer_norm(x, residual, weight, bias, eps=1e-5):
     var = ((v - mean) ** 2).mean(axis=-1, keepdims=True)
     y = (v - mean) / np.sqrt(var + eps) * np.asarray(weight, np.float64) + np.asarray(bias, np.float64)
     return y.astype(np.float32)
+
+
+def add_layer_norm_backward(x, residual, weight, dy, eps=1e-5):
+    """(ds, dgamma, dbeta) of y = LayerNorm(x + residual) * weight + bias in float64: ds is the gradient of the
+    sum (of x and of residual alike).  What autograd derives for src/models/lmu_encoder.py:97, 274."""
+    v = np.asarray(x, dtype=np.float32)
+    if residual is not None:
+        v = v + np.asarray(residual, dtype=np.float32)
+    v = v.astype(np.float64)
+    C = v.shape[-1]
+    mean = v.mean(axis=-1, keepdims=True)
+    rstd = 1.0 / np.sqrt(((v - mean) ** 2).mean(axis=-1, keepdims=True) + eps)
+    xhat = (v - mean) * rstd
+    g = np.asarray(dy, dtype=np.float64)
+    gy = g * np.asarray(weight, np.float64)
+    ds = rstd * (gy - gy.mean(axis=-1, keepdims=True) - xhat * (gy * xhat).mean(axis=-1, keepdims=True))
+    return ds, (g * xhat).reshape(-1, C).sum(axis=0), g.reshape(-1, C).sum(axis=0)

@@ -195,9 +195,10 @@ def test_cached_bf16_weights_follow_parameter_updates():
 
 def test_strict_kernels_and_fp16_input():
     """Under bf16 autocast in inference every op of the harness runs a HIP kernel of this package:
-    inside strict_kernels() nothing raises and no torch formulation is counted.  With gradients enabled
-    the same call raises instead of silently timing torch ops.  fp16 activations (the reference
-    trainer's autocast dtype) are widened to fp32 by the layer."""
+    inside strict_kernels() nothing raises and no torch formulation is counted.  With gradients enabled under
+    bf16 autocast the training kernels (attention, Linear, layer norm, LMUFFT) run and nothing raises either; in
+    fp32 training the Linear layers are torch ops, and there the call raises instead of silently timing them.
+    fp16 activations (the reference trainer's autocast dtype) are widened to fp32 by the layer."""
     from asr_amd import LMUFFT, harness
     from asr_amd.harness import LMUASRModel
 
@@ -211,8 +212,12 @@ def test_strict_kernels_and_fp16_input():
     with harness.strict_kernels(), torch.autocast("cuda", dtype=torch.bfloat16):
         model.transcribe(spec, lengths)
     assert harness.PATHS and not [k for k in harness.PATHS if k.startswith("torch:")], harness.PATHS
+    harness.PATHS.clear()
+    with harness.strict_kernels(), torch.enable_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        enc, _ = model.encoder(spec, lengths)
+    assert enc.requires_grad and not [k for k in harness.PATHS if k.startswith("torch:")], harness.PATHS
     with pytest.raises(RuntimeError, match="strict_kernels"):
-        with harness.strict_kernels(), torch.enable_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        with harness.strict_kernels(), torch.enable_grad():
             model.encoder(spec, lengths)
     layer = LMUFFT(80, 96, 64, 100, 50.0).to(dev)
     x = torch.randn(2, 100, 80, device=dev)

@@ -118,3 +118,67 @@ def test_layer_norm_in_projection_epilogue(B, T, D, M, Hd, out_dtype):
         assert not wide.supports_fused_layer_norm(x)
         with pytest.raises(RuntimeError, match="lmufft_add_layernorm"):
             wide.forward_layer_norm(x, torch.nn.LayerNorm(512).to(dev))
+
+
+def test_oracle_backward_matches_torch_autograd():
+    """The backward restatement against torch autograd of layer_norm(x + residual) on the CPU (fp64)."""
+    rng = np.random.default_rng(9)
+    for with_res in (False, True):
+        x = rng.standard_normal((13, 24)).astype(np.float32)
+        r = rng.standard_normal((13, 24)).astype(np.float32) if with_res else None
+        w, dy = rng.standard_normal(24), rng.standard_normal((13, 24))
+        ds, dg, db = lo.add_layer_norm_backward(x, r, w, dy, 1e-5)
+        tx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+        tr = torch.tensor(r, dtype=torch.float64, requires_grad=True) if with_res else None
+        tw = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+        tb = torch.zeros(24, dtype=torch.float64, requires_grad=True)
+        torch.nn.functional.layer_norm(tx if tr is None else tx + tr, (24,), tw, tb, 1e-5).backward(torch.tensor(dy))
+        # the oracle forms x + residual in fp32, as the reference does; torch here adds in fp64
+        tol = dict(rtol=1e-5, atol=1e-6) if with_res else dict(rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(ds, tx.grad.numpy(), **tol)
+        if with_res:
+            np.testing.assert_allclose(ds, tr.grad.numpy(), **tol)
+        np.testing.assert_allclose(dg, tw.grad.numpy(), rtol=1e-5 if with_res else 1e-10, atol=1e-6 if with_res else 1e-12)
+        np.testing.assert_allclose(db, tb.grad.numpy(), rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,C", [(5, 8), (25600, 384), (1000, 1024), (33, 200)])
+@pytest.mark.parametrize("x_dtype,res_dtype,dy_dtype", [(torch.float32, None, torch.float32),
+                                                       (torch.bfloat16, torch.float32, torch.float32),
+                                                       (torch.bfloat16, torch.bfloat16, torch.bfloat16),
+                                                       (torch.float32, torch.bfloat16, torch.bfloat16)])
+def test_training_layer_norm_matches_oracle(rows, C, x_dtype, res_dtype, dy_dtype):
+    """add_layer_norm_train: forward as the inference kernel, backward (k_layernorm_bwd) against the oracle on the
+    same (rounded) inputs.  fp32 bar: ds to 1e-4 of its scale per element (bf16 outputs: one more rounding);
+    dweight / dbias: sums over the rows, 1e-4 of their scale."""
+    from asr_amd.layernorm import add_layer_norm_train
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(rows + C)
+    x = torch.randn(rows, C, generator=g).to(x_dtype)
+    r = None if res_dtype is None else torch.randn(rows, C, generator=g).to(res_dtype)
+    w = torch.randn(C, generator=g) * 0.5 + 1.0
+    b = torch.randn(C, generator=g)
+    dy = torch.randn(rows, C, generator=g).to(dy_dtype)
+    xd = x.to(dev).requires_grad_(True)
+    rd = None if r is None else r.to(dev).requires_grad_(True)
+    wd, bd = torch.nn.Parameter(w.to(dev)), torch.nn.Parameter(b.to(dev))
+    y = add_layer_norm_train(xd, rd, wd, bd, 1e-5, dy_dtype)
+    assert y.dtype == dy_dtype
+    y.backward(dy.to(dev))
+    ds, dg, db = lo.add_layer_norm_backward(x.float().numpy(), None if r is None else r.float().numpy(), w.numpy(),
+                                            dy.float().numpy(), 1e-5)
+    scale = np.abs(ds).max()
+
+    def close(t, tol):
+        return np.abs(t.float().cpu().double().numpy() - ds).max() <= tol * scale
+
+    assert xd.grad.dtype == x_dtype and close(xd.grad, 1e-4 if x_dtype == torch.float32 else 2.0 ** -7)
+    if r is not None:
+        assert rd.grad.dtype == res_dtype and close(rd.grad, 1e-4 if res_dtype == torch.float32 else 2.0 ** -7)
+    assert np.abs(wd.grad.cpu().double().numpy() - dg).max() <= 1e-4 * np.abs(dg).max() + 1e-5
+    assert np.abs(bd.grad.cpu().double().numpy() - db).max() <= 1e-4 * np.abs(db).max() + 1e-5
+    ref_y = lo.add_layer_norm(x.float().numpy(), None if r is None else r.float().numpy(), w.numpy(), b.numpy(), 1e-5)
+    assert np.abs(y.detach().float().cpu().numpy() - ref_y).max() <= (1e-5 if dy_dtype == torch.float32 else 2.0 ** -7) * \
+        np.abs(ref_y).max() + 1e-5
