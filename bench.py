@@ -59,6 +59,8 @@ def parse_args():
     ap.add_argument("--no-overlap", action="store_true",
                     help="exchange all gradients in one all-reduce after the backward instead of per bucket "
                          "behind the remaining backward segments")
+    ap.add_argument("--bf16-stream", action="store_true",
+                    help="c2_full: layer norms write bf16 instead of autocast's fp32 (one more bf16 rounding per block)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying HIP graphs")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -299,6 +301,7 @@ def bench_full_step(args, dev, rank, world):
             torch.nn.init.xavier_uniform_(mod.weight)
             torch.nn.init.zeros_(mod.bias)
     enc = model.encoder
+    enc.bf16_stream = bool(args.bf16_stream)
     groups = [[*model.decoder.parameters(), *enc.output_projection.parameters()]]
     for i in reversed(range(args.layers)):  # the order in which the backward completes them
         groups += [list(enc.layer_norms[i].parameters()), enc.lmu_layers[i], list(enc.attention_layers[i].parameters())]
@@ -312,14 +315,17 @@ def bench_full_step(args, dev, rank, world):
     in_len = torch.full((B,), T, dtype=torch.long, device=dev)
     tgt_len = torch.randint(20, 61, (B,), device=dev, generator=g)
     targets = torch.randint(0, 33, (B, 60), device=dev, generator=g)
-    total = int(tgt_len.sum().item())  # a data loader knows this; keeps the step free of read-backs
+    # The data loader hands out the lengths on the host; torch's CTC loss wants them there (device tensors are
+    # read back, a synchronisation per step).  The total is known there too: the step makes no read-back.
+    in_len_host, tgt_len_host = in_len.cpu(), tgt_len.cpu()
+    total = int(tgt_len_host.sum())
     losses = []
 
     def step():
         buckets.zero_grad()
         with torch.autocast("cuda", dtype=torch.bfloat16):
             lp = model.log_probs_for_training(spec, in_len)
-        loss = model.compute_loss(lp, targets, in_len, tgt_len, total)
+        loss = model.compute_loss(lp, targets, in_len_host, tgt_len_host, total)
         loss.backward()
         buckets.finish()
         opt.step()
@@ -370,6 +376,7 @@ def bench_full_step(args, dev, rank, world):
                    "batch_per_gpu": B, "frames": T, "parallelism": f"dp{world}", "world_size": world,
                    "hip_kernels": "LMUFFT forward/backward, gradient norm + clip + AdamW, CTC target packing",
                    "torch_ops": "attention, layer norms, Linear projections, dropout, log-softmax, CTC loss",
+                   "activation_stream": "bf16 between blocks" if args.bf16_stream else "fp32 between blocks (autocast)",
                    "gradient_buckets": len(buckets.buckets)},
         "roofline": None,
         "hip_kernel_ms_per_step": hip_ms,
