@@ -19,7 +19,7 @@ CONV_AUTO = 0
 CONV_TOEPLITZ = 1
 CONV_FFT = 2
 NOALLOC_SCRATCH_BYTES = 8 << 20
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class Shape(ctypes.Structure):
@@ -126,6 +126,10 @@ def _load():
     lib.lmufft_linear_wgrad_workspace_bytes.argtypes = [i64, i32, i32]
     lib.lmufft_linear_wgrad_bf16.restype = ci
     lib.lmufft_linear_wgrad_bf16.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp, sz, vp]
+    lib.lmufft_ctc_loss_workspace_bytes.restype = sz
+    lib.lmufft_ctc_loss_workspace_bytes.argtypes = [i32, i32, i32]
+    lib.lmufft_ctc_loss.restype = ci
+    lib.lmufft_ctc_loss.argtypes = [vp, vp, i64, vp, vp, i32, i32, i32, i32, i32, ci, ci, vp, vp, vp, sz, vp]
     lib.lmufft_ctc_pack_targets.restype = ci
     lib.lmufft_ctc_pack_targets.argtypes = [vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, vp, vp, vp]
     lib.lmufft_grad_norm_workspace_bytes.restype = sz
@@ -184,6 +188,8 @@ EXPORTS = (
     "lmufft_ctc_workspace_bytes",
     "lmufft_ctc_greedy",
     "lmufft_ctc_pack_targets",
+    "lmufft_ctc_loss_workspace_bytes",
+    "lmufft_ctc_loss",
     "lmufft_grad_norm_workspace_bytes",
     "lmufft_grad_norm2_f32",
     "lmufft_adamw_step_f32",

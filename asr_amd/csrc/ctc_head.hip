@@ -360,6 +360,273 @@ __global__ __launch_bounds__(kPackThreads) void k_ctc_pack_targets(const int64_t
   for (int i = threadIdx.x; i < len; i += kPackThreads) packed[o + i] = targets[(long)b * ld + i];
 }
 
+// ---------------------------------------------------------------------------
+// CTC loss and its gradient (training).  The reference uses nn.CTCLoss(blank = vocab_size - 1,
+// reduction = 'mean', zero_infinity = True), src/models/asr_model.py:105, 130-156.  Per utterance, in the log
+// domain (states 0..2L: even = blank, odd = label (s-1)/2):
+//   alpha_t(s) = lp_t(c_s) + lse(alpha_{t-1}(s), alpha_{t-1}(s-1), [c_s != c_{s-2}] alpha_{t-1}(s-2))
+//   beta_t(s)  = lp_t(c_s) + lse(beta_{t+1}(s),  beta_{t+1}(s+1),  [c_s != c_{s+2}] beta_{t+1}(s+2))
+//   nll = -lse(alpha_{Tb-1}(2L), alpha_{Tb-1}(2L-1))
+//   grad_t(c) = w (exp lp_t(c) - exp(lse_{s: c_s = c}(alpha_t(s) + beta_t(s)) + nll - lp_t(c)))   for t < Tb, else 0
+// -- the gradient torch's ctc_loss returns for log_probs (it is the gradient through the log-softmax that produced
+// them: its rows sum to zero), w = 1 / (B max(L, 1)) for the mean reduction.
+//
+// Two launches.  k_ctc_alpha_beta is the serial part: one workgroup per utterance, thread l owns blank state 2l
+// and label state 2l+1, and the two recursions -- which do not depend on each other -- run at the same time in two
+// halves of the workgroup (one after the other when 2 x 16 waves would not fit).  A step is one exchange of the
+// neighbour's value through double-buffered LDS and two log-sum-exps; the log-probabilities it needs are fetched
+// eight frames ahead, since nothing else hides a global load here.  Both sets of variables go to the workspace.
+// k_ctc_grad is the parallel part: one wave per frame adds alpha + beta + nll, and lane c forms class c's sum by
+// walking the list of its label positions (blank: a wave reduction) -- fixed orders, no atomics.
+//
+// The recursions run on doubles: |alpha| grows like T log V (about 1400 at 400 frames), where an fp32 ulp is 1e-4
+// and 400 roundings would put 1e-3 of relative error into every posterior.  Only the maximum and the sums are
+// double; the exponentials and the logarithm see differences of a few units and stay in fp32.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double ctc_lse2(double a, double b) {
+  const double m = fmax(a, b);
+  if (m == -INFINITY) return -INFINITY;
+  return m + (double)__logf(__expf((float)(a - m)) + __expf((float)(b - m)));
+}
+__device__ __forceinline__ double ctc_lse3(double a, double b, double c) {
+  const double m = fmax(fmax(a, b), c);
+  if (m == -INFINITY) return -INFINITY;
+  return m + (double)__logf(__expf((float)(a - m)) + __expf((float)(b - m)) + __expf((float)(c - m)));
+}
+
+// other lanes' LDS stores feed this lane's next loads: the LDS serves a wave's instructions in order, the compiler
+// only has to keep them in order
+__device__ __forceinline__ void ctc_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// workgroup barrier for LDS traffic only: global loads and stores stay in flight across it
+template <int NW>
+__device__ __forceinline__ void ctc_sync() {
+  if (NW == 1) {
+    ctc_wave_sync();
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+}
+
+constexpr int kCtcAhead = 8;  // frames of log-probabilities in flight per thread
+
+// One recursion over the frames of an utterance.  FWD: alpha, frames 0 .. Tb-1; otherwise beta, frames Tb-1 .. 0.
+// xb / xl: [2][NT + 2] exchange buffers of the blank / label values, thread l at index l + 1, both ends -inf.
+// Every thread of the group makes Tb - 1 calls of ctc_sync.  Returns the buffer the last step wrote.
+template <int NW, bool FWD>
+__device__ __forceinline__ int ctc_sweep(const float* __restrict__ lpb, int V, int blank, int my_label, int l, int L, int Tb,
+                                         bool skip, double* __restrict__ w, double (*xb)[64 * NW + 2],
+                                         double (*xl)[64 * NW + 2], double& vb, double& vl) {
+  constexpr int NT = 64 * NW;
+  const int t0 = FWD ? 0 : Tb - 1;
+  {
+    const float* row = lpb + (long)t0 * V;
+    if (FWD) {
+      vb = l == 0 ? (double)row[blank] : -INFINITY;
+      vl = (l == 0 && L > 0) ? (double)row[my_label] : -INFINITY;
+    } else {
+      vb = l == L ? (double)row[blank] : -INFINITY;
+      vl = l == L - 1 ? (double)row[my_label] : -INFINITY;
+    }
+  }
+  int cur = 0;
+  xb[0][l + 1] = vb;
+  xl[0][l + 1] = vl;
+  if (l == 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) xb[i][0] = xl[i][0] = xb[i][NT + 1] = xl[i][NT + 1] = -INFINITY;
+  }
+  *reinterpret_cast<double2*>(w + (long)t0 * 2 * NT + 2 * l) = make_double2(vb, vl);
+  float qb[kCtcAhead], ql[kCtcAhead];
+#pragma unroll
+  for (int i = 0; i < kCtcAhead; ++i) {
+    const int k = min(1 + i, Tb - 1);
+    const float* row = lpb + (long)(FWD ? k : Tb - 1 - k) * V;
+    qb[i] = row[blank];
+    ql[i] = row[my_label];
+  }
+  ctc_sync<NW>();
+  for (int k0 = 1; k0 < Tb; k0 += kCtcAhead) {
+    float nqb[kCtcAhead], nql[kCtcAhead];
+#pragma unroll
+    for (int i = 0; i < kCtcAhead; ++i) {
+      const int k = min(k0 + kCtcAhead + i, Tb - 1);
+      const float* row = lpb + (long)(FWD ? k : Tb - 1 - k) * V;
+      nqb[i] = row[blank];
+      nql[i] = row[my_label];
+    }
+#pragma unroll
+    for (int i = 0; i < kCtcAhead; ++i) {
+      const int k = k0 + i;
+      if (k < Tb) {  // uniform over the workgroup
+        const int t = FWD ? k : Tb - 1 - k;
+        double nb, nl;
+        if (FWD) {
+          const double pl = xl[cur][l];  // label state of thread l - 1
+          nb = l <= L ? ctc_lse2(vb, pl) + (double)qb[i] : -INFINITY;
+          nl = l < L ? ctc_lse3(vl, vb, skip ? pl : -INFINITY) + (double)ql[i] : -INFINITY;
+        } else {
+          const double nxb = xb[cur][l + 2], nxl = xl[cur][l + 2];  // states of thread l + 1
+          nb = l <= L ? ctc_lse2(vb, vl) + (double)qb[i] : -INFINITY;
+          nl = l < L ? ctc_lse3(vl, nxb, skip ? nxl : -INFINITY) + (double)ql[i] : -INFINITY;
+        }
+        vb = nb;
+        vl = nl;
+        cur ^= 1;
+        if (!FWD) xb[cur][l + 1] = vb;
+        xl[cur][l + 1] = vl;
+        *reinterpret_cast<double2*>(w + (long)t * 2 * NT + 2 * l) = make_double2(vb, vl);
+        ctc_sync<NW>();
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kCtcAhead; ++i) {
+      qb[i] = nqb[i];
+      ql[i] = nql[i];
+    }
+  }
+  return cur;
+}
+
+// workspace of the two kernels: alpha [B][T][2 NT], beta [B][T][2 NT], nll [B], all doubles
+template <int NW, bool BOTH>
+__global__ __launch_bounds__(64 * NW * (BOTH ? 2 : 1)) void k_ctc_alpha_beta(
+    const float* __restrict__ log_probs, const int64_t* __restrict__ targets, long ld, const int32_t* __restrict__ input_lengths,
+    const int32_t* __restrict__ target_lengths, int B, int T, int V, int blank, float* __restrict__ nll_out,
+    double* __restrict__ ws) {
+  constexpr int NT = 64 * NW;
+  constexpr int ND = BOTH ? 2 : 1;
+  __shared__ double xb[ND][2][NT + 2], xl[ND][2][NT + 2];
+  __shared__ int lab[NT + 1];
+  const int b = blockIdx.x;
+  const int l = threadIdx.x & (NT - 1), half = BOTH ? threadIdx.x / NT : 0;
+  const int Tb = min(max(input_lengths[b], 0), T);
+  const int L = min(max(target_lengths[b], 0), NT - 1);
+  const float* lpb = log_probs + (long)b * T * V;
+  double* alpha = ws + (long)b * T * 2 * NT;
+  double* beta = ws + ((long)B + b) * T * 2 * NT;
+  double* nll_d = ws + (long)2 * B * T * 2 * NT;
+  const int my_label = l < L ? min(max((int)targets[(long)b * ld + l], 0), V - 1) : blank;
+  if (half == 0) lab[l] = my_label;
+  if (threadIdx.x == 0) lab[NT] = blank;
+  __syncthreads();
+  if (Tb == 0) {  // no frames: nothing aligns (torch returns inf here)
+    if (threadIdx.x == 0) {
+      nll_out[b] = INFINITY;
+      nll_d[b] = INFINITY;
+    }
+    return;
+  }
+  const bool skip_prev = l >= 1 && l < L && lab[l - 1] != my_label;  // label l may be entered from label l-1
+  const bool skip_next = l + 1 < L && lab[l + 1] != my_label;        // label l may move on to label l+1
+  double vb, vl;
+  if (half == 0) {
+    const int cur = ctc_sweep<NW, true>(lpb, V, blank, my_label, l, L, Tb, skip_prev, alpha, xb[0], xl[0], vb, vl);
+    if (l == L) {  // vb = alpha(2L); alpha(2L-1) is the label value of thread L-1
+      const double ll = ctc_lse2(vb, xl[0][cur][L]);
+      nll_out[b] = (float)-ll;
+      nll_d[b] = -ll;
+    }
+  }
+  if (!BOTH) __syncthreads();  // the exchange buffers are used again
+  if (half == ND - 1) ctc_sweep<NW, false>(lpb, V, blank, my_label, l, L, Tb, skip_next, beta, xb[ND - 1], xl[ND - 1], vb, vl);
+}
+
+constexpr int kCtcGradWaves = 4;    // one frame per wave at a time
+constexpr int kCtcGradFrames = 16;  // frames per workgroup
+
+template <int NW>
+__global__ __launch_bounds__(64 * kCtcGradWaves) void k_ctc_grad(
+    const float* __restrict__ log_probs, const int64_t* __restrict__ targets, long ld, const int32_t* __restrict__ input_lengths,
+    const int32_t* __restrict__ target_lengths, int B, int T, int V, int blank, int mean, int zero_infinity,
+    float* __restrict__ grad, const double* __restrict__ ws) {
+  constexpr int NT = 64 * NW;
+  __shared__ float x[kCtcGradWaves][2 * NT];
+  __shared__ int lab[NT];
+  __shared__ int cls_start[65], cls_pos[NT];
+  const int b = blockIdx.y, t_first = blockIdx.x * kCtcGradFrames;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int Tb = min(max(input_lengths[b], 0), T);
+  const int L = min(max(target_lengths[b], 0), NT - 1);
+  const double nll = ws[(long)2 * B * T * 2 * NT + b];
+  const bool dead = !(nll < (double)INFINITY);  // no valid alignment (or NaN)
+  float* gb = grad + (long)b * T * V;
+  const int t_end = min(t_first + kCtcGradFrames, T);
+  if (t_first >= Tb || (dead && zero_infinity)) {  // frames past the utterance's end, or a zeroed utterance
+    for (int i = threadIdx.x; i < (t_end - t_first) * V; i += 64 * kCtcGradWaves) gb[(long)t_first * V + i] = 0.f;
+    return;
+  }
+  // label positions grouped by class, ascending inside a class: thread c counts, a scan places, thread c fills
+  for (int i = threadIdx.x; i < L; i += 64 * kCtcGradWaves) lab[i] = min(max((int)targets[(long)b * ld + i], 0), V - 1);
+  __syncthreads();
+  if (wave == 0) {
+    int n = 0;
+    if (lane < V)
+      for (int i = 0; i < L; ++i) n += lab[i] == lane;
+    int incl = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o);
+      if (lane >= o) incl += up;
+    }
+    int at = incl - n;
+    cls_start[lane] = at;
+    if (lane == 63) cls_start[64] = incl;
+    if (lane < V)
+      for (int i = 0; i < L; ++i)
+        if (lab[i] == lane) cls_pos[at++] = i;
+  }
+  __syncthreads();
+  const float w = mean ? 1.f / ((float)B * (float)max(L, 1)) : 1.f;
+  const int S = 2 * L + 1;
+  float* xw = x[wave];
+  for (int t = t_first + wave; t < t_end; t += kCtcGradWaves) {
+    float g = 0.f;
+    if (t < Tb) {
+      const float lpc = lane < V ? log_probs[((long)b * T + t) * V + lane] : 0.f;
+      if (dead) {  // (zero_infinity off) no path through any state: the posterior term vanishes
+        g = w * __expf(lpc);
+      } else {
+        const double* a = ws + ((long)b * T + t) * 2 * NT;
+        const double* bt = ws + (((long)B + b) * T + t) * 2 * NT;
+        // log of (path mass through the state) x p_t(class) over the total: a few units around lp, so fp32 from here
+        for (int s = lane; s < S; s += 64) xw[s] = (float)(a[s] + bt[s] + nll);
+        ctc_wave_sync();
+        float lab_sum;
+        {  // blank class: states 0, 2, .., 2L over the lanes
+          float m = -INFINITY;
+          for (int i = lane; i <= L; i += 64) m = fmaxf(m, xw[2 * i]);
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+          float e = 0.f;
+          if (m != -INFINITY)
+            for (int i = lane; i <= L; i += 64) e += __expf(xw[2 * i] - m);
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
+          lab_sum = m == -INFINITY ? -INFINITY : m + __logf(e);
+        }
+        if (lane < V && lane != blank) {
+          const int p0 = cls_start[lane], p1 = cls_start[lane + 1];
+          float mm = -INFINITY;
+          for (int i = p0; i < p1; ++i) mm = fmaxf(mm, xw[2 * cls_pos[i] + 1]);
+          float ss = 0.f;
+          for (int i = p0; i < p1; ++i) ss += __expf(xw[2 * cls_pos[i] + 1] - mm);
+          lab_sum = mm == -INFINITY ? -INFINITY : mm + __logf(ss);
+        }
+        const float occ = lab_sum == -INFINITY ? 0.f : __expf(lab_sum - lpc);
+        g = w * (__expf(lpc) - occ);
+        ctc_wave_sync();  // the next frame overwrites xw
+      }
+    }
+    if (lane < V) gb[(long)t * V + lane] = g;
+  }
+}
+
 }  // namespace lmufft
 
 using namespace lmufft;
@@ -452,6 +719,57 @@ int lmufft_ctc_pack_targets(const int64_t* targets, const int32_t* target_length
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error("launch of k_ctc_pack_targets failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
+// waves per workgroup: one thread per label position and one more, rounded up to 1, 2, 4, 8 or 16 waves
+static int ctc_loss_waves(int Lmax) {
+  const int need = (Lmax + 1 + 63) / 64;
+  int nw = 1;
+  while (nw < need) nw *= 2;
+  return nw;
+}
+
+size_t lmufft_ctc_loss_workspace_bytes(int32_t B, int32_t T, int32_t Lmax) {
+  if (B <= 0 || T <= 0 || Lmax < 0 || Lmax + 1 > 1024) return 0;
+  return sizeof(double) * ((size_t)2 * B * T * 2 * 64 * (size_t)ctc_loss_waves(Lmax) + (size_t)B);
+}
+
+int lmufft_ctc_loss(const float* log_probs, const int64_t* targets, int64_t ld, const int32_t* input_lengths,
+                    const int32_t* target_lengths, int32_t B, int32_t T, int32_t V, int32_t Lmax, int32_t blank,
+                    int reduction_mean, int zero_infinity, float* nll, float* grad, void* workspace, size_t workspace_bytes,
+                    void* stream) {
+  if (B <= 0 || T <= 0 || V <= 0 || Lmax < 0 || ld < Lmax) return set_error("ctc loss: bad shape (B=%d T=%d V=%d Lmax=%d)", B, T, V, Lmax);
+  if (V > 64) return set_error("ctc loss: vocabulary of %d entries (at most 64)", V);
+  if (blank < 0 || blank >= V) return set_error("ctc loss: blank index %d outside the vocabulary", blank);
+  if (Lmax + 1 > 1024) return set_error("ctc loss: targets of up to %d labels (at most 1023)", Lmax);
+  if (!log_probs || (!targets && Lmax > 0) || !input_lengths || !target_lengths || !nll || !grad || !workspace)
+    return set_error("ctc loss: NULL pointer");
+  if (workspace_bytes < lmufft_ctc_loss_workspace_bytes(B, T, Lmax))
+    return set_error("ctc loss: workspace of %zu bytes needed, %zu given", lmufft_ctc_loss_workspace_bytes(B, T, Lmax), workspace_bytes);
+  if (((uintptr_t)workspace & 15) != 0) return set_error("ctc loss: the workspace must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int nw = ctc_loss_waves(Lmax);
+  const dim3 ggrid((T + kCtcGradFrames - 1) / kCtcGradFrames, B);
+  {
+    ProfScope ps("k_ctc_loss", st);
+#define CTC_LOSS(NWV, BOTH)                                                                                             \
+  do {                                                                                                                  \
+    hipLaunchKernelGGL((k_ctc_alpha_beta<NWV, BOTH>), dim3(B), dim3(64 * NWV * (BOTH ? 2 : 1)), 0, st, log_probs,       \
+                       targets, (long)ld, input_lengths, target_lengths, B, T, V, blank, nll, (double*)workspace);      \
+    hipLaunchKernelGGL(k_ctc_grad<NWV>, ggrid, dim3(64 * kCtcGradWaves), 0, st, log_probs, targets, (long)ld,           \
+                       input_lengths, target_lengths, B, T, V, blank, reduction_mean, zero_infinity, grad,              \
+                       (const double*)workspace);                                                                       \
+  } while (0)
+    if (nw <= 1) CTC_LOSS(1, true);
+    else if (nw <= 2) CTC_LOSS(2, true);
+    else if (nw <= 4) CTC_LOSS(4, true);
+    else if (nw <= 8) CTC_LOSS(8, true);
+    else CTC_LOSS(16, false);
+#undef CTC_LOSS
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error("launch of k_ctc_loss failed: %s", hipGetErrorString(e));
   return 0;
 }
 

@@ -100,3 +100,60 @@ def pack_targets(targets: torch.Tensor, target_lengths: torch.Tensor, total: Opt
     if total is None:
         total = int(offsets[B].item())
     return packed[:total], offsets
+
+
+class _CTCLoss(torch.autograd.Function):
+    """Loss and gradient come out of one kernel launch; the backward only scales the stored gradient."""
+
+    @staticmethod
+    def forward(ctx, log_probs, targets, input_lengths, target_lengths, blank, zero_infinity):
+        B, T, V = log_probs.shape
+        dev = log_probs.device
+        lp = log_probs.detach().float().contiguous()
+        Lmax = targets.shape[1]
+        nll = torch.empty(B, dtype=torch.float32, device=dev)
+        grad = torch.empty((B, T, V), dtype=torch.float32, device=dev)
+        ws = torch.empty(max(_lib.lib.lmufft_ctc_loss_workspace_bytes(B, T, Lmax), 16), dtype=torch.uint8, device=dev)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        with torch.cuda.device(dev):
+            rc = _lib.lib.lmufft_ctc_loss(p(lp), p(targets), targets.stride(0), p(input_lengths), p(target_lengths), B, T, V,
+                                          Lmax, blank, 1, 1 if zero_infinity else 0, p(nll), p(grad), p(ws), ws.numel(),
+                                          ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        _lib.check(rc, "lmufft_ctc_loss")
+        per = nll / target_lengths.clamp(min=1).to(torch.float32)
+        if zero_infinity:
+            per = torch.where(torch.isinf(per), torch.zeros_like(per), per)
+        ctx.save_for_backward(grad)
+        ctx.in_dtype = log_probs.dtype
+        return per.mean()
+
+    @staticmethod
+    def backward(ctx, gout):
+        (grad,) = ctx.saved_tensors
+        return (grad * gout).to(ctx.in_dtype), None, None, None, None, None
+
+
+def ctc_loss(log_probs: torch.Tensor, targets: torch.Tensor, input_lengths: torch.Tensor, target_lengths: torch.Tensor,
+             blank: int, zero_infinity: bool = True) -> torch.Tensor:
+    """Mean-reduced CTC loss of log_probs [batch, frames, vocab] (batch first, as the model produces them) against
+    the padded labels targets [batch, max_len]: what nn.CTCLoss(blank, reduction='mean', zero_infinity) returns for
+    log_probs.transpose(0, 1) in the reference (src/models/asr_model.py:105, 144-154), with autograd.  HIP kernel
+    k_ctc_loss (loss and gradient in one launch, no target packing, lengths stay on the device)."""
+    if not log_probs.is_cuda:
+        raise RuntimeError(f"ctc_loss: log_probs live on {log_probs.device}; this runs only as a HIP kernel on a GPU "
+                           "(there is no CPU fallback)")
+    if log_probs.dim() != 3 or targets.dim() != 2 or targets.shape[0] != log_probs.shape[0]:
+        raise RuntimeError(f"ctc_loss: expected log_probs [batch, frames, vocab] and targets [batch, max_len], got "
+                           f"{tuple(log_probs.shape)} and {tuple(targets.shape)}")
+    B, T, V = log_probs.shape
+    if V > 64:
+        raise RuntimeError(f"ctc_loss: vocabulary of {V} entries; the kernel holds at most 64")
+    dev = log_probs.device
+    t = targets.to(device=dev, dtype=torch.int64)
+    if t.shape[1] == 0:
+        t = torch.zeros((B, 1), dtype=torch.int64, device=dev)
+    if t.stride(1) != 1:
+        t = t.contiguous()
+    il = input_lengths.to(device=dev, dtype=torch.int32).contiguous()
+    tl = target_lengths.to(device=dev, dtype=torch.int32).contiguous()
+    return _CTCLoss.apply(log_probs, t, il, tl, int(blank), bool(zero_infinity))

@@ -288,9 +288,14 @@ class LMUASRModel(nn.Module):
     def compute_loss(self, log_probs: torch.Tensor, targets: torch.Tensor, input_lengths: torch.Tensor,
                      target_lengths: torch.Tensor, total_targets: Optional[int] = None) -> torch.Tensor:
         """CTC loss as the reference builds it (src/models/asr_model.py:130-156; nn.CTCLoss(blank=vocab_size-1,
-        reduction='mean', zero_infinity=True), :105), with the labels packed on the device."""
-        from .ctc import pack_targets
+        reduction='mean', zero_infinity=True), :105): this package's CTC kernel on the GPU, otherwise torch's loss on
+        labels packed on the device."""
+        from .ctc import ctc_loss, pack_targets
 
+        if log_probs.is_cuda and self.vocab_size <= 64 and log_probs.dtype == torch.float32:
+            _took("hip", "ctc_loss")  # loss and gradient in one kernel; the padded labels are read in place
+            return ctc_loss(log_probs, targets, input_lengths, target_lengths, self.vocab_size - 1, True)
+        _took("torch", "ctc_loss")
         packed, _ = pack_targets(targets, target_lengths, total_targets)
         return torch.nn.functional.ctc_loss(log_probs.transpose(0, 1), packed, input_lengths, target_lengths,
                                             blank=self.vocab_size - 1, reduction="mean", zero_infinity=True)

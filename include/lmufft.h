@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMUFFT_ABI_VERSION 11
+#define LMUFFT_ABI_VERSION 12
 
 /* element types of the activations (x, h, gh, gx, m) */
 #define LMUFFT_F32 0
@@ -304,6 +304,27 @@ int lmufft_linear_wgrad_bf16(const void* x, const void* dy, int64_t rows, int32_
 int lmufft_ctc_pack_targets(const int64_t* targets, const int32_t* target_lengths, int32_t B,
                             int32_t Lmax, int64_t ld, int64_t* packed, int32_t* offsets,
                             void* stream);
+
+/* ------------------------------------------------------------------------
+ * CTC loss with its gradient (training).  Replaces nn.CTCLoss(blank = vocab_size - 1, reduction = 'mean',
+ * zero_infinity = True) as LMUASRModel.compute_loss calls it, src/models/asr_model.py:105, 130-156, and its
+ * backward:
+ *   log_probs [B][T][V] f32 (V <= 64), targets [B][ld] int64 (utterance b holds target_lengths[b] <= Lmax labels,
+ *   no packing needed), input_lengths [B];
+ *   nll [B]: -log p(targets | log_probs) per utterance (+inf when nothing aligns);
+ *   grad [B][T][V]: the gradient torch's ctc_loss returns for log_probs (the gradient through the log-softmax
+ *   that produced them), times 1 / (B max(L_b, 1)) when reduction_mean != 0; rows t >= input_lengths[b] are zero;
+ *   with zero_infinity an utterance whose nll is infinite gets a zero gradient.
+ * The loss of the 'mean' reduction is mean_b(nll_b / max(L_b, 1)), infinite terms replaced by 0 under
+ * zero_infinity; multiply grad by the upstream gradient of the loss.
+ * The forward/backward recursions accumulate in double (their values grow like T log V); the workspace
+ * (16-byte aligned, lmufft_ctc_loss_workspace_bytes) holds the forward variables of every frame.
+ * ---------------------------------------------------------------------- */
+size_t lmufft_ctc_loss_workspace_bytes(int32_t B, int32_t T, int32_t Lmax);
+int lmufft_ctc_loss(const float* log_probs, const int64_t* targets, int64_t ld, const int32_t* input_lengths,
+                    const int32_t* target_lengths, int32_t B, int32_t T, int32_t V, int32_t Lmax, int32_t blank,
+                    int reduction_mean, int zero_infinity, float* nll, float* grad, void* workspace,
+                    size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Optimizer step of the training loop on flat fp32 arenas.  Replaces the per-parameter

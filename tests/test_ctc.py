@@ -120,3 +120,80 @@ def test_ctc_head_kernel_routes(B, T, Hd, V, dtype):
     lp = head(enc).cpu().numpy()
     np.testing.assert_allclose(lp, ref_lp, rtol=1e-4, atol=5e-5)
     assert head.decode(enc, lengths.to(dev)) == co.greedy_decode(ref_lp, lengths.numpy())
+
+
+def _ctc_case(seed, B, T, V, Lmax, full_lengths=False):
+    g = torch.Generator().manual_seed(seed)
+    lp = torch.randn(B, T, V, generator=g).log_softmax(-1)
+    targets = torch.randint(0, V - 1, (B, max(Lmax, 1)), generator=g)
+    tl = torch.randint(0 if not full_lengths else Lmax, Lmax + 1, (B,), generator=g)
+    il = torch.randint(max(1, T // 2), T + 1, (B,), generator=g)
+    il[0], tl[0] = T, Lmax
+    return lp, targets, il, tl
+
+
+def test_ctc_loss_oracle_matches_torch():
+    """The alpha-beta restatement against torch's CTC loss and autograd on the CPU: the library the reference calls
+    (nn.CTCLoss(blank=V-1, reduction='mean', zero_infinity=True), src/models/asr_model.py:105)."""
+    for seed, (B, T, V, Lmax) in enumerate([(3, 12, 6, 4), (4, 30, 34, 9), (2, 8, 5, 6)]):
+        lp, targets, il, tl = _ctc_case(seed, B, T, V, Lmax)
+        if seed == 2:
+            il[1], tl[1] = 3, 6  # no valid alignment: zero_infinity turns the term and its gradient into 0
+        x = lp.double().clone().requires_grad_(True)
+        packed = torch.cat([targets[i, : int(tl[i])] for i in range(B)])
+        ref = torch.nn.functional.ctc_loss(x.transpose(0, 1), packed, il, tl, blank=V - 1, reduction="mean",
+                                           zero_infinity=True)
+        ref.backward()
+        loss, grad = co.ctc_loss_and_grad(lp.double().numpy(), targets.numpy(), il.numpy(), tl.numpy(), V - 1, True)
+        want = float(ref.detach())
+        assert abs(loss - want) <= 1e-10 * max(1.0, abs(want))
+        np.testing.assert_allclose(grad, x.grad.numpy(), rtol=1e-8, atol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,V,Lmax", [(1, 1, 3, 0), (3, 12, 6, 4), (64, 400, 34, 60), (5, 50, 34, 63), (4, 300, 34, 64),
+                                       (2, 120, 10, 200)])
+def test_ctc_loss_kernel_matches_oracle(B, T, V, Lmax):
+    """k_ctc_loss through the C ABI (loss and gradient in one launch) against the oracle: fp32 log-domain recursions
+    over up to 400 frames: loss rtol 1e-5, gradient |err| <= 1e-4 * max|grad| + 1e-7."""
+    from asr_amd.ctc import ctc_loss
+
+    dev = torch.device("cuda:0")
+    lp, targets, il, tl = _ctc_case(B * 7 + T, B, T, V, Lmax)
+    if B >= 3:
+        il[1], tl[1] = max(1, Lmax // 2), Lmax        # too few frames: infinite term, zeroed
+        targets[2, : max(Lmax, 1)] = targets[2, 0]    # repeated labels need blanks in between
+    x = lp.to(dev).requires_grad_(True)
+    loss = ctc_loss(x, targets.to(dev), il.to(dev), tl.to(dev), V - 1, True)
+    (loss * 3.0).backward()
+    want, grad = co.ctc_loss_and_grad(lp.double().numpy(), targets.numpy(), il.numpy(), tl.numpy(), V - 1, True)
+    assert abs(float(loss.detach()) - want) <= 1e-5 * max(1.0, abs(want)), (float(loss.detach()), want)
+    got = x.grad.cpu().double().numpy() / 3.0
+    assert np.abs(got - grad).max() <= 1e-4 * np.abs(grad).max() + 1e-7
+    # rows past an utterance's end carry no gradient; rows inside sum to zero (gradient through the log-softmax)
+    for b in range(B):
+        assert (got[b, int(il[b]):] == 0).all()
+    assert np.abs(got.sum(-1)).max() <= 1e-5 * np.abs(grad).max() + 1e-7
+
+
+@pytest.mark.gpu
+def test_ctc_loss_kernel_matches_torch_on_the_gpu_and_is_deterministic():
+    from asr_amd.ctc import ctc_loss
+
+    dev = torch.device("cuda:0")
+    lp, targets, il, tl = _ctc_case(99, 16, 200, 34, 40, full_lengths=False)
+    tl = tl.clamp(min=1)
+    x = lp.to(dev).requires_grad_(True)
+    a = ctc_loss(x, targets.to(dev), il.to(dev), tl.to(dev), 33, True)
+    a.backward()
+    y = lp.to(dev).requires_grad_(True)
+    b = torch.nn.functional.ctc_loss(y.transpose(0, 1), targets.to(dev), il, tl, blank=33, reduction="mean", zero_infinity=True)
+    b.backward()
+    assert abs(float(a.detach()) - float(b.detach())) <= 1e-5 * abs(float(b.detach()))
+    # torch's CUDA kernel runs the recursion in fp32 (about 1e-3 of relative error in a posterior after 200 frames);
+    # the tight bound is the float64 oracle's, in test_ctc_loss_kernel_matches_oracle
+    assert torch.allclose(x.grad, y.grad, rtol=1e-3, atol=1e-3 * float(y.grad.abs().max()))
+    g1 = x.grad.clone()
+    x.grad = None
+    ctc_loss(x, targets.to(dev), il.to(dev), tl.to(dev), 33, True).backward()
+    assert torch.equal(g1, x.grad)

@@ -22,8 +22,8 @@ SHAPES = [
     (2, 16, 8, 16),      # one partial tile
     (3, 33, 32, 40),     # two tiles, the first with one frame; ldH > T
     (5, 100, 64, 100),   # the reference's smoke length
-    (2, 200, 192, 200),  # BASELINE's post-downsample length
-    (4, 400, 192, 400),  # BASELINE's training shape
+    (2, 200, 192, 200),  # the benchmark's post-downsample length
+    (4, 400, 192, 400),  # the benchmark's training shape
     (2, 416, 96, 416),   # the short-sequence kernels' limit
     (3, 400, 128, 400),  # channel count that is not a multiple of the 96-channel block
     (2, 300, 72, 320),   # channels a multiple of 8 only
