@@ -118,6 +118,57 @@ class _AttentionTrain(torch.autograd.Function):
         return dq, dkk, dv, None, None, None, None, None
 
 
+class _AttentionTrainPacked(torch.autograd.Function):
+    """_AttentionTrain on qkv [B, T, 3 * heads * d_k], the output of ONE projection over the concatenated weights
+    (q | k | v as column blocks); the backward writes dq | dk | dv as the column blocks of one tensor, the
+    projection's output gradient."""
+
+    @staticmethod
+    def forward(ctx, qkv, lengths, num_heads, p_drop, seed0, seed1):
+        B, T, C3 = qkv.shape
+        C = C3 // 3
+        dk = C // num_heads
+        qkv = qkv.contiguous()
+        es = qkv.element_size()
+        out = torch.empty((B, T, C), dtype=qkv.dtype, device=qkv.device)
+        stats = torch.empty((B, num_heads, T, 2), dtype=torch.float32, device=qkv.device)
+        base = qkv.data_ptr()
+        p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        with torch.cuda.device(qkv.device):
+            rc = _lib.lib.lmufft_attention_fwd_train(
+                ctypes.c_void_p(base), ctypes.c_void_p(base + C * es), ctypes.c_void_p(base + 2 * C * es),
+                _DTYPES[qkv.dtype], C3, p(lengths), B, T, num_heads, dk, float(p_drop), seed0, seed1, p(out), p(stats),
+                ctypes.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream))
+        _lib.check(rc, "lmufft_attention_fwd_train")
+        ctx.save_for_backward(qkv, out, stats, lengths)
+        ctx.conf = (num_heads, float(p_drop), seed0, seed1)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, stats, lengths = ctx.saved_tensors
+        num_heads, p_drop, seed0, seed1 = ctx.conf
+        B, T, C3 = qkv.shape
+        C = C3 // 3
+        dk = C // num_heads
+        es = qkv.element_size()
+        dout = dout.contiguous()
+        if dout.dtype != qkv.dtype:
+            dout = dout.to(qkv.dtype)
+        dqkv = torch.empty_like(qkv)
+        dsum = torch.empty((B, num_heads, T), dtype=torch.float32, device=qkv.device)
+        base, gbase = qkv.data_ptr(), dqkv.data_ptr()
+        p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        with torch.cuda.device(qkv.device):
+            rc = _lib.lib.lmufft_attention_bwd(
+                ctypes.c_void_p(base), ctypes.c_void_p(base + C * es), ctypes.c_void_p(base + 2 * C * es), p(out), p(dout),
+                p(stats), _DTYPES[qkv.dtype], C3, p(lengths), B, T, num_heads, dk, p_drop, seed0, seed1,
+                ctypes.c_void_p(gbase), ctypes.c_void_p(gbase + C * es), ctypes.c_void_p(gbase + 2 * C * es), C3, p(dsum),
+                ctypes.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream))
+        _lib.check(rc, "lmufft_attention_bwd")
+        return dqkv, None, None, None, None, None
+
+
 _dropout_calls = 0
 
 
@@ -151,3 +202,31 @@ def masked_attention_train(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, nu
         seeds = (torch.initial_seed() & 0xFFFFFFFF, _dropout_calls & 0xFFFFFFFF)
     return _AttentionTrain.apply(q, k, v, lengths, num_heads, p_drop, int(seeds[0]) & 0xFFFFFFFF,
                                  int(seeds[1]) & 0xFFFFFFFF)
+
+
+def masked_attention_train_packed(qkv: torch.Tensor, num_heads: int, lengths: Optional[torch.Tensor] = None,
+                                  p_drop: float = 0.0, seeds=None) -> torch.Tensor:
+    """masked_attention_train with q, k, v given as the column blocks of one tensor [batch, frames, 3 * channels]
+    (w_q, w_k, w_v of src/models/lmu_encoder.py:41-43, 68-70 applied as a single GEMM over the concatenated
+    weights); the gradient comes back as one tensor of the same layout.  Seeds as in masked_attention_train."""
+    global _dropout_calls
+    if not qkv.is_cuda:
+        raise RuntimeError(f"masked_attention_train_packed: `qkv` lives on {qkv.device}; the kernels run only on a GPU "
+                           "(there is no CPU fallback)")
+    if qkv.dim() != 3 or qkv.shape[2] % 3:
+        raise RuntimeError(f"masked_attention_train_packed: qkv must be [batch, frames, 3 * channels], got {tuple(qkv.shape)}")
+    if qkv.dtype not in _DTYPES:
+        raise RuntimeError(f"masked_attention_train_packed: dtype {qkv.dtype}; supported: float32, bfloat16")
+    C = qkv.shape[2] // 3
+    if C % num_heads or C // num_heads not in SUPPORTED_HEAD_WIDTHS:
+        raise RuntimeError(f"masked_attention_train_packed: {C} channels over {num_heads} heads; head widths supported: "
+                           f"{SUPPORTED_HEAD_WIDTHS}")
+    if not 0.0 <= p_drop < 1.0:
+        raise ValueError(f"dropout probability has to be in [0, 1), got {p_drop}")
+    if lengths is not None:
+        lengths = lengths.to(device=qkv.device, dtype=torch.int32).contiguous()
+    if seeds is None:
+        _dropout_calls += 1
+        seeds = (torch.initial_seed() & 0xFFFFFFFF, _dropout_calls & 0xFFFFFFFF)
+    return _AttentionTrainPacked.apply(qkv, lengths, num_heads, p_drop, int(seeds[0]) & 0xFFFFFFFF,
+                                       int(seeds[1]) & 0xFFFFFFFF)

@@ -20,7 +20,8 @@ from typing import List, Optional, Tuple
 import torch
 from torch import nn
 
-from .attention import SUPPORTED_HEAD_WIDTHS, masked_attention, masked_attention_packed, masked_attention_train
+from .attention import (SUPPORTED_HEAD_WIDTHS, masked_attention, masked_attention_packed, masked_attention_train,
+                        masked_attention_train_packed)
 from .layernorm import MAX_WIDTH as _LN_MAX_WIDTH, add_layer_norm, add_layer_norm_train
 from .linear import linear_bf16, linear_train, supported as linear_supported, train_supported as linear_train_supported
 from .ctc import CTCDecoder
@@ -178,8 +179,18 @@ class _MultiHeadAttention(nn.Module):
             # training: HIP forward with dropout and HIP backward behind an autograd function; the projections
             # and the layer norm stay torch ops (autograd)
             _took("hip", "attention")
-            q, k, v = _linear(self.w_q, x), _linear(self.w_k, x), _linear(self.w_v, x)
-            ctx = masked_attention_train(q, k, v, self.num_heads, lengths, self.dropout.p if self.training else 0.0)
+            p_drop = self.dropout.p if self.training else 0.0
+            qkv = (self.w_q, self.w_k, self.w_v)
+            if (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+                    and all(l.bias is not None for l in qkv) and linear_train_supported(x, self.w_q.weight)):
+                # one GEMM for the three projections in both directions: x is cast and read once, the three input
+                # gradients arrive summed; the attention kernels read and write column blocks of its output
+                _took("hip", "qkv_projection")
+                packed = linear_train(x, torch.cat([l.weight for l in qkv]), torch.cat([l.bias for l in qkv]))
+                ctx = masked_attention_train_packed(packed, self.num_heads, lengths, p_drop)
+            else:
+                q, k, v = _linear(self.w_q, x), _linear(self.w_k, x), _linear(self.w_v, x)
+                ctx = masked_attention_train(q, k, v, self.num_heads, lengths, p_drop)
             return _layer_norm(self.layer_norm, _linear(self.w_o, ctx), x, out_dtype)
         _took("torch", "attention")
         split = lambda t: t.view(B, T, self.num_heads, self.d_k).transpose(1, 2)  # noqa: E731
@@ -279,10 +290,11 @@ class LMUASRModel(nn.Module):
 
     def log_probs_for_training(self, spectrograms: torch.Tensor, input_lengths: Optional[torch.Tensor] = None):
         """Log-probabilities with an autograd graph (the reference's LMUASRModel.forward in training,
-        src/models/asr_model.py:110-128).  The LMUFFT layers run their HIP forward and backward; attention, layer
-        norms, projections and the head are torch ops here (their HIP kernels are inference-only)."""
+        src/models/asr_model.py:110-128).  Under bf16 autocast on the GPU the LMUFFT layers, attention, layer norms
+        and every Linear (the vocabulary projection included) run this package's forward and backward kernels;
+        dropout after the layer norms, residual adds and the log-softmax are torch ops."""
         encoded, _ = self.encoder(spectrograms, input_lengths)
-        logits = torch.nn.functional.linear(encoded, self.decoder.ctc_projection.weight, self.decoder.ctc_projection.bias)
+        logits = _linear(self.decoder.ctc_projection, encoded)
         return torch.log_softmax(logits.float(), dim=-1)
 
     def compute_loss(self, log_probs: torch.Tensor, targets: torch.Tensor, input_lengths: torch.Tensor,

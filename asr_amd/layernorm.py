@@ -12,6 +12,7 @@ from typing import Optional
 import torch
 
 from . import _lib
+from .parallel import adopt, grad_slot
 
 _DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
 MAX_WIDTH = 1024
@@ -60,9 +61,11 @@ def add_layer_norm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: to
 
 
 def add_layer_norm_backward(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor, dy: torch.Tensor,
-                            eps: float = 1e-5):
+                            eps: float = 1e-5, out_weight: Optional[torch.Tensor] = None,
+                            out_bias: Optional[torch.Tensor] = None):
     """(dx, dresidual or None, dweight, dbias) of add_layer_norm: dx / dresidual carry the same values in the dtype
-    of x / residual (one tensor when the dtypes agree); dweight, dbias float32.  HIP kernel k_layernorm_bwd."""
+    of x / residual (one tensor when the dtypes agree); dweight, dbias float32, written into `out_weight` /
+    `out_bias` (contiguous float32 [C]) when given.  HIP kernel k_layernorm_bwd."""
     for name, t in (("x", x), ("residual", residual), ("weight", weight), ("dy", dy)):
         if t is not None and not t.is_cuda:
             raise RuntimeError(f"add_layer_norm_backward: `{name}` lives on {t.device}; the kernel runs only on a GPU "
@@ -79,8 +82,11 @@ def add_layer_norm_backward(x: torch.Tensor, residual: Optional[torch.Tensor], w
     dres = None
     if residual is not None and residual.dtype != x.dtype:
         dres = torch.empty_like(residual)
-    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
-    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    for name, t in (("out_weight", out_weight), ("out_bias", out_bias)):
+        if t is not None and (t.shape != (C,) or t.dtype != torch.float32 or not t.is_contiguous() or t.device != x.device):
+            raise RuntimeError(f"add_layer_norm_backward: `{name}` must be a contiguous float32 tensor [{C}] on {x.device}")
+    dgamma = out_weight if out_weight is not None else torch.empty(C, dtype=torch.float32, device=x.device)
+    dbeta = out_bias if out_bias is not None else torch.empty(C, dtype=torch.float32, device=x.device)
     ws = torch.empty(_lib.lib.lmufft_layernorm_bwd_workspace_bytes(C), dtype=torch.uint8, device=x.device)
     rows = x.numel() // C
     p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())  # noqa: E731
@@ -100,14 +106,19 @@ class _AddLayerNormTrain(torch.autograd.Function):
     def forward(ctx, x, residual, weight, bias, eps, out_dtype):
         ctx.save_for_backward(x, residual, weight)
         ctx.eps = eps
+        ctx.params = (weight, bias)
         return add_layer_norm(x, residual, weight, bias, eps, out_dtype)
 
     @staticmethod
     def backward(ctx, dy):
         x, residual, weight = ctx.saved_tensors
-        dx, dres, dgamma, dbeta = add_layer_norm_backward(x, residual, weight, dy, ctx.eps)
+        # parameters of a GradBuckets: the kernel writes into the bucket and autograd adopts the slices as .grad
+        slot_w, slot_b = grad_slot(ctx.params[0]), grad_slot(ctx.params[1])
+        dx, dres, dgamma, dbeta = add_layer_norm_backward(x, residual, weight, dy, ctx.eps, slot_w, slot_b)
+        dgamma = adopt(dgamma) if slot_w is not None else dgamma.to(weight.dtype)
+        dbeta = adopt(dbeta) if slot_b is not None else dbeta.to(weight.dtype)
         return (dx if ctx.needs_input_grad[0] else None, dres if ctx.needs_input_grad[1] else None,
-                dgamma.to(weight.dtype), dbeta.to(weight.dtype), None, None)
+                dgamma, dbeta, None, None)
 
 
 def add_layer_norm_train(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor, bias: torch.Tensor,

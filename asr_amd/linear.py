@@ -13,6 +13,7 @@ from typing import Optional
 import torch
 
 from . import _lib
+from .parallel import adopt, grad_slot
 
 _DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
 FUSED_LAYER_NORM_MAX_WIDTH = 384
@@ -101,10 +102,12 @@ def linear_add_layer_norm_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Opti
     return (y, proj) if return_projection else y
 
 
-def linear_weight_grad_bf16(x: torch.Tensor, dy: torch.Tensor, want_bias: bool = True):
+def linear_weight_grad_bf16(x: torch.Tensor, dy: torch.Tensor, want_bias: bool = True,
+                            out_weight: Optional[torch.Tensor] = None, out_bias: Optional[torch.Tensor] = None):
     """(dW [N, K] fp32, db [N] fp32 or None) of y = x W^T + b from x [..., K] and dy [..., N], both bf16:
     dW = sum over rows of dy^T x, db = sum over rows of dy (HIP kernel k_wgrad_bf16, fp32 accumulation in a
-    fixed order).  K and N must be multiples of 8."""
+    fixed order).  K and N must be multiples of 8.  `out_weight` / `out_bias`: contiguous float32 tensors to write
+    into (e.g. slices of a gradient bucket) instead of new ones."""
     for name, t in (("x", x), ("dy", dy)):
         if not t.is_cuda:
             raise RuntimeError(f"linear_weight_grad_bf16: `{name}` lives on {t.device}; the kernel runs only on a GPU "
@@ -117,8 +120,13 @@ def linear_weight_grad_bf16(x: torch.Tensor, dy: torch.Tensor, want_bias: bool =
         raise RuntimeError(f"linear_weight_grad_bf16: x {tuple(x.shape)} and dy {tuple(dy.shape)} must share their rows "
                            "and have widths that are multiples of 8")
     x, dy = x.detach().contiguous(), dy.detach().contiguous()
-    dW = torch.empty((N, K), dtype=torch.float32, device=x.device)
-    db = torch.empty((N,), dtype=torch.float32, device=x.device) if want_bias else None
+    for name, t, shape in (("out_weight", out_weight, (N, K)), ("out_bias", out_bias, (N,))):
+        if t is not None and (t.shape != shape or t.dtype != torch.float32 or not t.is_contiguous() or t.device != x.device):
+            raise RuntimeError(f"linear_weight_grad_bf16: `{name}` must be a contiguous float32 tensor {shape} on {x.device}")
+    dW = out_weight if out_weight is not None else torch.empty((N, K), dtype=torch.float32, device=x.device)
+    db = None
+    if want_bias:
+        db = out_bias if out_bias is not None else torch.empty((N,), dtype=torch.float32, device=x.device)
     ws = torch.empty(_lib.lib.lmufft_linear_wgrad_workspace_bytes(rows, K, N), dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
         rc = _lib.lib.lmufft_linear_wgrad_bf16(_ptr(x), _ptr(dy), rows, K, N, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(),
@@ -129,40 +137,64 @@ def linear_weight_grad_bf16(x: torch.Tensor, dy: torch.Tensor, want_bias: bool =
 
 class _LinearTrain(torch.autograd.Function):
     """nn.Linear under bf16 autocast with this package's kernels in both directions: y = bf16(x) bf16(W)^T + b
-    (fp32 accumulation, one rounding); dx = dy bf16(W) in bf16; dW, db in fp32 straight from bf16 x and dy."""
+    (fp32 accumulation, one rounding); dx = dy bf16(W) in bf16; dW, db in fp32 straight from bf16 x and dy.
+    An output width that is not a multiple of 8 (the vocabulary projection) runs on zero rows of padding."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
+        N = weight.shape[0]
+        pad = -N % 8
         xb = x.to(torch.bfloat16)
         w16 = weight.detach().to(torch.bfloat16)
         b32 = None if bias is None else bias.detach().to(torch.bfloat16).float()
+        if pad:
+            w16 = torch.nn.functional.pad(w16, (0, 0, 0, pad))
+            b32 = None if b32 is None else torch.nn.functional.pad(b32, (0, pad))
         ctx.save_for_backward(xb, w16)
         ctx.has_bias = bias is not None
         ctx.x_dtype = x.dtype
-        return linear_bf16(xb, w16, b32)
+        ctx.params = (weight, bias)
+        ctx.pad = pad
+        y = linear_bf16(xb, w16, b32)
+        return y[..., :N] if pad else y
 
     @staticmethod
     def backward(ctx, dy):
         xb, w16 = ctx.saved_tensors
-        dyb = dy.to(torch.bfloat16).contiguous()
+        dyb = dy.to(torch.bfloat16)
+        if ctx.pad:
+            dyb = torch.nn.functional.pad(dyb, (0, ctx.pad))
+        dyb = dyb.contiguous()
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
             dx = linear_bf16(dyb, w16.t().contiguous()).to(ctx.x_dtype)   # dy W: the same kernel on W^T
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dW, db = linear_weight_grad_bf16(xb, dyb, ctx.has_bias)
+            # parameters of a GradBuckets: the kernel writes into the bucket and autograd adopts the slice as .grad
+            weight, bias = ctx.params
+            slot_w = None if ctx.pad else grad_slot(weight)
+            slot_b = grad_slot(bias) if ctx.has_bias and not ctx.pad else None
+            dW, db = linear_weight_grad_bf16(xb, dyb, ctx.has_bias, slot_w, slot_b)
+            if slot_w is not None:
+                dW = adopt(dW)
+            if slot_b is not None:
+                db = adopt(db)
+            if ctx.pad:
+                n = weight.shape[0]
+                dW = dW[:n]
+                db = None if db is None else db[:n]
         return dx, dW, db
 
 
 def train_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
-    """True when linear_train can take this call (GPU, fp32 master weight, widths multiples of 8)."""
+    """True when linear_train can take this call (GPU, fp32 master weight, input width a multiple of 8)."""
     return (x.is_cuda and weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 2
             and x.dtype in (torch.float32, torch.bfloat16) and x.shape[-1] == weight.shape[1]
-            and weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0)
+            and weight.shape[1] % 8 == 0)
 
 
 def linear_train(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
     """torch.nn.functional.linear(x, weight, bias) as bf16 autocast computes it, with autograd, on HIP kernels."""
     if not train_supported(x, weight):
-        raise RuntimeError("linear_train: needs GPU tensors, a float32 weight [N, K] with N and K multiples of 8 and a "
+        raise RuntimeError("linear_train: needs GPU tensors, a float32 weight [N, K] with K a multiple of 8 and a "
                            "float32 or bfloat16 input [..., K]")
     return _LinearTrain.apply(x, weight, bias)

@@ -35,6 +35,24 @@ import torch.distributed as dist
 _ALIGN = 64  # every gradient starts on a 256-byte boundary of its bucket (vector stores in the kernels)
 
 
+def grad_slot(p):
+    """The slice of a gradient bucket a backward may write `p`'s gradient into, or None: `p` belongs to a
+    GradBuckets, is float32 and no backward has asked for the slice in this step.  Return `adopt(slot)` as the gradient:
+    a fresh tensor on the slice's memory, which autograd takes over as `p.grad` without copying (it copies when
+    other references to the tensor object exist, which is why the slice itself must not be returned)."""
+    v = getattr(p, "_grad_view", None)
+    if v is None or p.grad is not None or not getattr(p, "_grad_view_free", False) or v.dtype != torch.float32:
+        return None
+    # handed out once per step: autograd sums the gradients of a parameter used several times before it
+    # touches `.grad`, so a second writer into the same slice would corrupt the first one's result
+    p._grad_view_free = False
+    return v
+
+
+def adopt(slot: torch.Tensor) -> torch.Tensor:
+    return slot.view(slot.shape)
+
+
 def _group_params(grp):
     module = grp if isinstance(grp, torch.nn.Module) else None
     params = [p for p in (module.parameters() if module is not None else grp) if p.requires_grad]
@@ -51,7 +69,11 @@ class GradBuckets:
 
     For an LMUFFT module with fp32 parameters the bucket also becomes the layer's gradient sink:
     its backward kernels write the gradients into the flat buffer directly.  Every other parameter
-    reaches the buffer through autograd's accumulation into `.grad` (a view of the buffer).
+    starts a step with `.grad = None` and carries its slice of the buffer as `p._grad_view`: a backward
+    that knows of it (asr_amd.linear, asr_amd.layernorm) writes the gradient there and returns the
+    view, which autograd adopts as `.grad` without a copy; any other gradient is copied into the
+    slice when it arrives.  Further gradients for the same parameter in the same step are added in
+    place by autograd.  No slice is cleared between steps: the first arrival overwrites.
     Every parameter of a bucket must receive a gradient in every step (as with
     DistributedDataParallel without find_unused_parameters): finish() raises otherwise.
     With overlap=True a step has exactly ONE backward: a gradient that arrives for a bucket whose
@@ -74,7 +96,6 @@ class GradBuckets:
         self._params: List[List[torch.nn.Parameter]] = []
         self._views: List[List[torch.Tensor]] = []
         self._sinks: List[list] = []        # per bucket: the gradient sinks of its LMUFFT members
-        self._plain: List[List[torch.Tensor]] = []  # per bucket: views fed by autograd accumulation
         self._pending: List[int] = []
         self._launched: List[bool] = []
         self._handles = []
@@ -120,7 +141,7 @@ class GradBuckets:
                 flat = torch.zeros(n, dtype=mems[0][1][0].dtype, device=mems[0][1][0].device)
             bi = len(self.buckets)
             self.buckets.append(flat)
-            all_params, all_views, sinks, plain = [], [], [], []
+            all_params, all_views, sinks = [], [], []
             off = 0
             for module, params, _ in mems:
                 views = []
@@ -134,17 +155,17 @@ class GradBuckets:
                     module.grad_sink = sink
                     self._sunk_modules.append(module)
                     sinks.append(sink)
-                else:
-                    plain.extend(views)
                 for p, v in zip(params, views):
-                    p.grad = None if sink is not None else v
+                    p.grad = None
+                    if sink is None:
+                        p._grad_view = v
+                        p._grad_view_free = True
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi, v, sink)))
                 all_params.extend(params)
                 all_views.extend(views)
             self._params.append(all_params)
             self._views.append(all_views)
             self._sinks.append(sinks)
-            self._plain.append(plain)
             self._pending.append(len(all_params))
             self._launched.append(False)
 
@@ -228,15 +249,15 @@ class GradBuckets:
             self._deferred -= 1
 
     def zero_grad(self) -> None:
-        """Start a step: re-arm the buckets.  Parameters fed by a gradient sink need no clearing
-        (their first backward overwrites); the others are zeroed in place."""
+        """Start a step: re-arm the buckets.  Nothing is cleared: every parameter's first gradient of the
+        step overwrites its slice (`.grad` is None until then)."""
         for bi in range(len(self.buckets)):
             for sink in self._sinks[bi]:
                 sink.filled = False
-                for p in sink.params:
-                    p.grad = None
-            for v in self._plain[bi]:
-                v.zero_()
+            for p in self._params[bi]:
+                p.grad = None
+                if hasattr(p, "_grad_view"):
+                    p._grad_view_free = True
             self._pending[bi] = len(self._params[bi])
             self._launched[bi] = False
         self._handles = []
@@ -268,7 +289,7 @@ class GradBuckets:
         self._handles = []
 
     # -- HIP graph replay -------------------------------------------------------------------
-    def _capture(self, fn: Callable, first: bool, pool=None):
+    def _capture(self, fn: Callable, pool=None):
         graph = torch.cuda.CUDAGraph()
         self._ready_log = []
         self._capturing = True
@@ -277,12 +298,8 @@ class GradBuckets:
             # watchdog) neither break nor join the capture.  The segments share one memory pool:
             # a later segment reads tensors an earlier one produced.
             with torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"):
-                if first:
-                    # parameters without a sink receive `grad += g` from autograd: the graph itself
-                    # must clear them, or every replay would add onto the previous step's result
-                    for views in self._plain:
-                        for v in views:
-                            v.zero_()
+                # every parameter enters the capture with `.grad = None` (capture_pipeline re-arms the
+                # step first), so the captured kernels overwrite the slices and a replay needs no clearing
                 fn()
         finally:
             self._capturing = False
@@ -308,7 +325,7 @@ class GradBuckets:
         self.zero_grad()
         graphs, ready = [], []
         for i, fn in enumerate(fns):
-            g, r = self._capture(fn, first=(i == 0), pool=graphs[0].pool() if graphs else None)
+            g, r = self._capture(fn, pool=graphs[0].pool() if graphs else None)
             graphs.append(g)
             ready.append(r)
         done = sorted(bi for r in ready for bi in r)
@@ -338,3 +355,7 @@ class GradBuckets:
         for m in self._sunk_modules:
             m.grad_sink = None
         self._sunk_modules = []
+        for ps in self._params:
+            for p in ps:
+                if hasattr(p, "_grad_view"):
+                    del p._grad_view, p._grad_view_free

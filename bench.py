@@ -59,6 +59,8 @@ def parse_args():
     ap.add_argument("--no-overlap", action="store_true",
                     help="exchange all gradients in one all-reduce after the backward instead of per bucket "
                          "behind the remaining backward segments")
+    ap.add_argument("--torch-profile", action="store_true",
+                    help="c2_full: also print the GPU time per kernel of a few steps (torch profiler) to stderr")
     ap.add_argument("--bf16-stream", action="store_true",
                     help="c2_full: layer norms write bf16 instead of autocast's fp32 (one more bf16 rounding per block)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -282,9 +284,10 @@ def bench_full_step(args, dev, rank, world):
     """The reference's whole training step at its single-GPU configuration: mel-shaped input -> 3-layer encoder
     (attention, LMUFFT, layer norm, dropout 0.1) -> CTC head and loss -> backward -> clip 10 -> AdamW -> scheduler
     (configs/base_config.yaml:3-15, 29-36; src/training/distributed.py:139-234), bf16 autocast.  This package's
-    kernels run the LMUFFT layers, the gradient norm / clipping / AdamW step and the target packing; attention,
-    layer norms, projections, dropout and the CTC loss are torch ops (their HIP kernels here are inference-only),
-    so this line measures the model with the hot path swapped in, not a roofline."""
+    kernels run the LMUFFT layers, attention, the Linear layers and layer norms (forward and backward), the CTC loss
+    with its gradient and the gradient norm / clipping / AdamW step; dropout after the layer norms, residual adds,
+    dtype casts, the vocabulary projection and log-softmax are torch ops.  This line measures the model with the
+    hot path swapped in, not a roofline."""
     import torch
     import torch.distributed as dist
 
@@ -361,6 +364,17 @@ def bench_full_step(args, dev, rank, world):
     if rank == 0:
         _lib.profile_enable(False)
         per_kernel = read_profile(_lib, psteps)
+    if rank == 0 and getattr(args, "torch_profile", False):
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(psteps):
+                step()
+            torch.cuda.synchronize(dev)
+        rows = sorted(prof.key_averages(), key=lambda r: -r.self_device_time_total)
+        tot = sum(r.self_device_time_total for r in rows)
+        print(f"[torch profiler] GPU time {tot / psteps / 1e3:.3f} ms/step over {psteps} steps", file=sys.stderr)
+        for r in rows[:45]:
+            print(f"{r.self_device_time_total / psteps:9.1f} us/step  x{r.count / psteps:6.1f}  {r.key[:120]}", file=sys.stderr)
     if rank != 0:
         return None
     hip_ms = sum(v["total_ms_per_step"] for v in per_kernel.values())
@@ -374,8 +388,10 @@ def bench_full_step(args, dev, rank, world):
                                f"seq_len {T}), batch {B} per GPU, bf16 autocast: forward + CTC loss + backward + clip 10 + "
                                "AdamW(1.5e-3, wd 0.01) + warm-up scheduler, eager launches",
                    "batch_per_gpu": B, "frames": T, "parallelism": f"dp{world}", "world_size": world,
-                   "hip_kernels": "LMUFFT forward/backward, gradient norm + clip + AdamW, CTC target packing",
-                   "torch_ops": "attention, layer norms, Linear projections, dropout, log-softmax, CTC loss",
+                   "hip_kernels": "LMUFFT, attention, Linear, layer norm (forward and backward), CTC loss + gradient, "
+                                  "gradient norm + clip + AdamW",
+                   "torch_ops": "dropout after the layer norms, residual adds, dtype casts, vocabulary projection, "
+                                "log-softmax",
                    "activation_stream": "bf16 between blocks" if args.bf16_stream else "fp32 between blocks (autocast)",
                    "gradient_buckets": len(buckets.buckets)},
         "roofline": None,

@@ -74,6 +74,34 @@ def test_forward_and_backward_match_oracle(B, T, H, dk, lengths, p, dtype):
                               atol=2e-2 if dtype == torch.bfloat16 else 1e-6)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_packed_form_is_the_same_computation(dtype):
+    """q | k | v as column blocks of one tensor (one projection GEMM in front): context and gradients are bitwise
+    those of the three-tensor form, the gradient arrives as one tensor of the packed layout."""
+    from asr_amd.attention import masked_attention_train, masked_attention_train_packed
+
+    dev = _dev()
+    B, T, H, dk = 3, 130, 6, 64
+    C = H * dk
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(B, T, 3 * C, generator=g).to(dtype).to(dev)
+    go = torch.randn(B, T, C, generator=g).to(dtype).to(dev)
+    ln = torch.tensor([130, 64, 9], device=dev)
+    seeds = (11, 12)
+    a = qkv.clone().requires_grad_(True)
+    out_p = masked_attention_train_packed(a, H, ln, 0.1, seeds)
+    out_p.backward(go)
+    q, k, v = (qkv[..., i * C:(i + 1) * C].clone().requires_grad_(True) for i in range(3))
+    out = masked_attention_train(q, k, v, H, ln, 0.1, seeds)
+    out.backward(go)
+    assert torch.equal(out_p, out)
+    assert a.grad.shape == qkv.shape
+    for i, t in enumerate((q, k, v)):
+        assert torch.equal(a.grad[..., i * C:(i + 1) * C], t.grad), "qkv"[i]
+    with pytest.raises(RuntimeError, match="3 \\* channels"):
+        masked_attention_train_packed(qkv[..., :-1], H)
+
+
 def test_dropout_properties():
     """Keep rate, seeds name the mask, the default seeds follow torch.manual_seed and the call count, and
     masked positions receive no gradient."""

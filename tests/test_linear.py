@@ -185,7 +185,8 @@ def test_oracle_backward_matches_torch_autograd():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("rows,K,N,with_bias", [(64, 8, 8, True), (25600, 384, 384, True), (1000, 80, 384, False),
-                                                (777, 384, 1152, True), (130, 200, 40, True)])
+                                                (777, 384, 1152, True), (130, 200, 40, True),
+                                                (2000, 384, 34, True), (300, 64, 5, False)])
 def test_training_linear_matches_oracle(rows, K, N, with_bias):
     """linear_train (forward, input gradient, weight and bias gradient through the HIP kernels) against the oracle:
     y and dx at the bf16 bar of the forward tests, dW and db (fp32 results of bf16 operands) to 1e-4 of their
@@ -215,3 +216,40 @@ def test_training_linear_matches_oracle(rows, K, N, with_bias):
     assert wt.grad.dtype == torch.float32 and np.abs(got_dW - dW).max() <= 1e-4 * np.abs(dW).max()
     if with_bias:
         assert np.abs(bt.grad.cpu().double().numpy() - db).max() <= 1e-4 * np.abs(db).max()
+
+
+@pytest.mark.gpu
+def test_training_linear_writes_into_gradient_buckets():
+    """Parameters of a GradBuckets: the weight-gradient kernel writes into the bucket, `.grad` IS the bucket's slice
+    (no clearing between steps, no accumulation kernel), a second use in the same step adds; the padded
+    vocabulary width takes the copy route and lands in the bucket as well."""
+    from asr_amd.linear import linear_train
+    from asr_amd.parallel import GradBuckets
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    a, head = torch.nn.Linear(64, 48).to(dev), torch.nn.Linear(48, 34).to(dev)
+    buckets = GradBuckets([list(head.parameters()), list(a.parameters())], overlap=False)
+    x = torch.randn(200, 64, device=dev)
+    want = None
+    for step in range(2):
+        buckets.zero_grad()
+        assert a.weight.grad is None
+        buckets.arena.fill_(123.0)  # what the last step left behind must not leak into this one
+        h = linear_train(x, a.weight, a.bias)
+        (linear_train(h, head.weight, head.bias).float().sum() + linear_train(2 * x, a.weight, a.bias).float().sum()).backward()
+        buckets.finish()
+        for p, v in zip(buckets._params[1] + buckets._params[0], buckets._views[1] + buckets._views[0]):
+            assert p.grad.data_ptr() == v.data_ptr()
+        got = [p.grad.clone() for p in (a.weight, a.bias, head.weight, head.bias)]
+        if want is None:
+            # the same arithmetic without buckets
+            a2, head2 = torch.nn.Linear(64, 48).to(dev), torch.nn.Linear(48, 34).to(dev)
+            a2.load_state_dict(a.state_dict())
+            head2.load_state_dict(head.state_dict())
+            h2 = linear_train(x, a2.weight, a2.bias)
+            (linear_train(h2, head2.weight, head2.bias).float().sum()
+             + linear_train(2 * x, a2.weight, a2.bias).float().sum()).backward()
+            want = [p.grad for p in (a2.weight, a2.bias, head2.weight, head2.bias)]
+        for g, w in zip(got, want):
+            assert torch.allclose(g, w, rtol=1e-6, atol=1e-6 * float(w.abs().max()))

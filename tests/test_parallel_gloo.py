@@ -173,10 +173,54 @@ def test_grad_buckets_single_process():
     head = torch.nn.Linear(4, 3)
     b2 = GradBuckets([head])
     b2.zero_grad()
-    head.weight.grad.add_(1.0)
+    assert head.weight.grad is None and head.bias.grad is None  # a step starts empty; nothing is cleared
+    head.weight.grad = torch.ones_like(head.weight)
     _fire_hooks(head.weight)  # the bias never gets its gradient
+    assert head.weight.grad.data_ptr() == b2._views[0][0].data_ptr()  # moved into the bucket
     with pytest.raises(RuntimeError, match="incomplete"):
         b2.finish()
+    # a backward that knows of the bucket writes into the parameter's slice and hands autograd a fresh tensor on it
+    from asr_amd.parallel import adopt, grad_slot
+
+    class _Direct(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x)
+            ctx.w = w
+            return x @ w.t()
+
+        @staticmethod
+        def backward(ctx, gy):
+            (x,) = ctx.saved_tensors
+            slot = grad_slot(ctx.w)
+            if slot is None:
+                return None, gy.t() @ x
+            torch.mm(gy.t(), x, out=slot)
+            return None, adopt(slot)
+
+    lin = torch.nn.Linear(4, 3, bias=False)
+    b3 = GradBuckets([lin], overlap=False)
+    x = torch.randn(5, 4)
+    for rep in range(2):
+        b3.zero_grad()
+        b3.buckets[0].fill_(7.0)  # stale contents of the last step
+        with b3.accumulate():
+            _Direct.apply(x, lin.weight).sum().backward()
+            assert lin.weight.grad.data_ptr() == b3._views[0][0].data_ptr()
+            assert grad_slot(lin.weight) is None  # taken for this step
+            _Direct.apply(x, lin.weight).sum().backward()  # second gradient of the step: added in place
+            b3.finish()
+        want = 2 * torch.ones(3, 5) @ x
+        assert torch.allclose(b3._views[0][0], want, atol=1e-6)
+    # the parameter used twice in ONE backward: autograd sums both gradients before it touches .grad, so only the
+    # first use may write into the slice
+    b3.zero_grad()
+    (_Direct.apply(x, lin.weight).sum() + _Direct.apply(3 * x, lin.weight).sum()).backward()
+    b3.finish()
+    assert torch.allclose(b3._views[0][0], 4 * torch.ones(3, 5) @ x, atol=1e-5)
+    assert lin.weight.grad.data_ptr() == b3._views[0][0].data_ptr()
+    b3.remove()
+    assert not hasattr(lin.weight, "_grad_view")
 
 
 def test_bucket_plan():
