@@ -19,7 +19,7 @@ CONV_AUTO = 0
 CONV_TOEPLITZ = 1
 CONV_FFT = 2
 NOALLOC_SCRATCH_BYTES = 8 << 20
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class Shape(ctypes.Structure):
@@ -122,6 +122,11 @@ def _load():
     lib.lmufft_layernorm_bwd_workspace_bytes.argtypes = [i32]
     lib.lmufft_layernorm_bwd.restype = ci
     lib.lmufft_layernorm_bwd.argtypes = [vp, ci, vp, ci, vp, ci, vp, f32, i64, i32, vp, vp, vp, vp, vp, sz, vp]
+    lib.lmufft_add_layernorm_dropout.restype = ci
+    lib.lmufft_add_layernorm_dropout.argtypes = [vp, ci, vp, ci, vp, vp, f32, i64, i32, vp, ci, f32, u32, u32, vp]
+    lib.lmufft_layernorm_dropout_bwd.restype = ci
+    lib.lmufft_layernorm_dropout_bwd.argtypes = [vp, ci, vp, ci, vp, ci, vp, f32, i64, i32, f32, u32, u32, vp, vp, vp, vp,
+                                                 vp, sz, vp]
     lib.lmufft_linear_wgrad_workspace_bytes.restype = sz
     lib.lmufft_linear_wgrad_workspace_bytes.argtypes = [i64, i32, i32]
     lib.lmufft_linear_wgrad_bf16.restype = ci
@@ -181,6 +186,8 @@ EXPORTS = (
     "lmufft_add_layernorm",
     "lmufft_layernorm_bwd_workspace_bytes",
     "lmufft_layernorm_bwd",
+    "lmufft_add_layernorm_dropout",
+    "lmufft_layernorm_dropout_bwd",
     "lmufft_linear_bf16",
     "lmufft_linear_ln_bf16",
     "lmufft_linear_wgrad_workspace_bytes",

@@ -39,22 +39,8 @@ __device__ __forceinline__ float attn_ld(const T* p) { return (float)*p; }
 // (b, h, query, key) is kept when a counter-based hash of its index and the call's two seeds reaches the
 // threshold; the backward kernels evaluate the same function.  fmix32 is the 32-bit avalanche finaliser of
 // MurmurHash3, applied to the low word and again after folding in the high word.
-struct AttnDropout {
-  uint32_t seed0, seed1, threshold;  // keep <=> hash >= threshold; threshold = p * 2^32
-  float inv_keep;                    // 1 / (1 - p)
-};
-__device__ __forceinline__ uint32_t attn_fmix32(uint32_t x) {
-  x ^= x >> 16;
-  x *= 0x85EBCA6Bu;
-  x ^= x >> 13;
-  x *= 0xC2B2AE35u;
-  x ^= x >> 16;
-  return x;
-}
-__device__ __forceinline__ bool attn_keep(const AttnDropout& dr, unsigned long long idx) {
-  const uint32_t x = attn_fmix32(attn_fmix32((uint32_t)idx ^ dr.seed0) ^ (uint32_t)(idx >> 32) ^ dr.seed1);
-  return x >= dr.threshold;
-}
+typedef HashDropout AttnDropout;
+__device__ __forceinline__ bool attn_keep(const AttnDropout& dr, unsigned long long idx) { return hash_keep(dr, idx); }
 
 // TRAIN: dropout on the weights, and the row statistics (running maximum m, 1 / sum exp(s - m)) are saved for
 // the backward as stats[b][h][query][2] (the pair, not m + log l: a fully masked row has m = -1e9, where
@@ -1071,13 +1057,7 @@ int lmufft_attention_fwd_ld(const void* q, const void* k, const void* v, int dty
 }
 
 static AttnDropout attn_dropout(float p_drop, uint32_t seed0, uint32_t seed1) {
-  AttnDropout dr;
-  dr.seed0 = seed0;
-  dr.seed1 = seed1;
-  const double t = (double)p_drop * 4294967296.0;
-  dr.threshold = p_drop > 0.f ? (uint32_t)(t < 1.0 ? 1.0 : (t > 4294967295.0 ? 4294967295.0 : t)) : 0u;
-  dr.inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
-  return dr;
+  return make_hash_dropout(p_drop, seed0, seed1);
 }
 // the bf16 MFMA kernels load 16 bytes at a time: row strides in multiples of 8 elements, 16-byte aligned tensors
 static bool attn_bf16_fast(int64_t ld, int64_t ld2, const void* a, const void* b, const void* c, const void* d,

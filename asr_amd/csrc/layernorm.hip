@@ -57,12 +57,21 @@ __device__ __forceinline__ void ln_store4(void* base, long idx, const ln_f32x4& 
   }
 }
 
+// Dropout after the layer norm (`self.dropout_layer(layer_norm(x))`, src/models/lmu_encoder.py:274-277, training):
+// element (row, column) is kept by the hash of its flat index, scaled by 1 / (1 - p).
+__device__ __forceinline__ ln_f32x4 ln_dropout4(const ln_f32x4& v, const HashDropout& dr, unsigned long long idx) {
+  ln_f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = hash_keep(dr, idx + e) ? v[e] * dr.inv_keep : 0.f;
+  return o;
+}
+
 // RES: 0 none, 1 f32, 2 bf16
-template <bool XB, int RES, bool OB, int NG>
+template <bool XB, int RES, bool OB, int NG, bool DROP = false>
 __global__ __launch_bounds__(kLnThreads) void k_add_layernorm(const void* x, const void* res,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float eps, long rows,
-                                                              int C, void* out) {
+                                                              int C, void* out, HashDropout dr = HashDropout{0, 0, 0, 1.f}) {
   const int sub = threadIdx.x & 31;                                  // lane inside the row's half-wave
   const long row0 = (long)blockIdx.x * (kLnThreads / 32) + (threadIdx.x >> 5);
   const long row_step = (long)gridDim.x * (kLnThreads / 32);
@@ -108,17 +117,27 @@ __global__ __launch_bounds__(kLnThreads) void k_add_layernorm(const void* x, con
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
       const int c = sub + 32 * j;
-      if (c < groups) ln_store4<OB>(out, row * C + 4 * c, v[j] * rstd * g[j] + bt[j]);
+      if (c < groups) {
+        ln_f32x4 y = v[j] * rstd * g[j] + bt[j];
+        if (DROP) y = ln_dropout4(y, dr, (unsigned long long)(row * C + 4 * c));
+        ln_store4<OB>(out, row * C + 4 * c, y);
+      }
     }
   }
 }
 
 template <bool XB, int RES, bool OB>
 static void launch_ln(int ng, dim3 grid, hipStream_t st, const void* x, const void* res, const float* gamma,
-                      const float* beta, float eps, long rows, int C, void* out) {
-#define LN_CASE(NGV)                                                                                              \
-  hipLaunchKernelGGL((k_add_layernorm<XB, RES, OB, NGV>), grid, dim3(kLnThreads), 0, st, x, res, gamma, beta, eps, \
-                     rows, C, out)
+                      const float* beta, float eps, long rows, int C, void* out, const HashDropout& dr) {
+#define LN_CASE(NGV)                                                                                                  \
+  do {                                                                                                                \
+    if (dr.threshold)                                                                                                 \
+      hipLaunchKernelGGL((k_add_layernorm<XB, RES, OB, NGV, true>), grid, dim3(kLnThreads), 0, st, x, res, gamma,     \
+                         beta, eps, rows, C, out, dr);                                                                \
+    else                                                                                                              \
+      hipLaunchKernelGGL((k_add_layernorm<XB, RES, OB, NGV, false>), grid, dim3(kLnThreads), 0, st, x, res, gamma,    \
+                         beta, eps, rows, C, out, dr);                                                                \
+  } while (0)
   if (ng <= 1) LN_CASE(1);
   else if (ng <= 2) LN_CASE(2);
   else if (ng <= 3) LN_CASE(3);
@@ -152,7 +171,8 @@ constexpr int kLnBwdMaxBlocks = 512;
 template <int NG>
 __global__ __launch_bounds__(kLnThreads) void k_layernorm_bwd(const void* x, int xb, const void* res, int rb, const void* dy,
                                                               int gb, const float* __restrict__ gamma, float eps, long rows,
-                                                              int C, void* dx, void* dres, float* __restrict__ partial) {
+                                                              int C, void* dx, void* dres, float* __restrict__ partial,
+                                                              HashDropout dr) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [8 row slots][2][C]
   const int sub = threadIdx.x & 31, slot = threadIdx.x >> 5;
   const long row0 = (long)blockIdx.x * (kLnThreads / 32) + slot;
@@ -177,6 +197,7 @@ __global__ __launch_bounds__(kLnThreads) void k_layernorm_bwd(const void* x, int
         v[j] = ln_load4_rt(x, row * C + 4 * c, xb);
         if (res) v[j] += ln_load4_rt(res, row * C + 4 * c, rb);
         gy[j] = ln_load4_rt(dy, row * C + 4 * c, gb);
+        if (dr.threshold) gy[j] = ln_dropout4(gy[j], dr, (unsigned long long)(row * C + 4 * c));  // through the dropout
         s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
       }
     }
@@ -264,9 +285,9 @@ __global__ __launch_bounds__(kLnThreads) void k_layernorm_param_reduce(const flo
 
 using namespace lmufft;
 
-extern "C" int lmufft_add_layernorm(const void* x, int x_dtype, const void* res, int res_dtype, const float* gamma,
-                                    const float* beta, float eps, int64_t rows, int32_t C, void* out, int out_dtype,
-                                    void* stream) {
+static int add_layernorm_any(const void* x, int x_dtype, const void* res, int res_dtype, const float* gamma,
+                            const float* beta, float eps, int64_t rows, int32_t C, void* out, int out_dtype,
+                            const HashDropout& dr, void* stream) {
   if (rows < 0 || C <= 0) return set_error("layernorm: bad shape (rows=%lld C=%d)", (long long)rows, C);
   if (C % 4 != 0 || C > 32 * 4 * kLnMaxGroups)
     return set_error("layernorm: width %d (needs a multiple of 4, at most %d)", C, 32 * 4 * kLnMaxGroups);
@@ -291,7 +312,7 @@ extern "C" int lmufft_add_layernorm(const void* x, int x_dtype, const void* res,
   const int rk = !res ? 0 : (res_dtype == LMUFFT_BF16 ? 2 : 1);
   {
     ProfScope ps("k_add_layernorm", st);
-#define LN_GO(XBV, RV, OBV) launch_ln<XBV, RV, OBV>(ng, grid, st, x, res, gamma, beta, eps, (long)rows, C, out)
+#define LN_GO(XBV, RV, OBV) launch_ln<XBV, RV, OBV>(ng, grid, st, x, res, gamma, beta, eps, (long)rows, C, out, dr)
 #define LN_RES(XBV, OBV)          \
   do {                            \
     if (rk == 0) LN_GO(XBV, 0, OBV); \
@@ -310,6 +331,24 @@ extern "C" int lmufft_add_layernorm(const void* x, int x_dtype, const void* res,
   return 0;
 }
 
+extern "C" int lmufft_add_layernorm(const void* x, int x_dtype, const void* res, int res_dtype, const float* gamma,
+                                    const float* beta, float eps, int64_t rows, int32_t C, void* out, int out_dtype,
+                                    void* stream) {
+  return add_layernorm_any(x, x_dtype, res, res_dtype, gamma, beta, eps, rows, C, out, out_dtype,
+                           make_hash_dropout(0.f, 0, 0), stream);
+}
+
+extern "C" int lmufft_add_layernorm_dropout(const void* x, int x_dtype, const void* res, int res_dtype, const float* gamma,
+                                            const float* beta, float eps, int64_t rows, int32_t C, void* out,
+                                            int out_dtype, float p_drop, uint32_t seed0, uint32_t seed1, void* stream) {
+  if (!(p_drop >= 0.f && p_drop < 1.f)) return set_error("layernorm: dropout probability %g outside [0, 1)", (double)p_drop);
+  if (out == x || (res && out == res)) {
+    if (p_drop > 0.f) return set_error("layernorm with dropout: the backward recomputes from x and res; out may not alias them");
+  }
+  return add_layernorm_any(x, x_dtype, res, res_dtype, gamma, beta, eps, rows, C, out, out_dtype,
+                           make_hash_dropout(p_drop, seed0, seed1), stream);
+}
+
 extern "C" size_t lmufft_layernorm_bwd_workspace_bytes(int32_t C) {
   return C > 0 ? sizeof(float) * 2 * (size_t)C * kLnBwdMaxBlocks : 0;
 }
@@ -317,6 +356,17 @@ extern "C" size_t lmufft_layernorm_bwd_workspace_bytes(int32_t C) {
 extern "C" int lmufft_layernorm_bwd(const void* x, int x_dtype, const void* res, int res_dtype, const void* dy, int dy_dtype,
                                     const float* gamma, float eps, int64_t rows, int32_t C, void* dx, void* dres,
                                     float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
+  return lmufft_layernorm_dropout_bwd(x, x_dtype, res, res_dtype, dy, dy_dtype, gamma, eps, rows, C, 0.f, 0, 0, dx, dres,
+                                      dgamma, dbeta, workspace, workspace_bytes, stream);
+}
+
+extern "C" int lmufft_layernorm_dropout_bwd(const void* x, int x_dtype, const void* res, int res_dtype, const void* dy,
+                                            int dy_dtype, const float* gamma, float eps, int64_t rows, int32_t C,
+                                            float p_drop, uint32_t seed0, uint32_t seed1, void* dx, void* dres,
+                                            float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                                            void* stream) {
+  if (!(p_drop >= 0.f && p_drop < 1.f)) return set_error("layernorm backward: dropout probability %g outside [0, 1)", (double)p_drop);
+  const HashDropout dr = make_hash_dropout(p_drop, seed0, seed1);
   if (rows <= 0 || C <= 0) return set_error("layernorm backward: bad shape (rows=%lld C=%d)", (long long)rows, C);
   if (C % 4 != 0 || C > 32 * 4 * kLnMaxGroups)
     return set_error("layernorm backward: width %d (needs a multiple of 4, at most %d)", C, 32 * 4 * kLnMaxGroups);
@@ -343,7 +393,7 @@ extern "C" int lmufft_layernorm_bwd(const void* x, int x_dtype, const void* res,
     ProfScope ps("k_layernorm_bwd", st);
 #define LN_BWD(NGV)                                                                                                    \
   hipLaunchKernelGGL((k_layernorm_bwd<NGV>), dim3(nb), dim3(kLnThreads), lds, st, x, x_dtype == LMUFFT_BF16, res,         \
-                     res_dtype == LMUFFT_BF16, dy, dy_dtype == LMUFFT_BF16, gamma, eps, (long)rows, C, dx, dres, partial)
+                     res_dtype == LMUFFT_BF16, dy, dy_dtype == LMUFFT_BF16, gamma, eps, (long)rows, C, dx, dres, partial, dr)
     if (ng <= 1) LN_BWD(1);
     else if (ng <= 2) LN_BWD(2);
     else if (ng <= 3) LN_BWD(3);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
+#include <stdint.h>
 #include <stdio.h>
 
 #include "lmufft.h"
@@ -60,6 +61,35 @@ int fft_conv_backward(const lmufft_shape& s, const float* gm, const void* prep, 
                       hipStream_t st);
 // out[i] = sum_p part[p*n + i], masked by u[i] > 0 when u != NULL (defined in lmufft_f32.hip)
 int launch_sum_slabs_masked(const float* part, const float* u, float* out, long n, int P, hipStream_t st);
+
+// Dropout without a stored mask: element idx of a call is kept when a counter-based hash of (idx, the call's two
+// seeds) reaches the threshold p * 2^32 -- MurmurHash3's 32-bit finaliser applied twice.  The forward and the
+// backward of a call recompute the same decisions.  threshold = 0: no dropout.
+struct HashDropout {
+  uint32_t seed0, seed1, threshold;
+  float inv_keep;  // 1 / (1 - p)
+};
+__device__ __forceinline__ uint32_t hash_fmix32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x85EBCA6Bu;
+  x ^= x >> 13;
+  x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ bool hash_keep(const HashDropout& dr, unsigned long long idx) {
+  const uint32_t x = hash_fmix32(hash_fmix32((uint32_t)idx ^ dr.seed0) ^ (uint32_t)(idx >> 32) ^ dr.seed1);
+  return x >= dr.threshold;
+}
+inline HashDropout make_hash_dropout(float p_drop, uint32_t seed0, uint32_t seed1) {
+  HashDropout dr;
+  dr.seed0 = seed0;
+  dr.seed1 = seed1;
+  const double t = (double)p_drop * 4294967296.0;
+  dr.threshold = p_drop > 0.f ? (uint32_t)(t < 1.0 ? 1.0 : (t > 4294967295.0 ? 4294967295.0 : t)) : 0u;
+  dr.inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+  return dr;
+}
 
 // Brackets one kernel launch with HIP events when profiling is enabled
 // (lmufft_profile_enable); a no-op otherwise.

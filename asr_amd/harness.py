@@ -127,10 +127,12 @@ def _qkv_projection(wq: nn.Linear, wk: nn.Linear, wv: nn.Linear, x: torch.Tensor
 
 
 def _layer_norm(ln: nn.LayerNorm, x: torch.Tensor, residual: Optional[torch.Tensor] = None,
-                out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
-    """ln(x + residual): the one-pass HIP kernel for inference on the GPU, torch otherwise."""
+                out_dtype: Optional[torch.dtype] = None, dropout: Optional[nn.Dropout] = None) -> torch.Tensor:
+    """dropout(ln(x + residual)): the one-pass HIP kernels on the GPU (the dropout rides on the same pass), torch
+    otherwise."""
     C = x.shape[-1]
-    if (x.is_cuda and not torch.is_grad_enabled() and ln.elementwise_affine and ln.bias is not None
+    p_drop = dropout.p if (dropout is not None and dropout.training) else 0.0
+    if (x.is_cuda and not torch.is_grad_enabled() and p_drop == 0.0 and ln.elementwise_affine and ln.bias is not None
             and C % 4 == 0 and C <= _LN_MAX_WIDTH and x.dtype in (torch.float32, torch.bfloat16)
             and (residual is None or residual.dtype in (torch.float32, torch.bfloat16))):
         _took("hip", "layer_norm")
@@ -139,10 +141,11 @@ def _layer_norm(ln: nn.LayerNorm, x: torch.Tensor, residual: Optional[torch.Tens
             and C <= _LN_MAX_WIDTH and x.dtype in (torch.float32, torch.bfloat16) and ln.weight.dtype == torch.float32
             and (residual is None or residual.dtype in (torch.float32, torch.bfloat16))):
         _took("hip", "layer_norm")  # training: the same forward kernel, and its backward, behind an autograd function
-        return add_layer_norm_train(x, residual, ln.weight, ln.bias, ln.eps, out_dtype)
+        return add_layer_norm_train(x, residual, ln.weight, ln.bias, ln.eps, out_dtype, p_drop)
     _took("torch", "layer_norm")
     y = ln(x if residual is None else x + residual)
-    return y if out_dtype is None else y.to(out_dtype)
+    y = y if out_dtype is None else y.to(out_dtype)
+    return y if dropout is None else dropout(y)
 
 
 class _MultiHeadAttention(nn.Module):
@@ -246,11 +249,17 @@ class LMUEncoder(nn.Module):
     def forward(self, x: torch.Tensor, lengths: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, list]:
         stream = torch.bfloat16 if (self.bf16_stream and x.is_cuda and torch.is_autocast_enabled()
                                     and torch.get_autocast_dtype("cuda") == torch.bfloat16) else None
+        # The attention block's output has one consumer, the LMU layer, which under bf16 autocast rounds it to bf16
+        # first: its layer norm writes that rounding directly -- the same numbers without the fp32 tensor and the cast
+        # (and, in training, without the widening of the layer's input gradient).
+        att_out = stream
+        if att_out is None and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+            att_out = torch.bfloat16
         x = _linear(self.input_projection, x)
         states = []
         for att, lmu, ln in zip(self.attention_layers, self.lmu_layers, self.layer_norms):
             if self.use_attention:
-                x = att(x, lengths, stream)
+                x = att(x, lengths, att_out)
             drop = self.training and self.dropout_layer.p > 0
             if not drop and ln.elementwise_affine and ln.bias is not None and lmu.supports_fused_layer_norm(x):
                 # the layer norm rides on the projection kernel's epilogue: h never goes to HBM
@@ -258,7 +267,7 @@ class LMUEncoder(nn.Module):
                     x, ln, stream or (torch.float32 if torch.is_autocast_enabled() else x.dtype))
             else:
                 x, h_n = lmu(x)
-                x = self.dropout_layer(_layer_norm(ln, x, None, stream))
+                x = _layer_norm(ln, x, None, stream, self.dropout_layer)
             states.append(h_n)
         return _linear(self.output_projection, x), states
 

@@ -19,12 +19,14 @@ MAX_WIDTH = 1024
 
 
 def add_layer_norm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor, bias: torch.Tensor,
-                   eps: float = 1e-5, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+                   eps: float = 1e-5, out_dtype: Optional[torch.dtype] = None, p_drop: float = 0.0,
+                   seeds=(0, 0)) -> torch.Tensor:
     """LayerNorm over the last dimension of `x (+ residual)` with fp32 statistics.
 
     x, residual: [..., C] float32 or bfloat16 (they may differ); weight, bias: [C].  The result has
     `out_dtype`, by default float32 under autocast (where torch runs layer_norm in fp32) and the
-    promoted input dtype otherwise.
+    promoted input dtype otherwise.  `p_drop` > 0: dropout on the result in the same pass (training; the mask
+    is a function of `seeds` = two 32-bit integers and the element's index, nothing is stored).
     """
     for name, t in (("x", x), ("residual", residual), ("weight", weight), ("bias", bias)):
         if t is not None and not t.is_cuda:
@@ -52,20 +54,21 @@ def add_layer_norm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: to
     rows = x.numel() // C if C else 0
     p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())  # noqa: E731
     with torch.cuda.device(x.device):
-        rc = _lib.lib.lmufft_add_layernorm(
+        rc = _lib.lib.lmufft_add_layernorm_dropout(
             p(x), _DTYPES[x.dtype], p(residual), _DTYPES[residual.dtype] if residual is not None else 0, p(weight),
-            p(bias), float(eps), rows, C, p(out), _DTYPES[out_dtype],
-            ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
-    _lib.check(rc, "lmufft_add_layernorm")
+            p(bias), float(eps), rows, C, p(out), _DTYPES[out_dtype], float(p_drop), int(seeds[0]) & 0xFFFFFFFF,
+            int(seeds[1]) & 0xFFFFFFFF, ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    _lib.check(rc, "lmufft_add_layernorm_dropout")
     return out
 
 
 def add_layer_norm_backward(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor, dy: torch.Tensor,
                             eps: float = 1e-5, out_weight: Optional[torch.Tensor] = None,
-                            out_bias: Optional[torch.Tensor] = None):
+                            out_bias: Optional[torch.Tensor] = None, p_drop: float = 0.0, seeds=(0, 0)):
     """(dx, dresidual or None, dweight, dbias) of add_layer_norm: dx / dresidual carry the same values in the dtype
     of x / residual (one tensor when the dtypes agree); dweight, dbias float32, written into `out_weight` /
-    `out_bias` (contiguous float32 [C]) when given.  HIP kernel k_layernorm_bwd."""
+    `out_bias` (contiguous float32 [C]) when given.  `p_drop`, `seeds`: those of the forward call; dy passes
+    through the same dropout decisions first.  HIP kernel k_layernorm_bwd."""
     for name, t in (("x", x), ("residual", residual), ("weight", weight), ("dy", dy)):
         if t is not None and not t.is_cuda:
             raise RuntimeError(f"add_layer_norm_backward: `{name}` lives on {t.device}; the kernel runs only on a GPU "
@@ -91,11 +94,12 @@ def add_layer_norm_backward(x: torch.Tensor, residual: Optional[torch.Tensor], w
     rows = x.numel() // C
     p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())  # noqa: E731
     with torch.cuda.device(x.device):
-        rc = _lib.lib.lmufft_layernorm_bwd(
+        rc = _lib.lib.lmufft_layernorm_dropout_bwd(
             p(x), _DTYPES[x.dtype], p(residual), _DTYPES[residual.dtype] if residual is not None else 0, p(dy),
-            _DTYPES[dy.dtype], p(weight), float(eps), rows, C, p(dx), p(dres), p(dgamma), p(dbeta), p(ws), ws.numel(),
+            _DTYPES[dy.dtype], p(weight), float(eps), rows, C, float(p_drop), int(seeds[0]) & 0xFFFFFFFF,
+            int(seeds[1]) & 0xFFFFFFFF, p(dx), p(dres), p(dgamma), p(dbeta), p(ws), ws.numel(),
             ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
-    _lib.check(rc, "lmufft_layernorm_bwd")
+    _lib.check(rc, "lmufft_layernorm_dropout_bwd")
     if residual is None:
         return dx, None, dgamma, dbeta
     return dx, (dx if dres is None else dres), dgamma, dbeta
@@ -103,28 +107,44 @@ def add_layer_norm_backward(x: torch.Tensor, residual: Optional[torch.Tensor], w
 
 class _AddLayerNormTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, eps, out_dtype):
+    def forward(ctx, x, residual, weight, bias, eps, out_dtype, p_drop, seed0, seed1):
         ctx.save_for_backward(x, residual, weight)
         ctx.eps = eps
         ctx.params = (weight, bias)
-        return add_layer_norm(x, residual, weight, bias, eps, out_dtype)
+        ctx.drop = (p_drop, (seed0, seed1))
+        return add_layer_norm(x, residual, weight, bias, eps, out_dtype, p_drop, (seed0, seed1))
 
     @staticmethod
     def backward(ctx, dy):
         x, residual, weight = ctx.saved_tensors
         # parameters of a GradBuckets: the kernel writes into the bucket and autograd adopts the slices as .grad
         slot_w, slot_b = grad_slot(ctx.params[0]), grad_slot(ctx.params[1])
-        dx, dres, dgamma, dbeta = add_layer_norm_backward(x, residual, weight, dy, ctx.eps, slot_w, slot_b)
+        dx, dres, dgamma, dbeta = add_layer_norm_backward(x, residual, weight, dy, ctx.eps, slot_w, slot_b, *ctx.drop)
         dgamma = adopt(dgamma) if slot_w is not None else dgamma.to(weight.dtype)
         dbeta = adopt(dbeta) if slot_b is not None else dbeta.to(weight.dtype)
         return (dx if ctx.needs_input_grad[0] else None, dres if ctx.needs_input_grad[1] else None,
-                dgamma, dbeta, None, None)
+                dgamma, dbeta, None, None, None, None, None)
+
+
+_dropout_calls = 0
 
 
 def add_layer_norm_train(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor, bias: torch.Tensor,
-                         eps: float = 1e-5, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
-    """add_layer_norm with autograd (forward k_add_layernorm, backward k_layernorm_bwd)."""
+                         eps: float = 1e-5, out_dtype: Optional[torch.dtype] = None, p_drop: float = 0.0,
+                         seeds=None) -> torch.Tensor:
+    """add_layer_norm with autograd (forward k_add_layernorm, backward k_layernorm_bwd), optionally followed by
+    dropout in the same passes (`self.dropout_layer(layer_norm(x))`, src/models/lmu_encoder.py:274-277).
+    `seeds` = (seed0, seed1) name the dropout mask; by default torch's seed and a per-process call counter, so runs
+    that start from the same torch.manual_seed and make the same calls draw the same masks."""
+    global _dropout_calls
+    if not 0.0 <= p_drop < 1.0:
+        raise ValueError(f"dropout probability has to be in [0, 1), got {p_drop}")
     if out_dtype is None:
         out_dtype = torch.float32 if torch.is_autocast_enabled() else (
             x.dtype if residual is None else torch.promote_types(x.dtype, residual.dtype))
-    return _AddLayerNormTrain.apply(x, residual, weight, bias, eps, out_dtype)
+    if seeds is None:
+        if p_drop > 0:
+            _dropout_calls += 1
+        seeds = (torch.initial_seed() & 0xFFFFFFFF, 0x4C4E0000 ^ (_dropout_calls & 0xFFFFFFFF))
+    return _AddLayerNormTrain.apply(x, residual, weight, bias, eps, out_dtype, float(p_drop), int(seeds[0]) & 0xFFFFFFFF,
+                                    int(seeds[1]) & 0xFFFFFFFF)

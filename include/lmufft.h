@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMUFFT_ABI_VERSION 12
+#define LMUFFT_ABI_VERSION 13
 
 /* element types of the activations (x, h, gh, gx, m) */
 #define LMUFFT_F32 0
@@ -280,6 +280,23 @@ size_t lmufft_layernorm_bwd_workspace_bytes(int32_t C);
 int lmufft_layernorm_bwd(const void* x, int x_dtype, const void* res, int res_dtype, const void* dy, int dy_dtype,
                          const float* gamma, float eps, int64_t rows, int32_t C, void* dx, void* dres,
                          float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Layer norm followed by dropout (training), and its backward.  Replaces
+ * `x = self.dropout_layer(layer_norm(x))`, src/models/lmu_encoder.py:274-277 (nn.Dropout, :232), as one pass
+ * over HBM in each direction: the forward multiplies element (row, column) of the normalised output by
+ * keep / (1 - p_drop), keep decided by the library's counter-based hash of row * C + column and the call's two
+ * seeds (as lmufft_attention_fwd_train; no mask is stored); the backward sends dy through the same decisions
+ * before the layer-norm backward above.  p_drop in [0, 1); 0 gives the plain kernels.  With p_drop > 0 `out`
+ * may not alias x or res (the backward recomputes from them).
+ * ---------------------------------------------------------------------- */
+int lmufft_add_layernorm_dropout(const void* x, int x_dtype, const void* res, int res_dtype, const float* gamma,
+                                 const float* beta, float eps, int64_t rows, int32_t C, void* out, int out_dtype,
+                                 float p_drop, uint32_t seed0, uint32_t seed1, void* stream);
+int lmufft_layernorm_dropout_bwd(const void* x, int x_dtype, const void* res, int res_dtype, const void* dy,
+                                 int dy_dtype, const float* gamma, float eps, int64_t rows, int32_t C, float p_drop,
+                                 uint32_t seed0, uint32_t seed1, void* dx, void* dres, float* dgamma, float* dbeta,
+                                 void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Weight and bias gradient of a Linear layer under bf16 autocast (training).  Replaces what autograd runs

@@ -182,3 +182,53 @@ def test_training_layer_norm_matches_oracle(rows, C, x_dtype, res_dtype, dy_dtyp
     ref_y = lo.add_layer_norm(x.float().numpy(), None if r is None else r.float().numpy(), w.numpy(), b.numpy(), 1e-5)
     assert np.abs(y.detach().float().cpu().numpy() - ref_y).max() <= (1e-5 if dy_dtype == torch.float32 else 2.0 ** -7) * \
         np.abs(ref_y).max() + 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,C,dtype,with_res", [(25600, 384, torch.float32, False), (777, 200, torch.bfloat16, True)])
+def test_training_layer_norm_with_dropout(rows, C, dtype, with_res):
+    """Dropout in the layer norm's passes: the forward is the plain result times keep / (1 - p) for the oracle's mask
+    of the same seeds, the backward that of the plain layer norm for dy times keep / (1 - p); the keep rate; the
+    default seeds follow torch.manual_seed and the call count."""
+    from asr_amd import layernorm as ln
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, C, generator=g).to(dtype)
+    r = torch.randn(rows, C, generator=g).to(dtype) if with_res else None
+    w, b = torch.randn(C, generator=g) * 0.5 + 1.0, torch.randn(C, generator=g)
+    dy = torch.randn(rows, C, generator=g).to(dtype)
+    p, seeds = 0.1, (77, 78)
+    keep = lo.dropout_keep((rows, C), p, *seeds)
+    assert abs(keep.mean() - 0.9) < 0.01
+    scale = torch.from_numpy(keep.astype(np.float32) / (1.0 - p)).to(dev)
+
+    def run(p_drop, upstream):
+        xd = x.to(dev).requires_grad_(True)
+        rd = None if r is None else r.to(dev).requires_grad_(True)
+        wd, bd = torch.nn.Parameter(w.to(dev)), torch.nn.Parameter(b.to(dev))
+        y = ln.add_layer_norm_train(xd, rd, wd, bd, 1e-5, dtype, p_drop, seeds)
+        y.backward(upstream)
+        return y.detach(), xd.grad, None if rd is None else rd.grad, wd.grad, bd.grad
+
+    y_d, dx_d, dr_d, dw_d, db_d = run(p, dy.to(dev))
+    y_0, dx_0, dr_0, dw_0, db_0 = run(0.0, (dy.to(dev).float() * scale).to(dtype))
+    tol = 1e-6 if dtype == torch.float32 else 2.0 ** -7
+    want_y = y_0.float() * scale
+    assert torch.equal(y_d == 0, want_y == 0) or abs(float((y_d == 0).float().mean()) - 0.1) < 0.01
+    assert torch.allclose(y_d.float(), want_y, rtol=tol, atol=tol)
+    # the backward sees dy * keep / (1 - p) in fp32; the comparison run rounded that product to the tensor dtype
+    for got, want in ((dx_d, dx_0), (dr_d, dr_0), (dw_d, dw_0), (db_d, db_0)):
+        if want is not None:
+            assert torch.allclose(got.float(), want.float(), rtol=4 * tol, atol=4 * tol * float(want.float().abs().max()))
+    # default seeds: torch's seed and a call counter
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    torch.manual_seed(5)
+    ln._dropout_calls = 0
+    a1, a2 = ln.add_layer_norm_train(xd, None, wd, bd, 1e-5, dtype, p), ln.add_layer_norm_train(xd, None, wd, bd, 1e-5, dtype, p)
+    torch.manual_seed(5)
+    ln._dropout_calls = 0
+    b1 = ln.add_layer_norm_train(xd, None, wd, bd, 1e-5, dtype, p)
+    assert torch.equal(a1, b1) and not torch.equal(a1, a2)
+    with pytest.raises(ValueError):
+        ln.add_layer_norm_train(xd, None, wd, bd, 1e-5, dtype, 1.0)
