@@ -35,12 +35,11 @@ constexpr int kAttnKeys = 32;       // keys per tile
 template <class T>
 __device__ __forceinline__ float attn_ld(const T* p) { return (float)*p; }
 
-// Dropout of the attention weights (src/models/lmu_encoder.py:45, 86) without a stored mask: element
-// (b, h, query, key) is kept when a counter-based hash of its index and the call's two seeds reaches the
-// threshold; the backward kernels evaluate the same function.  fmix32 is the 32-bit avalanche finaliser of
-// MurmurHash3, applied to the low word and again after folding in the high word.
+// Dropout of the attention weights (src/models/lmu_encoder.py:45, 86) without a stored mask: a row is one
+// (b, h, query), its columns the keys; the hash (HashDropout) serves two neighbouring keys of a query.  Kernels
+// whose lanes own a query hash once per key pair; the key-owning sweep shares a hash between the two lanes of a
+// key pair.  The backward kernels evaluate the same function.
 typedef HashDropout AttnDropout;
-__device__ __forceinline__ bool attn_keep(const AttnDropout& dr, unsigned long long idx) { return hash_keep(dr, idx); }
 
 // TRAIN: dropout on the weights, and the row statistics (running maximum m, 1 / sum exp(s - m)) are saved for
 // the backward as stats[b][h][query][2] (the pair, not m + log l: a fully masked row has m = -1e9, where
@@ -150,11 +149,11 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? (TRAIN ? 2 : 4) : 1) void k_att
     l_run = l_run * alpha + psum;
     m_run = m_new;
     if (TRAIN && dr.threshold) {  // the normaliser keeps every weight; the context only the surviving ones
-      const unsigned long long row0 = (((unsigned long long)b * H + h) * T + qi) * T;
+      const HashRow hrow = hash_row(dr, ((unsigned long long)b * H + h) * T + qi, (unsigned)(T + 1) >> 1);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int j = j0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-        st[i] = attn_keep(dr, row0 + j) ? st[i] * dr.inv_keep : 0.f;
+        st[i] = hash_keep(dr, hrow, j) ? st[i] * dr.inv_keep : 0.f;
       }
     }
 #pragma unroll
@@ -215,7 +214,7 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? (TRAIN ? 2 : 4) : 1) void k_att
 // like the forward's O^T) and also writes D; k_attention_bwd_dkv gives a lane one KEY (sweeping query tiles:
 // S and dW tiles with the lane's K and V rows as B operands, dV^T and dK^T accumulated).  fp32 arithmetic on
 // the exact-fp32 MFMA for fp32 and bf16 tensors alike.  The dropout mask is recomputed from the element
-// index (attn_keep), nothing [T x T] is ever stored.
+// index (HashDropout), nothing [T x T] is ever stored.
 // ---------------------------------------------------------------------------
 template <int DK, class TIO, int NW>
 __global__ __launch_bounds__(64 * NW) void k_attention_bwd_dq(const TIO* __restrict__ q, const TIO* __restrict__ k,
@@ -283,7 +282,7 @@ __global__ __launch_bounds__(64 * NW) void k_attention_bwd_dq(const TIO* __restr
       }
     }
   };
-  const unsigned long long row0 = ((unsigned long long)bh * T + qi) * T;
+  const HashRow hrow = hash_row(dr, (unsigned long long)bh * T + qi, (unsigned)(T + 1) >> 1);
 
   fetch(0);
   for (int j0 = 0; j0 < T; j0 += kAttnKeys) {
@@ -306,7 +305,7 @@ __global__ __launch_bounds__(64 * NW) void k_attention_bwd_dq(const TIO* __restr
       const bool inside = q_valid && j < len;
       const float pv = j < T ? __expf((inside ? st[i] : -1e9f) - m) * invl : 0.f;
       float dw = dp[i];
-      if (dr.threshold) dw = attn_keep(dr, row0 + j) ? dw * dr.inv_keep : 0.f;
+      if (dr.threshold) dw = hash_keep(dr, hrow, j) ? dw * dr.inv_keep : 0.f;
       st[i] = inside ? pv * (dw - D) * scale : 0.f;
     }
     // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
@@ -439,7 +438,7 @@ __global__ __launch_bounds__(64 * NW) void k_attention_bwd_dkv(const TIO* __rest
       const int row = (i & 3) + 8 * (i >> 2) + 4 * hh, qq = i0 + row;
       const bool inside = qq < len && k_valid;
       const float pv = __expf((inside ? st[i] * scale : -1e9f) - Ms[row]) * Ls[row];
-      const bool keep = dr.threshold ? attn_keep(dr, ((unsigned long long)bh * T + qq) * T + kj) : true;
+      const bool keep = dr.threshold ? hash_keep(dr, hash_row(dr, (unsigned long long)bh * T + qq, (unsigned)(T + 1) >> 1), kj) : true;
       const float dw = keep ? dp[i] * dr.inv_keep : 0.f;
       st[i] = keep ? pv * dr.inv_keep : 0.f;                 // W[query][key]
       dp[i] = inside ? pv * (dw - Ds[row]) * scale : 0.f;    // dS[query][key] / sqrt(dk)
@@ -572,6 +571,8 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? (TRAIN ? 3 : 4) : 1) void k_att
     }
   };
 
+  [[maybe_unused]] const HashRow hrow = hash_row(dr, ((unsigned long long)b * H + h) * T + qi, (unsigned)(T + 1) >> 1);
+
   fetch(0);
   for (int j0 = 0; j0 < T; j0 += KEYS) {
     __syncthreads();
@@ -619,18 +620,21 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? (TRAIN ? 3 : 4) : 1) void k_att
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float psum = 0.f;
     attn_bf16x8 pf[NKT][2];
-    [[maybe_unused]] const unsigned long long row0 = (((unsigned long long)b * H + h) * T + qi) * T;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float pv = __builtin_amdgcn_exp2f(st[kt][i] - m_new);
-        psum += pv;
+      for (int i = 0; i < 16; i += 2) {  // registers i, i + 1: keys j, j + 1 (j even), one hash for the pair
+        float pv0 = __builtin_amdgcn_exp2f(st[kt][i] - m_new);
+        float pv1 = __builtin_amdgcn_exp2f(st[kt][i + 1] - m_new);
+        psum += pv0 + pv1;
         if (TRAIN && dr.threshold) {  // the normaliser keeps every weight; the context only the surviving ones
           const int j = j0 + 32 * kt + (i & 3) + 8 * (i >> 2) + 4 * hh;
-          pv = attn_keep(dr, row0 + j) ? pv * dr.inv_keep : 0.f;
+          const uint32_t x = hash_pair(hrow, (unsigned)j >> 1);
+          pv0 = hash_keep_lo(dr, x) ? pv0 * dr.inv_keep : 0.f;
+          pv1 = hash_keep_hi(dr, x) ? pv1 * dr.inv_keep : 0.f;
         }
-        pf[kt][i >> 3][i & 7] = (attn_bf16)pv;
+        pf[kt][i >> 3][i & 7] = (attn_bf16)pv0;
+        pf[kt][i >> 3][(i & 7) + 1] = (attn_bf16)pv1;
       }
     psum += __shfl_xor(psum, 32);
     l_run = l_run * alpha + psum;
@@ -784,7 +788,7 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 2 : 1) void k_attention_bwd_dq_
       }
     }
   };
-  const unsigned long long row0 = ((unsigned long long)bh * T + qi) * T;
+  const HashRow hrow = hash_row(dr, (unsigned long long)bh * T + qi, (unsigned)(T + 1) >> 1);
 
   fetch(0);
   for (int j0 = 0; j0 < T; j0 += 32) {
@@ -794,6 +798,7 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 2 : 1) void k_attention_bwd_dq_
     if (j0 + 32 < T) fetch(j0 + 32);
 
     attn_f16v st, dp;
+    [[maybe_unused]] uint32_t xpair = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) st[i] = 0.f, dp[i] = 0.f;
 #pragma unroll
@@ -810,7 +815,12 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 2 : 1) void k_attention_bwd_dq_
       const bool inside = q_valid && j < len;
       const float pv = j < T ? __builtin_amdgcn_exp2f((inside ? st[i] * scale2 : kMasked2) - m2) * invl : 0.f;
       float dw = dp[i];
-      if (dr.threshold) dw = attn_keep(dr, row0 + j) ? dw * dr.inv_keep : 0.f;
+      if (dr.threshold) {  // registers i, i + 1 (i even) are the two keys of one hash
+        uint32_t x = 0;
+        if ((i & 1) == 0) x = xpair = hash_pair(hrow, (unsigned)j >> 1);
+        else x = xpair;
+        dw = ((i & 1) ? hash_keep_hi(dr, x) : hash_keep_lo(dr, x)) ? dw * dr.inv_keep : 0.f;
+      }
       dsf[i >> 3][i & 7] = (attn_bf16)(inside ? pv * (dw - D) * scale : 0.f);
     }
     // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
@@ -942,12 +952,29 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 2 : 1) void k_attention_bwd_dkv
       dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, vf[s], dp, 0, 0, 0);
     }
     attn_bf16x8 wf[2], dsf[2];
+    // Dropout decisions: lanes r and r ^ 1 own the two keys of a pair and need the same 16 hashes (one per query
+    // register); the even lane computes those of the even registers, the odd lane those of the odd ones, and a
+    // lane swap within the pair delivers the rest.
+    uint32_t xq[16];
+    if (dr.threshold) {
+      const int odd = r & 1;
+#pragma unroll
+      for (int ii = 0; ii < 8; ++ii) {
+        const int i = 2 * ii;  // this lane hashes register i + odd: query row rho(i) + odd
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * hh + odd;
+        const uint32_t mine = hash_pair(hash_row(dr, (unsigned long long)bh * T + (i0 + row), (unsigned)(T + 1) >> 1),
+                                        (unsigned)kj >> 1);
+        const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xF, 0xF, false);  // lane ^ 1
+        xq[i] = odd ? other : mine;
+        xq[i + 1] = odd ? mine : other;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = (i & 3) + 8 * (i >> 2) + 4 * hh, qq = i0 + row;
       const bool inside = qq < len && k_valid;
       const float pv = __builtin_amdgcn_exp2f((inside ? st[i] * scale2 : kMasked2) - Ms[row]) * Ls[row];
-      const bool keep = dr.threshold ? attn_keep(dr, ((unsigned long long)bh * T + qq) * T + kj) : true;
+      const bool keep = dr.threshold ? ((kj & 1) ? hash_keep_hi(dr, xq[i]) : hash_keep_lo(dr, xq[i])) : true;
       const float dw = keep ? dp[i] * dr.inv_keep : 0.f;
       wf[i >> 3][i & 7] = (attn_bf16)(keep ? pv * dr.inv_keep : 0.f);
       dsf[i >> 3][i & 7] = (attn_bf16)(inside ? pv * (dw - Ds[row]) * scale : 0.f);

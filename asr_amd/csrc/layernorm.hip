@@ -58,11 +58,14 @@ __device__ __forceinline__ void ln_store4(void* base, long idx, const ln_f32x4& 
 }
 
 // Dropout after the layer norm (`self.dropout_layer(layer_norm(x))`, src/models/lmu_encoder.py:274-277, training):
-// element (row, column) is kept by the hash of its flat index, scaled by 1 / (1 - p).
-__device__ __forceinline__ ln_f32x4 ln_dropout4(const ln_f32x4& v, const HashDropout& dr, unsigned long long idx) {
+// element (row, column) is kept by the shared hash (HashDropout: rows of C columns), scaled by 1 / (1 - p).
+__device__ __forceinline__ ln_f32x4 ln_dropout4(const ln_f32x4& v, const HashDropout& dr, const HashRow& hr, int col) {
+  const uint32_t x0 = hash_pair(hr, (unsigned)col >> 1), x1 = hash_pair(hr, ((unsigned)col >> 1) + 1);
   ln_f32x4 o;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = hash_keep(dr, idx + e) ? v[e] * dr.inv_keep : 0.f;
+  o[0] = hash_keep_lo(dr, x0) ? v[0] * dr.inv_keep : 0.f;
+  o[1] = hash_keep_hi(dr, x0) ? v[1] * dr.inv_keep : 0.f;
+  o[2] = hash_keep_lo(dr, x1) ? v[2] * dr.inv_keep : 0.f;
+  o[3] = hash_keep_hi(dr, x1) ? v[3] * dr.inv_keep : 0.f;
   return o;
 }
 
@@ -114,12 +117,13 @@ __global__ __launch_bounds__(kLnThreads) void k_add_layernorm(const void* x, con
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o);
     const float rstd = rsqrtf(q * inv_c + eps);
+    [[maybe_unused]] const HashRow hr = hash_row(dr, (unsigned long long)row, (unsigned)C >> 1);
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
       const int c = sub + 32 * j;
       if (c < groups) {
         ln_f32x4 y = v[j] * rstd * g[j] + bt[j];
-        if (DROP) y = ln_dropout4(y, dr, (unsigned long long)(row * C + 4 * c));
+        if (DROP) y = ln_dropout4(y, dr, hr, 4 * c);
         ln_store4<OB>(out, row * C + 4 * c, y);
       }
     }
@@ -166,7 +170,7 @@ __device__ __forceinline__ void ln_store4_rt(void* base, long idx, const ln_f32x
   else ln_store4<false>(base, idx, v);
 }
 
-constexpr int kLnBwdMaxBlocks = 512;
+constexpr int kLnBwdMaxBlocks = 1024;  // four workgroups per CU (what its registers allow): the row loop is a chain of load, reductions, store
 
 template <int NG>
 __global__ __launch_bounds__(kLnThreads) void k_layernorm_bwd(const void* x, int xb, const void* res, int rb, const void* dy,
@@ -190,6 +194,7 @@ __global__ __launch_bounds__(kLnThreads) void k_layernorm_bwd(const void* x, int
   for (long row = row0; row < rows; row += row_step) {
     ln_f32x4 v[NG], gy[NG];
     float s = 0.f;
+    const HashRow hr = hash_row(dr, (unsigned long long)row, (unsigned)C >> 1);
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
       const int c = sub + 32 * j;
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(kLnThreads) void k_layernorm_bwd(const void* x, int
         v[j] = ln_load4_rt(x, row * C + 4 * c, xb);
         if (res) v[j] += ln_load4_rt(res, row * C + 4 * c, rb);
         gy[j] = ln_load4_rt(dy, row * C + 4 * c, gb);
-        if (dr.threshold) gy[j] = ln_dropout4(gy[j], dr, (unsigned long long)(row * C + 4 * c));  // through the dropout
+        if (dr.threshold) gy[j] = ln_dropout4(gy[j], dr, hr, 4 * c);  // through the dropout
         s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
       }
     }

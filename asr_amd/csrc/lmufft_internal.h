@@ -62,12 +62,19 @@ int fft_conv_backward(const lmufft_shape& s, const float* gm, const void* prep, 
 // out[i] = sum_p part[p*n + i], masked by u[i] > 0 when u != NULL (defined in lmufft_f32.hip)
 int launch_sum_slabs_masked(const float* part, const float* u, float* out, long n, int P, hipStream_t st);
 
-// Dropout without a stored mask: element idx of a call is kept when a counter-based hash of (idx, the call's two
-// seeds) reaches the threshold p * 2^32 -- MurmurHash3's 32-bit finaliser applied twice.  The forward and the
-// backward of a call recompute the same decisions.  threshold = 0: no dropout.
+// Dropout without a stored mask.  The elements of a call form rows of `width` columns; columns 2c and 2c + 1 of a
+// row share one 32-bit hash and read its low / high 16 bits:
+//   pairs_per_row = (width + 1) / 2,   g = row * pairs_per_row  (64 bits),
+//   x = fmix32((lo32(g) + col / 2) ^ seed0 ^ ((hi32(g) + seed1) * 0x9E3779B1)),   fmix32 = MurmurHash3's finaliser,
+//   keep <=> ((x >> 16 (col & 1)) & 0xFFFF) >= threshold,   threshold = round(p * 65536) in [1, 65535].
+// The row part (HashRow) is computed once per row, a hash costs an add, a xor and the finaliser, and serves two
+// elements.  The forward and the backward of a call recompute the same decisions.  threshold = 0: no dropout.
 struct HashDropout {
   uint32_t seed0, seed1, threshold;
   float inv_keep;  // 1 / (1 - p)
+};
+struct HashRow {
+  uint32_t lo, c;  // lo32(g);  seed0 ^ ((hi32(g) + seed1) * 0x9E3779B1)
 };
 __device__ __forceinline__ uint32_t hash_fmix32(uint32_t x) {
   x ^= x >> 16;
@@ -77,16 +84,23 @@ __device__ __forceinline__ uint32_t hash_fmix32(uint32_t x) {
   x ^= x >> 16;
   return x;
 }
-__device__ __forceinline__ bool hash_keep(const HashDropout& dr, unsigned long long idx) {
-  const uint32_t x = hash_fmix32(hash_fmix32((uint32_t)idx ^ dr.seed0) ^ (uint32_t)(idx >> 32) ^ dr.seed1);
-  return x >= dr.threshold;
+__device__ __forceinline__ HashRow hash_row(const HashDropout& dr, unsigned long long row, unsigned pairs_per_row) {
+  const unsigned long long g = row * pairs_per_row;
+  return HashRow{(uint32_t)g, dr.seed0 ^ (((uint32_t)(g >> 32) + dr.seed1) * 0x9E3779B1u)};
+}
+__device__ __forceinline__ uint32_t hash_pair(const HashRow& hr, unsigned pair) { return hash_fmix32((hr.lo + pair) ^ hr.c); }
+__device__ __forceinline__ bool hash_keep_lo(const HashDropout& dr, uint32_t x) { return (x & 0xFFFFu) >= dr.threshold; }
+__device__ __forceinline__ bool hash_keep_hi(const HashDropout& dr, uint32_t x) { return (x >> 16) >= dr.threshold; }
+__device__ __forceinline__ bool hash_keep(const HashDropout& dr, const HashRow& hr, unsigned col) {
+  const uint32_t x = hash_pair(hr, col >> 1);
+  return (col & 1) ? hash_keep_hi(dr, x) : hash_keep_lo(dr, x);
 }
 inline HashDropout make_hash_dropout(float p_drop, uint32_t seed0, uint32_t seed1) {
   HashDropout dr;
   dr.seed0 = seed0;
   dr.seed1 = seed1;
-  const double t = (double)p_drop * 4294967296.0;
-  dr.threshold = p_drop > 0.f ? (uint32_t)(t < 1.0 ? 1.0 : (t > 4294967295.0 ? 4294967295.0 : t)) : 0u;
+  const double t = (double)p_drop * 65536.0 + 0.5;
+  dr.threshold = p_drop > 0.f ? (uint32_t)(t < 1.0 ? 1.0 : (t > 65535.0 ? 65535.0 : t)) : 0u;
   dr.inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
   return dr;
 }

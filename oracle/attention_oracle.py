@@ -47,17 +47,29 @@ def _fmix32(x):
     return x
 
 
-def dropout_keep_mask(B, H, T, p_drop, seed0, seed1):
-    """keep[b, h, i, j] (bool) for dropout probability p_drop and the call's two 32-bit seeds."""
+def hash_keep(rows, cols, width, p_drop, seed0, seed1):
+    """keep (bool, broadcast of rows and cols) of the build's mask-free dropout: the elements of a call form rows of
+    `width` columns, columns 2c and 2c + 1 share one 32-bit hash and read its low / high 16 bits:
+      g = row * ((width + 1) // 2)  (64 bits);  x = fmix32((lo32(g) + col // 2) ^ seed0 ^ ((hi32(g) + seed1) * 0x9E3779B1));
+      keep <=> ((x >> 16 (col & 1)) & 0xFFFF) >= round(p * 65536) clamped to [1, 65535]."""
+    rows, cols = np.broadcast_arrays(np.asarray(rows, dtype=np.uint64), np.asarray(cols, dtype=np.uint64))
     if p_drop <= 0:
-        return np.ones((B, H, T, T), dtype=bool)
-    thr = np.uint32(min(max(p_drop * 4294967296.0, 1.0), 4294967295.0))
-    idx = np.arange(B * H * T * T, dtype=np.uint64).reshape(B, H, T, T)
-    lo = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-    hi = (idx >> np.uint64(32)).astype(np.uint32)
+        return np.ones(rows.shape, dtype=bool)
+    thr = np.uint32(min(max(int(p_drop * 65536.0 + 0.5), 1), 65535))
     with np.errstate(over="ignore"):
-        x = _fmix32(_fmix32(lo ^ np.uint32(seed0)) ^ hi ^ np.uint32(seed1))
-    return x >= thr
+        g = rows * np.uint64((width + 1) // 2)
+        lo = (g & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        hi = (g >> np.uint64(32)).astype(np.uint32)
+        c = np.uint32(seed0) ^ ((hi + np.uint32(seed1)) * np.uint32(0x9E3779B1)).astype(np.uint32)
+        x = _fmix32((lo + (cols >> np.uint64(1)).astype(np.uint32)).astype(np.uint32) ^ c)
+    field = (x >> ((cols & np.uint64(1)).astype(np.uint32) * np.uint32(16))) & np.uint32(0xFFFF)
+    return field >= thr
+
+
+def dropout_keep_mask(B, H, T, p_drop, seed0, seed1):
+    """keep[b, h, i, j] (bool) for dropout probability p_drop and the call's two 32-bit seeds: row (b, h, i), column j."""
+    rows = np.arange(B * H * T, dtype=np.uint64).reshape(B, H, T, 1)
+    return hash_keep(rows, np.arange(T, dtype=np.uint64).reshape(1, 1, 1, T), T, p_drop, seed0, seed1)
 
 
 def attention_train(q, k, v, lengths, num_heads, keep=None, p_drop=0.0):

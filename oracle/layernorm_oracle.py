@@ -41,19 +41,12 @@ def add_layer_norm_backward(x, residual, weight, dy, eps=1e-5):
 
 
 def dropout_keep(shape, p_drop, seed0, seed1):
-    """keep[...] (bool) of the dropout that follows the layer norm in training (`self.dropout_layer(layer_norm(x))`,
+    """keep[row, col] (bool) of the dropout that follows the layer norm in training (`self.dropout_layer(layer_norm(x))`,
     src/models/lmu_encoder.py:274-277; nn.Dropout multiplies the kept elements by 1 / (1 - p)).  torch's random
-    stream cannot be reproduced by another implementation; the build decides element idx (flat, row-major) of a
-    call by MurmurHash3's 32-bit finaliser applied to idx and the call's two seeds, restated here."""
-    from .attention_oracle import _fmix32
+    stream cannot be reproduced by another implementation; the build decides an element by a hash of its row, its
+    column and the call's two seeds (attention_oracle.hash_keep restates it)."""
+    from .attention_oracle import hash_keep
 
-    n = int(np.prod(shape))
-    if p_drop <= 0:
-        return np.ones(shape, dtype=bool)
-    thr = np.uint32(min(max(p_drop * 4294967296.0, 1.0), 4294967295.0))
-    idx = np.arange(n, dtype=np.uint64)
-    lo = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-    hi = (idx >> np.uint64(32)).astype(np.uint32)
-    with np.errstate(over="ignore"):
-        x = _fmix32(_fmix32(lo ^ np.uint32(seed0)) ^ hi ^ np.uint32(seed1))
-    return (x >= thr).reshape(shape)
+    rows, C = int(np.prod(shape[:-1])), shape[-1]
+    keep = hash_keep(np.arange(rows, dtype=np.uint64)[:, None], np.arange(C, dtype=np.uint64)[None, :], C, p_drop, seed0, seed1)
+    return keep.reshape(shape)
