@@ -250,7 +250,10 @@ int lmufft_ctc_greedy(const void* enc, int dtype, const float* W, const float* b
  * src/models/lmu_encoder.py:72-90 (self.dropout at :45, :86), and what autograd derives from it.
  *   lmufft_attention_fwd_train: as lmufft_attention_fwd_ld; additionally element (b, h, query, key) of
  *   the weights is dropped with probability p_drop (kept weights scaled by 1/(1 - p_drop)), decided by a
- *   counter-based hash of the element's index and (seed0, seed1) -- no mask is stored -- and
+ *   counter-based hash of the element's row (b, h, query), its key and (seed0, seed1): with
+ *   g = row * ((T + 1) / 2) as a 64-bit number, x = fmix32((lo32(g) + key / 2) ^ seed0 ^ ((hi32(g) + seed1) * 0x9E3779B1))
+ *   (fmix32: MurmurHash3's 32-bit finaliser) and the element is kept when the low (even key) or high (odd key)
+ *   16 bits of x reach round(p_drop * 65536) -- no mask is stored -- and
  *   stats [B][H][T][2] f32 receives per query row the maximum score and 1 / sum exp(score - max).
  *   lmufft_attention_bwd: dq, dk, dv ([B][T][H*DK] with row stride ld_grad, dtype as the inputs) from
  *   q, k, v, the forward's ctx and stats, the upstream gradient dctx ([B][T][H*DK] dense) and the same
@@ -285,8 +288,9 @@ int lmufft_layernorm_bwd(const void* x, int x_dtype, const void* res, int res_dt
  * Layer norm followed by dropout (training), and its backward.  Replaces
  * `x = self.dropout_layer(layer_norm(x))`, src/models/lmu_encoder.py:274-277 (nn.Dropout, :232), as one pass
  * over HBM in each direction: the forward multiplies element (row, column) of the normalised output by
- * keep / (1 - p_drop), keep decided by the library's counter-based hash of row * C + column and the call's two
- * seeds (as lmufft_attention_fwd_train; no mask is stored); the backward sends dy through the same decisions
+ * keep / (1 - p_drop), keep decided by the library's counter-based hash of the row, the column and the call's two
+ * seeds (the function given at lmufft_attention_fwd_train with rows of C columns; no mask is stored); the backward
+ * sends dy through the same decisions
  * before the layer-norm backward above.  p_drop in [0, 1); 0 gives the plain kernels.  With p_drop > 0 `out`
  * may not alias x or res (the backward recomputes from them).
  * ---------------------------------------------------------------------- */
