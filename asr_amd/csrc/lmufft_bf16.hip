@@ -794,7 +794,8 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
                                                          const bf16_t* __restrict__ m,
                                                          const bf16_t* __restrict__ x,
                                                          const float* __restrict__ ga, float* __restrict__ slabs,
-                                                         int rows, int rows_per_split, int M, int D, int Hd) {
+                                                         int rows, int rows_per_split, int M, int D, int Hd,
+                                                         int tile_blocks = 1) {
   using TL = WgradTileB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
@@ -803,9 +804,13 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
   LMUFFT_STAMP_ADD(1, 4, -g_stamps[stamp_block() * 8 + 4]);
   LMUFFT_STAMP_ADD(1, 5, -g_stamps[stamp_block() * 8 + 5]);
   LMUFFT_STAMP_ADD(1, 6, -g_stamps[stamp_block() * 8 + 6]);
-  // all output tiles of one row range share its slices of gz and [m;x]: same XCD
+  // all output tiles of one row range share its slices of gz and [m;x]: same XCD.  When there are more tiles
+  // than an XCD should take of one range (tile_blocks > 1), a range's tiles form that many groups.
   const int tiles_j = (MD + TL::BN - 1) / TL::BN, tiles_n = (Hd + TL::BM - 1) / TL::BM;
-  const XcdSlot slot = xcd_slot(tiles_j * tiles_n);
+  const int inner = tiles_j * tiles_n / tile_blocks;
+  XcdSlot slot = xcd_slot(inner);
+  slot.member += (slot.group % tile_blocks) * inner;
+  slot.group /= tile_blocks;
   const int tile_j = slot.member % tiles_j, tile_n = slot.member / tiles_j;
   const int j0 = tile_j * TL::BN;
   const int n0 = tile_n * TL::BM;
@@ -1559,7 +1564,7 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
 // Weight and bias gradient of a Linear layer, dW[out][in] = sum_rows dy[row][out] x[row][in], db[out] = sum_rows
 // dy[row][out]: the layer's weight-gradient kernel with an empty memory block (M = 0) and no encoder gradient.
 struct LinWgradPlan {
-  int S, rps, tiles_j, tiles_n;
+  int S, rps, tiles_j, tiles_n, tile_blocks;
   long slab_floats;
   size_t off_scratch, total;
 };
@@ -1569,7 +1574,12 @@ static LinWgradPlan plan_linear_wgrad(long rows, int in, int out) {
   p.tiles_j = cdivb(in, TL::BN);
   p.tiles_n = cdivb(out, TL::BM);
   const int tiles = p.tiles_j * p.tiles_n;
-  const int S = 8 * std::max(1, 32 / tiles);
+  // One round of workgroups: an XCD (32 CUs, one workgroup each) takes whole groups of `inner` tiles.  A row range
+  // with more than 16 tiles is cut into tile_blocks groups, so that an XCD still holds several ranges' worth.
+  p.tile_blocks = 1;
+  while (tiles / p.tile_blocks > 16 || tiles % p.tile_blocks) ++p.tile_blocks;
+  const int inner = tiles / p.tile_blocks;
+  const int S = std::max(1, std::min(64, 8 * (32 / inner) / p.tile_blocks));
   int rps = cdivb(rows, S);
   rps = cdivb(rps, TL::BK) * TL::BK;
   p.S = cdivb(rows, rps);
@@ -1598,7 +1608,7 @@ int lmufft_linear_wgrad_bf16(const void* x, const void* dy, int64_t rows, int32_
   hipStream_t st = (hipStream_t)stream;
   float* wslab = (float*)workspace;
   float* scratch = (float*)((char*)workspace + p.off_scratch);  // gw_u (in) | gb_u (1) | db when the layer has no bias
-  const dim3 grid(xcd_grid(p.S, p.tiles_j * p.tiles_n));
+  const dim3 grid(xcd_grid((long)p.S * p.tile_blocks, p.tiles_j * p.tiles_n / p.tile_blocks));
   const size_t lds = std::max(2 * (sizeof(bf16_t) * (size_t)TL::BK * ((TL::BM + 32) + (TL::BN + 32)) + sizeof(float) * TL::BK),
                               sizeof(float) * (size_t)TL::BM * (TL::BN + 4));
   if (hipFuncSetAttribute((const void*)k_wgrad_bf16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -1606,7 +1616,7 @@ int lmufft_linear_wgrad_bf16(const void* x, const void* dy, int64_t rows, int32_
   {
     PROFB("k_linear_wgrad_bf16");
     hipLaunchKernelGGL(k_wgrad_bf16<true>, grid, dim3(kThreads), lds, st, (const bf16_t*)dy, (const bf16_t*)nullptr,
-                       (const bf16_t*)x, (const float*)nullptr, wslab, (int)rows, p.rps, 0, in, out);
+                       (const bf16_t*)x, (const float*)nullptr, wslab, (int)rows, p.rps, 0, in, out, p.tile_blocks);
   }
   LAUNCH_CHECKB("k_linear_wgrad_bf16");
   const SlabOutputs o{{dW, db ? db : scratch + in + 4, scratch, scratch + in},
