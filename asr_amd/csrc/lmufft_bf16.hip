@@ -128,20 +128,35 @@ __global__ __launch_bounds__(kThreads) void k_encode_fwd_bf16(const bf16_t* __re
   if (VEC) {
     // sixteen lanes per row, four rows per wave: a row is 16-byte loads of 256 contiguous bytes per
     // pass, a lane has all its loads in flight at once, and the reduction is four shuffles
+    // A workgroup takes 32 consecutive rows per step, a lane group rows g and g + 16 of them: the loads of both
+    // are issued before either is reduced.
     const int sub = lane & 15;
-    for (long row = ((long)eblock * 4 + wave) * 4 + (lane >> 4); row < rows; row += (long)eblocks * 16) {
+    for (long row = (long)eblock * 32 + wave * 4 + (lane >> 4); row < rows; row += (long)eblocks * 32) {
+      const long row2 = row + 16;
+      const bool two = row2 < rows;
       const bf16_t* xr = x + row * D;
-      float s = 0.f;
+      const bf16_t* xr2 = x + (two ? row2 : row) * D;
+      float s = 0.f, s2 = 0.f;
       for (int c = sub * 8; c < D; c += 128) {
         const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xr + c);
+        const bf16x8 xv2 = *reinterpret_cast<const bf16x8*>(xr2 + c);
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(w_u + c);
         const f32x4 w1 = *reinterpret_cast<const f32x4*>(w_u + c + 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s += (float)xv[j] * w0[j] + (float)xv[4 + j] * w1[j];
+        for (int j = 0; j < 4; ++j) {
+          s += (float)xv[j] * w0[j] + (float)xv[4 + j] * w1[j];
+          s2 += (float)xv2[j] * w0[j] + (float)xv2[4 + j] * w1[j];
+        }
       }
 #pragma unroll
-      for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off);
-      if (sub == 0) u[row] = fmaxf(s + bias, 0.f);
+      for (int off = 8; off > 0; off >>= 1) {
+        s += __shfl_xor(s, off);
+        s2 += __shfl_xor(s2, off);
+      }
+      if (sub == 0) {
+        u[row] = fmaxf(s + bias, 0.f);
+        if (two) u[row2] = fmaxf(s2 + bias, 0.f);
+      }
     }
   } else {
     for (int row = eblock * 4 + wave; row < rows; row += eblocks * 4) {
@@ -1314,7 +1329,7 @@ static int forward_bf16_impl(const lmufft_shape* s, const void* x_, const float*
     int prep_blocks = 0;
     WeightPrep prep{nullptr, nullptr, nullptr, 0, 0, 0, 0};
     if (W_h) prep = weight_prep(*s, W_h, wprep, &prep_blocks);
-    const dim3 grid(prep_blocks + min(cdivb(rows, vec ? 16 : 4), 4096));
+    const dim3 grid(prep_blocks + min(cdivb(rows, vec ? 32 : 4), 4096));
     PROFB("k_encode_fwd_bf16");
     if (vec)
       hipLaunchKernelGGL(k_encode_fwd_bf16<true>, grid, dim3(kThreads), 0, st, x, w_u, b_u, u, (int)rows, s->D, prep,
