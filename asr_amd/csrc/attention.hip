@@ -629,9 +629,9 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? (TRAIN ? 3 : 4) : 1) void k_att
         psum += pv0 + pv1;
         if (TRAIN && dr.threshold) {  // the normaliser keeps every weight; the context only the surviving ones
           const int j = j0 + 32 * kt + (i & 3) + 8 * (i >> 2) + 4 * hh;
-          const uint32_t x = hash_pair(hrow, (unsigned)j >> 1);
-          pv0 = hash_keep_lo(dr, x) ? pv0 * dr.inv_keep : 0.f;
-          pv1 = hash_keep_hi(dr, x) ? pv1 * dr.inv_keep : 0.f;
+          const uint32_t x = hash_pair(hrow, (unsigned)j >> 1);  // (the 1 / (1 - p) is applied with 1 / l at the end)
+          pv0 = hash_keep_lo(dr, x) ? pv0 : 0.f;
+          pv1 = hash_keep_hi(dr, x) ? pv1 : 0.f;
         }
         pf[kt][i >> 3][i & 7] = (attn_bf16)pv0;
         pf[kt][i >> 3][(i & 7) + 1] = (attn_bf16)pv1;
@@ -667,12 +667,13 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? (TRAIN ? 3 : 4) : 1) void k_att
         }
   }
 
-  const float inv = 1.0f / l_run;
+  float inv = 1.0f / l_run;
   if (TRAIN && hh == 0 && qi < T) {
     float* sp = stats + 2 * ((((long)b * H + h) * T) + qi);
     sp[0] = m_run;
     sp[1] = inv;
   }
+  if (TRAIN) inv *= dr.inv_keep;
   float* ws = Os + wave * 8 * OP;  // wave-private strip of 8 queries
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
@@ -750,10 +751,13 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 2 : 1) void k_attention_bwd_dq_
   }
   D += __shfl_xor(D, 32);
   if (hh == 0 && qi < T) dsum[bh * T + qi] = D;
-  const float m2 = stats[2 * (bh * T + qc)], invl = stats[2 * (bh * T + qc) + 1];
+  // With W = keep p / (1 - p):  dS = p (dW - D) / sqrt(dk) = [p / (1 - p)] ([keep ? dP : 0] - (1 - p) D) / sqrt(dk):
+  // the 1 / (1 - p) rides on 1 / l, D is scaled once, and 1 / sqrt(dk) is applied to the accumulated dQ.
+  const float m2 = stats[2 * (bh * T + qc)], invl = stats[2 * (bh * T + qc) + 1] * dr.inv_keep;
+  const float Dk = D / dr.inv_keep;
   const float scale2 = scale * 1.4426950408889634f;
-  constexpr float kMasked2 = -1e9f * 1.4426950408889634f;
   const int tq = (lane & 15) >> 2, tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const bool all_q_valid = __all(q_valid);
 
   attn_f16v dqa[DT];
 #pragma unroll
@@ -809,19 +813,25 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 2 : 1) void k_attention_bwd_dq_
       dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[s], dp, 0, 0, 0);
     }
     attn_bf16x8 dsf[2];
+    const bool interior = all_q_valid && j0 + 32 <= len;  // wave-uniform: no mask tests on such tiles
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int j = j0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-      const bool inside = q_valid && j < len;
-      const float pv = j < T ? __builtin_amdgcn_exp2f((inside ? st[i] * scale2 : kMasked2) - m2) * invl : 0.f;
       float dw = dp[i];
       if (dr.threshold) {  // registers i, i + 1 (i even) are the two keys of one hash
         uint32_t x = 0;
         if ((i & 1) == 0) x = xpair = hash_pair(hrow, (unsigned)j >> 1);
         else x = xpair;
-        dw = ((i & 1) ? hash_keep_hi(dr, x) : hash_keep_lo(dr, x)) ? dw * dr.inv_keep : 0.f;
+        dw = ((i & 1) ? hash_keep_hi(dr, x) : hash_keep_lo(dr, x)) ? dw : 0.f;
       }
-      dsf[i >> 3][i & 7] = (attn_bf16)(inside ? pv * (dw - D) * scale : 0.f);
+      float ds;
+      if (interior) {
+        ds = __builtin_amdgcn_exp2f(__builtin_fmaf(st[i], scale2, -m2)) * invl * (dw - Dk);
+      } else {
+        const bool inside = q_valid && j < len;
+        ds = inside ? __builtin_amdgcn_exp2f(st[i] * scale2 - m2) * invl * (dw - Dk) : 0.f;
+      }
+      dsf[i >> 3][i & 7] = (attn_bf16)ds;
     }
     // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
 #pragma unroll
@@ -840,7 +850,7 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 2 : 1) void k_attention_bwd_dq_
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int d = 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
-        if ((r >> 3) == pass) ws[(r & 7) * OP + d] = dqa[t][i];
+        if ((r >> 3) == pass) ws[(r & 7) * OP + d] = dqa[t][i] * scale;
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     for (int idx = lane; idx < 8 * DK; idx += 64) {
@@ -864,7 +874,7 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 2 : 1) void k_attention_bwd_dkv
   __shared__ __attribute__((aligned(16))) attn_bf16 Gs[32 * KP];
   __shared__ __attribute__((aligned(16))) attn_bf16 Qt[32 * VP];
   __shared__ __attribute__((aligned(16))) attn_bf16 Gt[32 * VP];
-  __shared__ float Ms[32], Ls[32], Ds[32];
+  __shared__ __attribute__((aligned(16))) float Ms[32], Ls[32], Ds[32];
   __shared__ float Os[NW * 8 * OP];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -876,6 +886,7 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 2 : 1) void k_attention_bwd_dkv
   const long bh = (long)b * H + h;
   const int kj = blockIdx.x * (32 * NW) + wave * 32 + r;
   const bool k_valid = kj < len;
+  const bool all_k_valid = __all(k_valid);
   const int kc = min(kj, T - 1);
 
   attn_bf16x8 kf[NS], vf[NS];
@@ -927,10 +938,10 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 2 : 1) void k_attention_bwd_dkv
         *reinterpret_cast<attn_bf16x8*>(&Gt[row * VP + c]) = gst[n];
       }
     }
-    if (tid < 32) {
+    if (tid < 32) {  // 1 / (1 - p) rides on 1 / l, D is scaled once (see k_attention_bwd_dq_bf16)
       Ms[tid] = mst;
-      Ls[tid] = lst;
-      Ds[tid] = dst;
+      Ls[tid] = lst * dr.inv_keep;
+      Ds[tid] = dst / dr.inv_keep;
     }
   };
 
@@ -969,15 +980,30 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 2 : 1) void k_attention_bwd_dkv
         xq[i + 1] = odd ? mine : other;
       }
     }
+    const bool interior = all_k_valid && i0 + 32 <= len;  // wave-uniform: no mask tests on such tiles
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = (i & 3) + 8 * (i >> 2) + 4 * hh, qq = i0 + row;
-      const bool inside = qq < len && k_valid;
-      const float pv = __builtin_amdgcn_exp2f((inside ? st[i] * scale2 : kMasked2) - Ms[row]) * Ls[row];
-      const bool keep = dr.threshold ? ((kj & 1) ? hash_keep_hi(dr, xq[i]) : hash_keep_lo(dr, xq[i])) : true;
-      const float dw = keep ? dp[i] * dr.inv_keep : 0.f;
-      wf[i >> 3][i & 7] = (attn_bf16)(keep ? pv * dr.inv_keep : 0.f);
-      dsf[i >> 3][i & 7] = (attn_bf16)(inside ? pv * (dw - Ds[row]) * scale : 0.f);
+    for (int g = 0; g < 4; ++g) {
+      // registers 4g .. 4g + 3 are four consecutive query rows: their statistics come as three 16-byte reads
+      const int row0 = 8 * g + 4 * hh;
+      const attn_f4 m4 = *reinterpret_cast<const attn_f4*>(&Ms[row0]);
+      const attn_f4 l4 = *reinterpret_cast<const attn_f4*>(&Ls[row0]);
+      const attn_f4 d4 = *reinterpret_cast<const attn_f4*>(&Ds[row0]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * g + e;
+        const bool keep = dr.threshold ? ((kj & 1) ? hash_keep_hi(dr, xq[i]) : hash_keep_lo(dr, xq[i])) : true;
+        float pv;
+        bool inside = true;
+        if (interior) {
+          pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[i], scale2, -m4[e])) * l4[e];
+        } else {
+          inside = i0 + row0 + e < len && k_valid;
+          pv = __builtin_amdgcn_exp2f((inside ? st[i] * scale2 : kMasked2) - m4[e]) * l4[e];
+        }
+        const float dw = keep ? dp[i] : 0.f;
+        wf[i >> 3][i & 7] = (attn_bf16)(keep ? pv : 0.f);
+        dsf[i >> 3][i & 7] = (attn_bf16)(inside ? pv * (dw - d4[e]) : 0.f);
+      }
     }
     // dV^T[d][key] += dO^T[d][query] W[query][key];  dK^T[d][key] += Q^T[d][query] dS[query][key]
 #pragma unroll
@@ -1001,7 +1027,7 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 2 : 1) void k_attention_bwd_dkv
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int d = 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
-          if ((r >> 3) == pass) ws[(r & 7) * OP + d] = which ? dva[t][i] : dka[t][i];
+          if ((r >> 3) == pass) ws[(r & 7) * OP + d] = which ? dva[t][i] : dka[t][i] * scale;
         }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       for (int idx = lane; idx < 8 * DK; idx += 64) {
