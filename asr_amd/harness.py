@@ -23,7 +23,8 @@ from torch import nn
 from .attention import (SUPPORTED_HEAD_WIDTHS, masked_attention, masked_attention_packed, masked_attention_train,
                         masked_attention_train_packed)
 from .layernorm import MAX_WIDTH as _LN_MAX_WIDTH, add_layer_norm, add_layer_norm_train
-from .linear import linear_bf16, linear_train, supported as linear_supported, train_supported as linear_train_supported
+from .linear import (fused_linear_train, linear_bf16, linear_train, supported as linear_supported,
+                     train_supported as linear_train_supported)
 from .ctc import CTCDecoder
 from .lmu import LMUFFT
 
@@ -189,7 +190,7 @@ class _MultiHeadAttention(nn.Module):
                 # one GEMM for the three projections in both directions: x is cast and read once, the three input
                 # gradients arrive summed; the attention kernels read and write column blocks of its output
                 _took("hip", "qkv_projection")
-                packed = linear_train(x, torch.cat([l.weight for l in qkv]), torch.cat([l.bias for l in qkv]))
+                packed = fused_linear_train(x, qkv)
                 ctx = masked_attention_train_packed(packed, self.num_heads, lengths, p_drop)
             else:
                 q, k, v = _linear(self.w_q, x), _linear(self.w_k, x), _linear(self.w_v, x)
@@ -296,6 +297,23 @@ class LMUASRModel(nn.Module):
         """Greedy CTC token lists (the reference's decode(log_probs, input_lengths, beam_width=1))."""
         encoded, _ = self.encoder(spectrograms, input_lengths)
         return self.decoder.decode(encoded, input_lengths)
+
+    def bucket_groups(self) -> list:
+        """Parameter groups for asr_amd.parallel.GradBuckets in the order the backward completes them (head first,
+        input projection last).  Inside an attention block the q, k, v weights come first and back to back, then their
+        biases: the fused projection's weight gradient is then one kernel writing straight into the bucket."""
+        enc = self.encoder
+        groups = [[*self.decoder.parameters(), *enc.output_projection.parameters()]]
+        for i in reversed(range(len(enc.lmu_layers))):
+            groups.append(list(enc.layer_norms[i].parameters()))
+            groups.append(enc.lmu_layers[i])
+            if enc.use_attention:
+                a = enc.attention_layers[i].attention
+                qkv = (a.w_q, a.w_k, a.w_v)
+                groups.append([*(l.weight for l in qkv), *(l.bias for l in qkv if l.bias is not None),
+                               *a.w_o.parameters(), *a.layer_norm.parameters()])
+        groups.append(list(enc.input_projection.parameters()))
+        return groups
 
     def log_probs_for_training(self, spectrograms: torch.Tensor, input_lengths: Optional[torch.Tensor] = None):
         """Log-probabilities with an autograd graph (the reference's LMUASRModel.forward in training,

@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from .parallel import adopt, grad_slot
+from .parallel import adopt, fused_slot, grad_slot
 
 _DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
 FUSED_LAYER_NORM_MAX_WIDTH = 384
@@ -183,6 +183,57 @@ class _LinearTrain(torch.autograd.Function):
                 dW = dW[:n]
                 db = None if db is None else db[:n]
         return dx, dW, db
+
+
+class _FusedLinearTrain(torch.autograd.Function):
+    """Several nn.Linear layers on one input as ONE product over their concatenated weights (w_q, w_k, w_v of
+    src/models/lmu_encoder.py:41-43, 68-70): y = x [W_1; W_2; ...]^T, one input-gradient GEMM, one weight-gradient
+    launch.  When the layers' slices of a gradient bucket lie back to back (weights in this order, then biases in
+    this order), the weight gradient is written straight into them."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        weights, biases = params[0::2], params[1::2]
+        xb = x.to(torch.bfloat16)
+        w16 = torch.cat([w.detach() for w in weights]).to(torch.bfloat16)
+        b32 = torch.cat([b.detach() for b in biases]).to(torch.bfloat16).float()
+        ctx.save_for_backward(xb, w16)
+        ctx.x_dtype = x.dtype
+        ctx.params = (weights, biases)
+        return linear_bf16(xb, w16, b32)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, w16 = ctx.saved_tensors
+        weights, biases = ctx.params
+        dyb = dy.to(torch.bfloat16).contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = linear_bf16(dyb, w16.t().contiguous()).to(ctx.x_dtype)
+        fw = fused_slot(weights)
+        fb = fused_slot(biases)
+        dW, db = linear_weight_grad_bf16(xb, dyb, True, None if fw is None else fw[0], None if fb is None else fb[0])
+        rows = [w.shape[0] for w in weights]
+        gw = [adopt(s) for s in fw[1]] if fw is not None else list(torch.split(dW, rows))
+        gb = [adopt(s) for s in fb[1]] if fb is not None else list(torch.split(db, rows))
+        out = [dx]
+        for a, b in zip(gw, gb):
+            out += [a, b]
+        return tuple(out)
+
+
+def fused_linear_train(x: torch.Tensor, layers) -> torch.Tensor:
+    """[layer(x) for layer in layers] concatenated along the last dimension, as bf16 autocast computes them, with
+    autograd, on HIP kernels.  Every layer needs a bias and the same input width."""
+    layers = list(layers)
+    if not layers or any(l.bias is None for l in layers) or not all(train_supported(x, l.weight) for l in layers) \
+            or any(l.weight.shape[0] % 8 for l in layers):
+        raise RuntimeError("fused_linear_train: needs GPU tensors and float32 Linear layers with biases, one input width "
+                           "(a multiple of 8) and output widths that are multiples of 8")
+    params = []
+    for l in layers:
+        params += [l.weight, l.bias]
+    return _FusedLinearTrain.apply(x, *params)
 
 
 def train_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:

@@ -53,6 +53,30 @@ def adopt(slot: torch.Tensor) -> torch.Tensor:
     return slot.view(slot.shape)
 
 
+def release_slot(p) -> None:
+    """Hands back a slice obtained from grad_slot that was not written after all."""
+    if hasattr(p, "_grad_view"):
+        p._grad_view_free = True
+
+
+def fused_slot(params):
+    """(one tensor [sum of rows, ...] over the bucket slices of `params`, the slices) when all of them are free and
+    lie back to back in the bucket in this order (the slices are then taken); else None (nothing is taken)."""
+    slots = [grad_slot(p) for p in params]
+    ok = all(s is not None for s in slots)
+    if ok:
+        for a, b in zip(slots, slots[1:]):
+            ok = ok and b.data_ptr() == a.data_ptr() + a.numel() * a.element_size() and a.shape[1:] == b.shape[1:]
+    if not ok:
+        for p, s in zip(params, slots):
+            if s is not None:
+                release_slot(p)
+        return None
+    first = slots[0]
+    shape = (sum(s.shape[0] for s in slots),) + tuple(first.shape[1:])
+    return first.as_strided(shape, first.stride()), slots
+
+
 def _group_params(grp):
     module = grp if isinstance(grp, torch.nn.Module) else None
     params = [p for p in (module.parameters() if module is not None else grp) if p.requires_grad]

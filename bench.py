@@ -305,11 +305,7 @@ def bench_full_step(args, dev, rank, world):
             torch.nn.init.zeros_(mod.bias)
     enc = model.encoder
     enc.bf16_stream = bool(args.bf16_stream)
-    groups = [[*model.decoder.parameters(), *enc.output_projection.parameters()]]
-    for i in reversed(range(args.layers)):  # the order in which the backward completes them
-        groups += [list(enc.layer_norms[i].parameters()), enc.lmu_layers[i], list(enc.attention_layers[i].parameters())]
-    groups.append(list(enc.input_projection.parameters()))
-    buckets = GradBuckets(groups, bucket_mb=args.bucket_mb if args.bucket_mb is not None else 4.0,
+    buckets = GradBuckets(model.bucket_groups(), bucket_mb=args.bucket_mb if args.bucket_mb is not None else 4.0,
                           overlap=not args.no_overlap)
     opt = FlatAdamW(buckets=buckets, lr=1.5e-3, betas=(0.9, 0.999), weight_decay=0.01, max_grad_norm=10.0)
     sched = LearningRateScheduler(opt, warmup_steps=1500, max_lr=1.5e-3)

@@ -253,3 +253,41 @@ def test_training_linear_writes_into_gradient_buckets():
             want = [p.grad for p in (a2.weight, a2.bias, head2.weight, head2.bias)]
         for g, w in zip(got, want):
             assert torch.allclose(g, w, rtol=1e-6, atol=1e-6 * float(w.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("adjacent", [True, False])
+def test_fused_linear_train_matches_the_separate_layers(adjacent):
+    """w_q, w_k, w_v as one product: outputs bitwise those of the three layers (the same kernel on column blocks),
+    the input gradient one K = 3C product instead of three rounded ones (bf16 bar), the weight and bias gradients
+    those of the separate layers to fp32 accumulation order; with the slices back to back in a gradient bucket the
+    kernel writes them in place, otherwise they arrive by copy."""
+    from asr_amd.linear import fused_linear_train, linear_train
+    from asr_amd.parallel import GradBuckets
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    C, rows = 384, 1500
+    layers = [torch.nn.Linear(C, C).to(dev) for _ in range(3)]
+    ref = [torch.nn.Linear(C, C).to(dev) for _ in range(3)]
+    for a, b in zip(layers, ref):
+        b.load_state_dict(a.state_dict())
+    order = [l.weight for l in layers] + [l.bias for l in layers] if adjacent else [p for l in layers for p in l.parameters()]
+    buckets = GradBuckets([order], overlap=False)
+    x = torch.randn(rows, C, device=dev)
+    go = torch.randn(rows, 3 * C, device=dev).to(torch.bfloat16)
+    buckets.zero_grad()
+    xa = x.clone().requires_grad_(True)
+    ya = fused_linear_train(xa, layers)
+    ya.backward(go)
+    buckets.finish()
+    xb = x.clone().requires_grad_(True)
+    yb = torch.cat([linear_train(xb, l.weight, l.bias) for l in ref], dim=-1)
+    yb.backward(go)
+    assert torch.equal(ya, yb)
+    assert torch.allclose(xa.grad, xb.grad, rtol=2.0 ** -6, atol=2.0 ** -6 * float(xb.grad.abs().max()))
+    for a, b, views in zip(layers, ref, range(3)):
+        assert torch.allclose(a.weight.grad, b.weight.grad, rtol=1e-4, atol=1e-4 * float(b.weight.grad.abs().max()))
+        assert torch.allclose(a.bias.grad, b.bias.grad, rtol=1e-4, atol=1e-4 * float(b.bias.grad.abs().max()))
+    lo, hi = buckets.arena.data_ptr(), buckets.arena.data_ptr() + buckets.arena.numel() * 4
+    assert all(lo <= p.grad.data_ptr() < hi for l in layers for p in l.parameters())
