@@ -19,7 +19,7 @@ CONV_AUTO = 0
 CONV_TOEPLITZ = 1
 CONV_FFT = 2
 NOALLOC_SCRATCH_BYTES = 8 << 20
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class Shape(ctypes.Structure):
@@ -123,10 +123,10 @@ def _load():
     lib.lmufft_layernorm_bwd.restype = ci
     lib.lmufft_layernorm_bwd.argtypes = [vp, ci, vp, ci, vp, ci, vp, f32, i64, i32, vp, vp, vp, vp, vp, sz, vp]
     lib.lmufft_add_layernorm_dropout.restype = ci
-    lib.lmufft_add_layernorm_dropout.argtypes = [vp, ci, vp, ci, vp, vp, f32, i64, i32, vp, ci, f32, u32, u32, vp]
+    lib.lmufft_add_layernorm_dropout.argtypes = [vp, ci, vp, ci, vp, vp, f32, i64, i32, vp, ci, f32, u32, u32, vp, vp]
     lib.lmufft_layernorm_dropout_bwd.restype = ci
-    lib.lmufft_layernorm_dropout_bwd.argtypes = [vp, ci, vp, ci, vp, ci, vp, f32, i64, i32, f32, u32, u32, vp, vp, vp, vp,
-                                                 vp, sz, vp]
+    lib.lmufft_layernorm_dropout_bwd.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, vp, f32, i64, i32, f32, u32, u32, vp, vp,
+                                                 vp, vp, vp, sz, vp]
     lib.lmufft_linear_wgrad_workspace_bytes.restype = sz
     lib.lmufft_linear_wgrad_workspace_bytes.argtypes = [i64, i32, i32]
     lib.lmufft_linear_wgrad_bf16.restype = ci

@@ -74,7 +74,8 @@ template <bool XB, int RES, bool OB, int NG, bool DROP = false>
 __global__ __launch_bounds__(kLnThreads) void k_add_layernorm(const void* x, const void* res,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float eps, long rows,
-                                                              int C, void* out, HashDropout dr = HashDropout{0, 0, 0, 1.f}) {
+                                                              int C, void* out, HashDropout dr = HashDropout{0, 0, 0, 1.f},
+                                                              void* twin = nullptr) {
   const int sub = threadIdx.x & 31;                                  // lane inside the row's half-wave
   const long row0 = (long)blockIdx.x * (kLnThreads / 32) + (threadIdx.x >> 5);
   const long row_step = (long)gridDim.x * (kLnThreads / 32);
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(kLnThreads) void k_add_layernorm(const void* x, con
         ln_f32x4 y = v[j] * rstd * g[j] + bt[j];
         if (DROP) y = ln_dropout4(y, dr, hr, 4 * c);
         ln_store4<OB>(out, row * C + 4 * c, y);
+        if (!OB && twin) ln_store4<true>(twin, row * C + 4 * c, y);  // the same values rounded to bf16
       }
     }
   }
@@ -132,15 +134,15 @@ __global__ __launch_bounds__(kLnThreads) void k_add_layernorm(const void* x, con
 
 template <bool XB, int RES, bool OB>
 static void launch_ln(int ng, dim3 grid, hipStream_t st, const void* x, const void* res, const float* gamma,
-                      const float* beta, float eps, long rows, int C, void* out, const HashDropout& dr) {
+                      const float* beta, float eps, long rows, int C, void* out, const HashDropout& dr, void* twin) {
 #define LN_CASE(NGV)                                                                                                  \
   do {                                                                                                                \
     if (dr.threshold)                                                                                                 \
       hipLaunchKernelGGL((k_add_layernorm<XB, RES, OB, NGV, true>), grid, dim3(kLnThreads), 0, st, x, res, gamma,     \
-                         beta, eps, rows, C, out, dr);                                                                \
+                         beta, eps, rows, C, out, dr, twin);                                                          \
     else                                                                                                              \
       hipLaunchKernelGGL((k_add_layernorm<XB, RES, OB, NGV, false>), grid, dim3(kLnThreads), 0, st, x, res, gamma,    \
-                         beta, eps, rows, C, out, dr);                                                                \
+                         beta, eps, rows, C, out, dr, twin);                                                          \
   } while (0)
   if (ng <= 1) LN_CASE(1);
   else if (ng <= 2) LN_CASE(2);
@@ -176,7 +178,7 @@ template <int NG>
 __global__ __launch_bounds__(kLnThreads) void k_layernorm_bwd(const void* x, int xb, const void* res, int rb, const void* dy,
                                                               int gb, const float* __restrict__ gamma, float eps, long rows,
                                                               int C, void* dx, void* dres, float* __restrict__ partial,
-                                                              HashDropout dr) {
+                                                              HashDropout dr, const void* dy2, int g2b) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [8 row slots][2][C]
   const int sub = threadIdx.x & 31, slot = threadIdx.x >> 5;
   const long row0 = (long)blockIdx.x * (kLnThreads / 32) + slot;
@@ -202,6 +204,7 @@ __global__ __launch_bounds__(kLnThreads) void k_layernorm_bwd(const void* x, int
         v[j] = ln_load4_rt(x, row * C + 4 * c, xb);
         if (res) v[j] += ln_load4_rt(res, row * C + 4 * c, rb);
         gy[j] = ln_load4_rt(dy, row * C + 4 * c, gb);
+        if (dy2) gy[j] += ln_load4_rt(dy2, row * C + 4 * c, g2b);  // the gradient of the output's second copy
         if (dr.threshold) gy[j] = ln_dropout4(gy[j], dr, hr, 4 * c);  // through the dropout
         s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
       }
@@ -292,7 +295,7 @@ using namespace lmufft;
 
 static int add_layernorm_any(const void* x, int x_dtype, const void* res, int res_dtype, const float* gamma,
                             const float* beta, float eps, int64_t rows, int32_t C, void* out, int out_dtype,
-                            const HashDropout& dr, void* stream) {
+                            const HashDropout& dr, void* twin, void* stream) {
   if (rows < 0 || C <= 0) return set_error("layernorm: bad shape (rows=%lld C=%d)", (long long)rows, C);
   if (C % 4 != 0 || C > 32 * 4 * kLnMaxGroups)
     return set_error("layernorm: width %d (needs a multiple of 4, at most %d)", C, 32 * 4 * kLnMaxGroups);
@@ -300,6 +303,8 @@ static int add_layernorm_any(const void* x, int x_dtype, const void* res, int re
   if (!known(x_dtype) || !known(out_dtype) || (res && !known(res_dtype))) return set_error("layernorm: unknown dtype");
   if (rows == 0) return 0;
   if (!x || !gamma || !beta || !out) return set_error("layernorm: NULL pointer");
+  if (twin && (out_dtype != LMUFFT_F32 || (reinterpret_cast<uintptr_t>(twin) & 7) != 0 || twin == x || twin == res))
+    return set_error("layernorm: the bf16 twin needs a float32 `out`, 8-byte alignment and memory of its own");
   auto aligned = [](const void* p, int dtype) {
     return (reinterpret_cast<uintptr_t>(p) & (dtype == LMUFFT_F32 ? 15 : 7)) == 0;
   };
@@ -317,7 +322,7 @@ static int add_layernorm_any(const void* x, int x_dtype, const void* res, int re
   const int rk = !res ? 0 : (res_dtype == LMUFFT_BF16 ? 2 : 1);
   {
     ProfScope ps("k_add_layernorm", st);
-#define LN_GO(XBV, RV, OBV) launch_ln<XBV, RV, OBV>(ng, grid, st, x, res, gamma, beta, eps, (long)rows, C, out, dr)
+#define LN_GO(XBV, RV, OBV) launch_ln<XBV, RV, OBV>(ng, grid, st, x, res, gamma, beta, eps, (long)rows, C, out, dr, twin)
 #define LN_RES(XBV, OBV)          \
   do {                            \
     if (rk == 0) LN_GO(XBV, 0, OBV); \
@@ -340,18 +345,19 @@ extern "C" int lmufft_add_layernorm(const void* x, int x_dtype, const void* res,
                                     const float* beta, float eps, int64_t rows, int32_t C, void* out, int out_dtype,
                                     void* stream) {
   return add_layernorm_any(x, x_dtype, res, res_dtype, gamma, beta, eps, rows, C, out, out_dtype,
-                           make_hash_dropout(0.f, 0, 0), stream);
+                           make_hash_dropout(0.f, 0, 0), nullptr, stream);
 }
 
 extern "C" int lmufft_add_layernorm_dropout(const void* x, int x_dtype, const void* res, int res_dtype, const float* gamma,
                                             const float* beta, float eps, int64_t rows, int32_t C, void* out,
-                                            int out_dtype, float p_drop, uint32_t seed0, uint32_t seed1, void* stream) {
+                                            int out_dtype, float p_drop, uint32_t seed0, uint32_t seed1, void* out_bf16,
+                                            void* stream) {
   if (!(p_drop >= 0.f && p_drop < 1.f)) return set_error("layernorm: dropout probability %g outside [0, 1)", (double)p_drop);
   if (out == x || (res && out == res)) {
     if (p_drop > 0.f) return set_error("layernorm with dropout: the backward recomputes from x and res; out may not alias them");
   }
   return add_layernorm_any(x, x_dtype, res, res_dtype, gamma, beta, eps, rows, C, out, out_dtype,
-                           make_hash_dropout(p_drop, seed0, seed1), stream);
+                           make_hash_dropout(p_drop, seed0, seed1), out_bf16, stream);
 }
 
 extern "C" size_t lmufft_layernorm_bwd_workspace_bytes(int32_t C) {
@@ -361,12 +367,13 @@ extern "C" size_t lmufft_layernorm_bwd_workspace_bytes(int32_t C) {
 extern "C" int lmufft_layernorm_bwd(const void* x, int x_dtype, const void* res, int res_dtype, const void* dy, int dy_dtype,
                                     const float* gamma, float eps, int64_t rows, int32_t C, void* dx, void* dres,
                                     float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
-  return lmufft_layernorm_dropout_bwd(x, x_dtype, res, res_dtype, dy, dy_dtype, gamma, eps, rows, C, 0.f, 0, 0, dx, dres,
-                                      dgamma, dbeta, workspace, workspace_bytes, stream);
+  return lmufft_layernorm_dropout_bwd(x, x_dtype, res, res_dtype, dy, dy_dtype, nullptr, 0, gamma, eps, rows, C, 0.f, 0, 0,
+                                      dx, dres, dgamma, dbeta, workspace, workspace_bytes, stream);
 }
 
 extern "C" int lmufft_layernorm_dropout_bwd(const void* x, int x_dtype, const void* res, int res_dtype, const void* dy,
-                                            int dy_dtype, const float* gamma, float eps, int64_t rows, int32_t C,
+                                            int dy_dtype, const void* dy2, int dy2_dtype, const float* gamma, float eps,
+                                            int64_t rows, int32_t C,
                                             float p_drop, uint32_t seed0, uint32_t seed1, void* dx, void* dres,
                                             float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
                                             void* stream) {
@@ -376,7 +383,8 @@ extern "C" int lmufft_layernorm_dropout_bwd(const void* x, int x_dtype, const vo
   if (C % 4 != 0 || C > 32 * 4 * kLnMaxGroups)
     return set_error("layernorm backward: width %d (needs a multiple of 4, at most %d)", C, 32 * 4 * kLnMaxGroups);
   auto known = [](int d) { return d == LMUFFT_F32 || d == LMUFFT_BF16; };
-  if (!known(x_dtype) || !known(dy_dtype) || (res && !known(res_dtype))) return set_error("layernorm backward: unknown dtype");
+  if (!known(x_dtype) || !known(dy_dtype) || (res && !known(res_dtype)) || (dy2 && !known(dy2_dtype)))
+    return set_error("layernorm backward: unknown dtype");
   if (!x || !dy || !gamma || !dx || !dgamma || !dbeta || !workspace) return set_error("layernorm backward: NULL pointer");
   if (dres && !res) return set_error("layernorm backward: dres without res");
   if (workspace_bytes < lmufft_layernorm_bwd_workspace_bytes(C))
@@ -386,7 +394,8 @@ extern "C" int lmufft_layernorm_dropout_bwd(const void* x, int x_dtype, const vo
     return (reinterpret_cast<uintptr_t>(p) & (dtype == LMUFFT_F32 ? 15 : 7)) == 0;
   };
   if (!aligned(x, x_dtype) || !aligned(dx, x_dtype) || !aligned(dy, dy_dtype) || (res && !aligned(res, res_dtype)) ||
-      (dres && !aligned(dres, res_dtype)) || !aligned(gamma, LMUFFT_F32) || !aligned(workspace, LMUFFT_F32))
+      (dres && !aligned(dres, res_dtype)) || (dy2 && !aligned(dy2, dy2_dtype)) || !aligned(gamma, LMUFFT_F32) ||
+      !aligned(workspace, LMUFFT_F32))
     return set_error("layernorm backward: rows must start on 16-byte (f32) / 8-byte (bf16) boundaries");
   hipStream_t st = (hipStream_t)stream;
   const int ng = (C / 4 + 31) / 32;
@@ -398,7 +407,8 @@ extern "C" int lmufft_layernorm_dropout_bwd(const void* x, int x_dtype, const vo
     ProfScope ps("k_layernorm_bwd", st);
 #define LN_BWD(NGV)                                                                                                    \
   hipLaunchKernelGGL((k_layernorm_bwd<NGV>), dim3(nb), dim3(kLnThreads), lds, st, x, x_dtype == LMUFFT_BF16, res,         \
-                     res_dtype == LMUFFT_BF16, dy, dy_dtype == LMUFFT_BF16, gamma, eps, (long)rows, C, dx, dres, partial, dr)
+                     res_dtype == LMUFFT_BF16, dy, dy_dtype == LMUFFT_BF16, gamma, eps, (long)rows, C, dx, dres, partial, dr, \
+                     dy2, dy2_dtype == LMUFFT_BF16)
     if (ng <= 1) LN_BWD(1);
     else if (ng <= 2) LN_BWD(2);
     else if (ng <= 3) LN_BWD(3);

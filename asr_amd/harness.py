@@ -128,12 +128,12 @@ def _qkv_projection(wq: nn.Linear, wk: nn.Linear, wv: nn.Linear, x: torch.Tensor
 
 
 def _layer_norm(ln: nn.LayerNorm, x: torch.Tensor, residual: Optional[torch.Tensor] = None,
-                out_dtype: Optional[torch.dtype] = None, dropout: Optional[nn.Dropout] = None) -> torch.Tensor:
+                out_dtype: Optional[torch.dtype] = None, dropout: Optional[nn.Dropout] = None, twin: bool = False):
     """dropout(ln(x + residual)): the one-pass HIP kernels on the GPU (the dropout rides on the same pass), torch
-    otherwise."""
+    otherwise.  `twin`: returns (float32 result, its bfloat16 rounding) -- from the same pass on the training path."""
     C = x.shape[-1]
     p_drop = dropout.p if (dropout is not None and dropout.training) else 0.0
-    if (x.is_cuda and not torch.is_grad_enabled() and p_drop == 0.0 and ln.elementwise_affine and ln.bias is not None
+    if (x.is_cuda and not torch.is_grad_enabled() and p_drop == 0.0 and not twin and ln.elementwise_affine and ln.bias is not None
             and C % 4 == 0 and C <= _LN_MAX_WIDTH and x.dtype in (torch.float32, torch.bfloat16)
             and (residual is None or residual.dtype in (torch.float32, torch.bfloat16))):
         _took("hip", "layer_norm")
@@ -142,11 +142,12 @@ def _layer_norm(ln: nn.LayerNorm, x: torch.Tensor, residual: Optional[torch.Tens
             and C <= _LN_MAX_WIDTH and x.dtype in (torch.float32, torch.bfloat16) and ln.weight.dtype == torch.float32
             and (residual is None or residual.dtype in (torch.float32, torch.bfloat16))):
         _took("hip", "layer_norm")  # training: the same forward kernel, and its backward, behind an autograd function
-        return add_layer_norm_train(x, residual, ln.weight, ln.bias, ln.eps, out_dtype, p_drop)
+        return add_layer_norm_train(x, residual, ln.weight, ln.bias, ln.eps, out_dtype, p_drop, twin=twin)
     _took("torch", "layer_norm")
     y = ln(x if residual is None else x + residual)
     y = y if out_dtype is None else y.to(out_dtype)
-    return y if dropout is None else dropout(y)
+    y = y if dropout is None else dropout(y)
+    return (y, y.to(torch.bfloat16)) if twin else y
 
 
 class _MultiHeadAttention(nn.Module):
@@ -165,8 +166,10 @@ class _MultiHeadAttention(nn.Module):
         self.w_o = nn.Linear(d_model, d_model)
         self.layer_norm = nn.LayerNorm(d_model)
 
-    def forward(self, x: torch.Tensor, lengths: Optional[torch.Tensor],
-                out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, lengths: Optional[torch.Tensor], out_dtype: Optional[torch.dtype] = None,
+                x_bf16: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`x_bf16`: x rounded to bfloat16 when the caller already has it (the projections read that copy under
+        bf16 autocast; the residual connection keeps x)."""
         B, T, C = x.shape
         if (x.is_cuda and self.d_k in SUPPORTED_HEAD_WIDTHS and not torch.is_grad_enabled()
                 and not (self.training and self.dropout.p > 0)):
@@ -190,7 +193,7 @@ class _MultiHeadAttention(nn.Module):
                 # one GEMM for the three projections in both directions: x is cast and read once, the three input
                 # gradients arrive summed; the attention kernels read and write column blocks of its output
                 _took("hip", "qkv_projection")
-                packed = fused_linear_train(x, qkv)
+                packed = fused_linear_train(x if x_bf16 is None else x_bf16, qkv)
                 ctx = masked_attention_train_packed(packed, self.num_heads, lengths, p_drop)
             else:
                 q, k, v = _linear(self.w_q, x), _linear(self.w_k, x), _linear(self.w_v, x)
@@ -215,8 +218,8 @@ class _SelfAttention(nn.Module):
         super().__init__()
         self.attention = _MultiHeadAttention(d_model, num_heads, dropout)
 
-    def forward(self, x, lengths, out_dtype=None):
-        return self.attention(x, lengths, out_dtype)
+    def forward(self, x, lengths, out_dtype=None, x_bf16=None):
+        return self.attention(x, lengths, out_dtype, x_bf16)
 
 
 class LMUEncoder(nn.Module):
@@ -256,11 +259,19 @@ class LMUEncoder(nn.Module):
         att_out = stream
         if att_out is None and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
             att_out = torch.bfloat16
+        # In training the float32 output of a block has two readers in the next one: the residual connection, and
+        # the q/k/v projections, which round it to bf16 first.  The layer norm writes both forms in its pass and
+        # takes both gradients back in its backward; the last block's output has one reader (the output
+        # projection) and is written in bf16 only.
+        autocast16 = att_out == torch.bfloat16 and stream is None and torch.is_grad_enabled()
         x = _linear(self.input_projection, x)
         states = []
-        for att, lmu, ln in zip(self.attention_layers, self.lmu_layers, self.layer_norms):
+        x16 = None
+        n = len(self.lmu_layers)
+        for i, (att, lmu, ln) in enumerate(zip(self.attention_layers, self.lmu_layers, self.layer_norms)):
             if self.use_attention:
-                x = att(x, lengths, att_out)
+                x = att(x, lengths, att_out, x16)
+            x16 = None
             drop = self.training and self.dropout_layer.p > 0
             if not drop and ln.elementwise_affine and ln.bias is not None and lmu.supports_fused_layer_norm(x):
                 # the layer norm rides on the projection kernel's epilogue: h never goes to HBM
@@ -268,7 +279,12 @@ class LMUEncoder(nn.Module):
                     x, ln, stream or (torch.float32 if torch.is_autocast_enabled() else x.dtype))
             else:
                 x, h_n = lmu(x)
-                x = _layer_norm(ln, x, None, stream, self.dropout_layer)
+                if autocast16 and i == n - 1:
+                    x = _layer_norm(ln, x, None, torch.bfloat16, self.dropout_layer)
+                elif autocast16 and self.use_attention:
+                    x, x16 = _layer_norm(ln, x, None, None, self.dropout_layer, twin=True)
+                else:
+                    x = _layer_norm(ln, x, None, stream, self.dropout_layer)
             states.append(h_n)
         return _linear(self.output_projection, x), states
 

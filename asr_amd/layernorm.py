@@ -20,13 +20,15 @@ MAX_WIDTH = 1024
 
 def add_layer_norm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor, bias: torch.Tensor,
                    eps: float = 1e-5, out_dtype: Optional[torch.dtype] = None, p_drop: float = 0.0,
-                   seeds=(0, 0)) -> torch.Tensor:
+                   seeds=(0, 0), twin: bool = False):
     """LayerNorm over the last dimension of `x (+ residual)` with fp32 statistics.
 
     x, residual: [..., C] float32 or bfloat16 (they may differ); weight, bias: [C].  The result has
     `out_dtype`, by default float32 under autocast (where torch runs layer_norm in fp32) and the
     promoted input dtype otherwise.  `p_drop` > 0: dropout on the result in the same pass (training; the mask
     is a function of `seeds` = two 32-bit integers and the element's index, nothing is stored).
+    `twin` (float32 result only): returns (result, the same values rounded to bfloat16) -- the copy the next
+    block's projections read under bf16 autocast, written by the same pass instead of a cast kernel.
     """
     for name, t in (("x", x), ("residual", residual), ("weight", weight), ("bias", bias)):
         if t is not None and not t.is_cuda:
@@ -50,25 +52,30 @@ def add_layer_norm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: to
     residual = None if residual is None else residual.detach().contiguous()
     weight = weight.detach().float().contiguous()
     bias = bias.detach().float().contiguous()
+    if twin and out_dtype != torch.float32:
+        raise RuntimeError("add_layer_norm: the bfloat16 twin goes with a float32 result")
     out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    out16 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if twin else None
     rows = x.numel() // C if C else 0
     p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())  # noqa: E731
     with torch.cuda.device(x.device):
         rc = _lib.lib.lmufft_add_layernorm_dropout(
             p(x), _DTYPES[x.dtype], p(residual), _DTYPES[residual.dtype] if residual is not None else 0, p(weight),
             p(bias), float(eps), rows, C, p(out), _DTYPES[out_dtype], float(p_drop), int(seeds[0]) & 0xFFFFFFFF,
-            int(seeds[1]) & 0xFFFFFFFF, ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+            int(seeds[1]) & 0xFFFFFFFF, p(out16), ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
     _lib.check(rc, "lmufft_add_layernorm_dropout")
-    return out
+    return (out, out16) if twin else out
 
 
 def add_layer_norm_backward(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor, dy: torch.Tensor,
                             eps: float = 1e-5, out_weight: Optional[torch.Tensor] = None,
-                            out_bias: Optional[torch.Tensor] = None, p_drop: float = 0.0, seeds=(0, 0)):
+                            out_bias: Optional[torch.Tensor] = None, p_drop: float = 0.0, seeds=(0, 0),
+                            dy2: Optional[torch.Tensor] = None):
     """(dx, dresidual or None, dweight, dbias) of add_layer_norm: dx / dresidual carry the same values in the dtype
     of x / residual (one tensor when the dtypes agree); dweight, dbias float32, written into `out_weight` /
     `out_bias` (contiguous float32 [C]) when given.  `p_drop`, `seeds`: those of the forward call; dy passes
-    through the same dropout decisions first.  HIP kernel k_layernorm_bwd."""
+    through the same dropout decisions first.  `dy2`: a second upstream gradient of the same shape (float32 or
+    bfloat16), added to dy on load.  HIP kernel k_layernorm_bwd."""
     for name, t in (("x", x), ("residual", residual), ("weight", weight), ("dy", dy)):
         if t is not None and not t.is_cuda:
             raise RuntimeError(f"add_layer_norm_backward: `{name}` lives on {t.device}; the kernel runs only on a GPU "
@@ -79,6 +86,10 @@ def add_layer_norm_backward(x: torch.Tensor, residual: Optional[torch.Tensor], w
     if x.dtype not in _DTYPES or dy.dtype not in _DTYPES or (residual is not None and residual.dtype not in _DTYPES):
         raise RuntimeError("add_layer_norm_backward: supported dtypes are float32 and bfloat16")
     x, dy = x.detach().contiguous(), dy.detach().contiguous()
+    if dy2 is not None:
+        if dy2.shape != x.shape or dy2.dtype not in _DTYPES or not dy2.is_cuda:
+            raise RuntimeError("add_layer_norm_backward: dy2 must match x's shape, float32 or bfloat16, on the GPU")
+        dy2 = dy2.detach().contiguous()
     residual = None if residual is None else residual.detach().contiguous()
     weight = weight.detach().float().contiguous()
     dx = torch.empty_like(x)
@@ -96,7 +107,8 @@ def add_layer_norm_backward(x: torch.Tensor, residual: Optional[torch.Tensor], w
     with torch.cuda.device(x.device):
         rc = _lib.lib.lmufft_layernorm_dropout_bwd(
             p(x), _DTYPES[x.dtype], p(residual), _DTYPES[residual.dtype] if residual is not None else 0, p(dy),
-            _DTYPES[dy.dtype], p(weight), float(eps), rows, C, float(p_drop), int(seeds[0]) & 0xFFFFFFFF,
+            _DTYPES[dy.dtype], p(dy2), _DTYPES[dy2.dtype] if dy2 is not None else 0, p(weight), float(eps), rows, C,
+            float(p_drop), int(seeds[0]) & 0xFFFFFFFF,
             int(seeds[1]) & 0xFFFFFFFF, p(dx), p(dres), p(dgamma), p(dbeta), p(ws), ws.numel(),
             ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
     _lib.check(rc, "lmufft_layernorm_dropout_bwd")
@@ -107,23 +119,27 @@ def add_layer_norm_backward(x: torch.Tensor, residual: Optional[torch.Tensor], w
 
 class _AddLayerNormTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, eps, out_dtype, p_drop, seed0, seed1):
+    def forward(ctx, x, residual, weight, bias, eps, out_dtype, p_drop, seed0, seed1, twin):
         ctx.save_for_backward(x, residual, weight)
         ctx.eps = eps
         ctx.params = (weight, bias)
         ctx.drop = (p_drop, (seed0, seed1))
-        return add_layer_norm(x, residual, weight, bias, eps, out_dtype, p_drop, (seed0, seed1))
+        ctx.twin = twin
+        ctx.set_materialize_grads(False)  # an unused copy hands the backward None, not a tensor of zeros
+        return add_layer_norm(x, residual, weight, bias, eps, out_dtype, p_drop, (seed0, seed1), twin)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy16=None):
         x, residual, weight = ctx.saved_tensors
+        if dy is None:  # only the bfloat16 copy was used
+            dy, dy16 = dy16, None
         # parameters of a GradBuckets: the kernel writes into the bucket and autograd adopts the slices as .grad
         slot_w, slot_b = grad_slot(ctx.params[0]), grad_slot(ctx.params[1])
-        dx, dres, dgamma, dbeta = add_layer_norm_backward(x, residual, weight, dy, ctx.eps, slot_w, slot_b, *ctx.drop)
+        dx, dres, dgamma, dbeta = add_layer_norm_backward(x, residual, weight, dy, ctx.eps, slot_w, slot_b, *ctx.drop, dy16)
         dgamma = adopt(dgamma) if slot_w is not None else dgamma.to(weight.dtype)
         dbeta = adopt(dbeta) if slot_b is not None else dbeta.to(weight.dtype)
         return (dx if ctx.needs_input_grad[0] else None, dres if ctx.needs_input_grad[1] else None,
-                dgamma, dbeta, None, None, None, None, None)
+                dgamma, dbeta, None, None, None, None, None, None)
 
 
 _dropout_calls = 0
@@ -131,9 +147,11 @@ _dropout_calls = 0
 
 def add_layer_norm_train(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor, bias: torch.Tensor,
                          eps: float = 1e-5, out_dtype: Optional[torch.dtype] = None, p_drop: float = 0.0,
-                         seeds=None) -> torch.Tensor:
+                         seeds=None, twin: bool = False):
     """add_layer_norm with autograd (forward k_add_layernorm, backward k_layernorm_bwd), optionally followed by
     dropout in the same passes (`self.dropout_layer(layer_norm(x))`, src/models/lmu_encoder.py:274-277).
+    `twin`: returns (float32 result, its bfloat16 rounding) as two outputs; the gradients that arrive through the two
+    are added inside the backward kernel (no cast, no accumulation kernel).
     `seeds` = (seed0, seed1) name the dropout mask; by default torch's seed and a per-process call counter, so runs
     that start from the same torch.manual_seed and make the same calls draw the same masks."""
     global _dropout_calls
@@ -147,4 +165,4 @@ def add_layer_norm_train(x: torch.Tensor, residual: Optional[torch.Tensor], weig
             _dropout_calls += 1
         seeds = (torch.initial_seed() & 0xFFFFFFFF, 0x4C4E0000 ^ (_dropout_calls & 0xFFFFFFFF))
     return _AddLayerNormTrain.apply(x, residual, weight, bias, eps, out_dtype, float(p_drop), int(seeds[0]) & 0xFFFFFFFF,
-                                    int(seeds[1]) & 0xFFFFFFFF)
+                                    int(seeds[1]) & 0xFFFFFFFF, bool(twin))

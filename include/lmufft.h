@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMUFFT_ABI_VERSION 13
+#define LMUFFT_ABI_VERSION 14
 
 /* element types of the activations (x, h, gh, gx, m) */
 #define LMUFFT_F32 0
@@ -290,17 +290,21 @@ int lmufft_layernorm_bwd(const void* x, int x_dtype, const void* res, int res_dt
  * over HBM in each direction: the forward multiplies element (row, column) of the normalised output by
  * keep / (1 - p_drop), keep decided by the library's counter-based hash of the row, the column and the call's two
  * seeds (the function given at lmufft_attention_fwd_train with rows of C columns; no mask is stored); the backward
- * sends dy through the same decisions
- * before the layer-norm backward above.  p_drop in [0, 1); 0 gives the plain kernels.  With p_drop > 0 `out`
- * may not alias x or res (the backward recomputes from them).
+ * sends dy through the same decisions before the layer-norm backward above.  p_drop in [0, 1); 0 gives the plain
+ * kernels.  With p_drop > 0 `out` may not alias x or res (the backward recomputes from them).
+ * out_bf16 (may be NULL; needs a float32 `out`): receives the same output rounded to bf16 -- the copy the next
+ * block's projections read under bf16 autocast while its residual connection keeps the float32 one (the reference
+ * makes it with a cast kernel at every consumer).  dy2 (may be NULL; f32 or bf16): a second upstream gradient,
+ * added to dy on load -- the gradient that arrived through that second copy.
  * ---------------------------------------------------------------------- */
 int lmufft_add_layernorm_dropout(const void* x, int x_dtype, const void* res, int res_dtype, const float* gamma,
                                  const float* beta, float eps, int64_t rows, int32_t C, void* out, int out_dtype,
-                                 float p_drop, uint32_t seed0, uint32_t seed1, void* stream);
+                                 float p_drop, uint32_t seed0, uint32_t seed1, void* out_bf16, void* stream);
 int lmufft_layernorm_dropout_bwd(const void* x, int x_dtype, const void* res, int res_dtype, const void* dy,
-                                 int dy_dtype, const float* gamma, float eps, int64_t rows, int32_t C, float p_drop,
-                                 uint32_t seed0, uint32_t seed1, void* dx, void* dres, float* dgamma, float* dbeta,
-                                 void* workspace, size_t workspace_bytes, void* stream);
+                                 int dy_dtype, const void* dy2, int dy2_dtype, const float* gamma, float eps,
+                                 int64_t rows, int32_t C, float p_drop, uint32_t seed0, uint32_t seed1, void* dx,
+                                 void* dres, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                                 void* stream);
 
 /* ------------------------------------------------------------------------
  * Weight and bias gradient of a Linear layer under bf16 autocast (training).  Replaces what autograd runs

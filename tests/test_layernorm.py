@@ -232,3 +232,40 @@ def test_training_layer_norm_with_dropout(rows, C, dtype, with_res):
     assert torch.equal(a1, b1) and not torch.equal(a1, a2)
     with pytest.raises(ValueError):
         ln.add_layer_norm_train(xd, None, wd, bd, 1e-5, dtype, 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_training_layer_norm_twin_output(p):
+    """The float32 result and its bfloat16 copy from one pass; the gradients arriving through the two are added
+    inside the backward kernel: same results as one output fed the sum (to the rounding of that sum)."""
+    from asr_amd import layernorm as ln
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    rows, C = 3000, 384
+    x = torch.randn(rows, C, generator=g).to(torch.bfloat16).to(dev)
+    w, b = (torch.randn(C, generator=g) * 0.5 + 1.0).to(dev), torch.randn(C, generator=g).to(dev)
+    d32 = torch.randn(rows, C, generator=g).to(dev)
+    d16 = torch.randn(rows, C, generator=g).to(torch.bfloat16).to(dev)
+    seeds = (3, 4)
+
+    def run(twin, use):
+        xd = x.clone().requires_grad_(True)
+        wd, bd = torch.nn.Parameter(w.clone()), torch.nn.Parameter(b.clone())
+        out = ln.add_layer_norm_train(xd, None, wd, bd, 1e-5, torch.float32, p, seeds, twin=twin)
+        if twin:
+            y, y16 = out
+            assert y16.dtype == torch.bfloat16 and torch.equal(y16, y.to(torch.bfloat16))
+            torch.autograd.backward([t for t, u in ((y, use[0]), (y16, use[1])) if u],
+                                    [d for d, u in ((d32, use[0]), (d16, use[1])) if u])
+        else:
+            y = out
+            y.backward((d32 if use[0] else 0) + (d16.float() if use[1] else 0))
+        return y.detach(), xd.grad, wd.grad, bd.grad
+
+    for use in ((True, True), (True, False), (False, True)):
+        got, want = run(True, use), run(False, use)
+        assert torch.equal(got[0], want[0])
+        for a, c in zip(got[1:], want[1:]):
+            assert torch.allclose(a.float(), c.float(), rtol=2.0 ** -7, atol=1e-5 * float(c.float().abs().max()))
