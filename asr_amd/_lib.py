@@ -19,7 +19,7 @@ CONV_AUTO = 0
 CONV_TOEPLITZ = 1
 CONV_FFT = 2
 NOALLOC_SCRATCH_BYTES = 8 << 20
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class Shape(ctypes.Structure):
@@ -127,6 +127,8 @@ def _load():
     lib.lmufft_layernorm_dropout_bwd.restype = ci
     lib.lmufft_layernorm_dropout_bwd.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, vp, f32, i64, i32, f32, u32, u32, vp, vp,
                                                  vp, vp, vp, sz, vp]
+    lib.lmufft_linear_wprep_bf16.restype = ci
+    lib.lmufft_linear_wprep_bf16.argtypes = [vp, vp, i32, i32, i32, vp, vp, i64, vp, vp]
     lib.lmufft_linear_wgrad_workspace_bytes.restype = sz
     lib.lmufft_linear_wgrad_workspace_bytes.argtypes = [i64, i32, i32]
     lib.lmufft_linear_wgrad_bf16.restype = ci
@@ -190,6 +192,7 @@ EXPORTS = (
     "lmufft_layernorm_dropout_bwd",
     "lmufft_linear_bf16",
     "lmufft_linear_ln_bf16",
+    "lmufft_linear_wprep_bf16",
     "lmufft_linear_wgrad_workspace_bytes",
     "lmufft_linear_wgrad_bf16",
     "lmufft_ctc_workspace_bytes",

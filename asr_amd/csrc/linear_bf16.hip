@@ -475,6 +475,60 @@ int linear_impl(const void* x, const void* W, const float* bias, int64_t rows, i
 }
 }  // namespace
 
+// ---------------------------------------------------------------------------
+// Operands of a Linear layer's training step from its fp32 master weight in one launch: W in bf16 (forward), W^T
+// in bf16 (the input gradient is the forward kernel on W^T) and the bias as autocast sees it (rounded to bf16,
+// widened again).  A thread writes eight consecutive bf16: of one row for W, of one column j for W^T with
+// consecutive threads on consecutive j, so that the strided reads of W coalesce across lanes.
+// ---------------------------------------------------------------------------
+namespace lmufft {
+__global__ __launch_bounds__(256) void k_linear_wprep(const float* __restrict__ W, const float* __restrict__ bias, int N,
+                                                      int K, int Np, bf16_t* __restrict__ Wb, bf16_t* __restrict__ WbT,
+                                                      long ldT, float* __restrict__ bias_r) {
+  const int g1 = K / 8, g2 = Np / 8;
+  const long n1 = (long)Np * g1, n2 = (long)K * g2, n3 = bias_r ? Np : 0;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n1 + n2 + n3; i += (long)gridDim.x * 256) {
+    if (i < n1) {
+      const int n = (int)(i / g1), k0 = (int)(i % g1) * 8;
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(n < N ? W[(long)n * K + k0 + e] : 0.f);
+      *reinterpret_cast<bf16x8*>(Wb + (long)n * K + k0) = o;
+    } else if (i < n1 + n2) {
+      const long r = i - n1;
+      const int j = (int)(r % K), n0 = (int)(r / K) * 8;
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(n0 + e < N ? W[(long)(n0 + e) * K + j] : 0.f);
+      *reinterpret_cast<bf16x8*>(WbT + (long)j * ldT + n0) = o;
+    } else {
+      const int n = (int)(i - n1 - n2);
+      bias_r[n] = (bias && n < N) ? (float)(bf16_t)bias[n] : 0.f;
+    }
+  }
+}
+}  // namespace lmufft
+
+extern "C" int lmufft_linear_wprep_bf16(const float* W, const float* bias, int32_t N, int32_t K, int32_t N_pad, void* Wb,
+                                        void* WbT, int64_t ldT, float* bias_rounded, void* stream) {
+  if (N <= 0 || K <= 0 || N_pad < N) return set_error("linear wprep: bad shape (N=%d K=%d N_pad=%d)", N, K, N_pad);
+  if (K % 8 || N_pad % 8 || ldT % 8 || ldT < N_pad)
+    return set_error("linear wprep: K, N_pad and ldT must be multiples of 8, ldT >= N_pad (got %d, %d, %lld)", K, N_pad, (long long)ldT);
+  if (!W || !Wb || !WbT) return set_error("linear wprep: NULL pointer");
+  if ((((uintptr_t)Wb | (uintptr_t)WbT) & 15) != 0) return set_error("linear wprep: outputs must be 16-byte aligned");
+  const long items = (long)N_pad * (K / 8) + (long)K * (N_pad / 8) + (bias_rounded ? N_pad : 0);
+  const int blocks = (int)std::min<long>((items + 255) / 256, 2048);
+  hipStream_t st = (hipStream_t)stream;
+  {
+    ProfScope ps("k_linear_wprep", st);
+    hipLaunchKernelGGL(k_linear_wprep, dim3(blocks), dim3(256), 0, st, W, bias, N, K, N_pad, (bf16_t*)Wb, (bf16_t*)WbT,
+                       (long)ldT, bias_rounded);
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error("launch of k_linear_wprep failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
 extern "C" int lmufft_linear_bf16(const void* x, const void* W, const float* bias, int64_t rows, int32_t K, int32_t N,
                                   void* out, void* stream) {
   if (rows > 0 && !out) return set_error("linear: NULL pointer");

@@ -135,6 +135,39 @@ def linear_weight_grad_bf16(x: torch.Tensor, dy: torch.Tensor, want_bias: bool =
     return dW, db
 
 
+def linear_weight_prep(weights, biases):
+    """(W16 [N_pad, K], W16^T [K, N_pad], bias as autocast sees it [N_pad] fp32 or None) for the concatenation of the
+    given fp32 weights [N_i, K] (and biases, all or none): one kernel launch per weight instead of cast, transpose
+    and two bias casts.  N_pad rounds the total output width up to a multiple of 8 with zero rows."""
+    K = weights[0].shape[1]
+    N = sum(w.shape[0] for w in weights)
+    Np = -(-N // 8) * 8
+    dev = weights[0].device
+    has_bias = biases is not None and all(b is not None for b in biases)
+    w16 = torch.empty((Np, K), dtype=torch.bfloat16, device=dev)
+    w16t = torch.empty((K, Np), dtype=torch.bfloat16, device=dev)
+    b32 = torch.empty((Np,), dtype=torch.float32, device=dev) if has_bias else None
+    n0 = 0
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    with torch.cuda.device(dev):
+        for i, w in enumerate(weights):
+            wd = w.detach().contiguous()
+            n = wd.shape[0]
+            last = i == len(weights) - 1
+            if (n % 8 and not last) or wd.shape[1] != K or wd.dtype != torch.float32:
+                raise RuntimeError("linear_weight_prep: float32 weights of one input width; only the last output width "
+                                   "may be other than a multiple of 8")
+            npad = Np - n0 if last else n
+            bd = biases[i].detach().contiguous() if has_bias else None
+            rc = _lib.lib.lmufft_linear_wprep_bf16(
+                _ptr(wd), _ptr(bd), n, K, npad, ctypes.c_void_p(w16.data_ptr() + n0 * K * 2),
+                ctypes.c_void_p(w16t.data_ptr() + n0 * 2), Np, None if b32 is None else ctypes.c_void_p(b32.data_ptr() + n0 * 4),
+                st)
+            _lib.check(rc, "lmufft_linear_wprep_bf16")
+            n0 += n
+    return w16, w16t, b32
+
+
 class _LinearTrain(torch.autograd.Function):
     """nn.Linear under bf16 autocast with this package's kernels in both directions: y = bf16(x) bf16(W)^T + b
     (fp32 accumulation, one rounding); dx = dy bf16(W) in bf16; dW, db in fp32 straight from bf16 x and dy.
@@ -145,12 +178,8 @@ class _LinearTrain(torch.autograd.Function):
         N = weight.shape[0]
         pad = -N % 8
         xb = x.to(torch.bfloat16)
-        w16 = weight.detach().to(torch.bfloat16)
-        b32 = None if bias is None else bias.detach().to(torch.bfloat16).float()
-        if pad:
-            w16 = torch.nn.functional.pad(w16, (0, 0, 0, pad))
-            b32 = None if b32 is None else torch.nn.functional.pad(b32, (0, pad))
-        ctx.save_for_backward(xb, w16)
+        w16, w16t, b32 = linear_weight_prep([weight], None if bias is None else [bias])
+        ctx.save_for_backward(xb, w16t)
         ctx.has_bias = bias is not None
         ctx.x_dtype = x.dtype
         ctx.params = (weight, bias)
@@ -160,14 +189,14 @@ class _LinearTrain(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        xb, w16 = ctx.saved_tensors
+        xb, w16t = ctx.saved_tensors
         dyb = dy.to(torch.bfloat16)
         if ctx.pad:
             dyb = torch.nn.functional.pad(dyb, (0, ctx.pad))
         dyb = dyb.contiguous()
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
-            dx = linear_bf16(dyb, w16.t().contiguous()).to(ctx.x_dtype)   # dy W: the same kernel on W^T
+            dx = linear_bf16(dyb, w16t).to(ctx.x_dtype)   # dy W: the same kernel on W^T
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             # parameters of a GradBuckets: the kernel writes into the bucket and autograd adopts the slice as .grad
             weight, bias = ctx.params
@@ -195,21 +224,20 @@ class _FusedLinearTrain(torch.autograd.Function):
     def forward(ctx, x, *params):
         weights, biases = params[0::2], params[1::2]
         xb = x.to(torch.bfloat16)
-        w16 = torch.cat([w.detach() for w in weights]).to(torch.bfloat16)
-        b32 = torch.cat([b.detach() for b in biases]).to(torch.bfloat16).float()
-        ctx.save_for_backward(xb, w16)
+        w16, w16t, b32 = linear_weight_prep(list(weights), list(biases))
+        ctx.save_for_backward(xb, w16t)
         ctx.x_dtype = x.dtype
         ctx.params = (weights, biases)
         return linear_bf16(xb, w16, b32)
 
     @staticmethod
     def backward(ctx, dy):
-        xb, w16 = ctx.saved_tensors
+        xb, w16t = ctx.saved_tensors
         weights, biases = ctx.params
         dyb = dy.to(torch.bfloat16).contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = linear_bf16(dyb, w16.t().contiguous()).to(ctx.x_dtype)
+            dx = linear_bf16(dyb, w16t).to(ctx.x_dtype)
         fw = fused_slot(weights)
         fb = fused_slot(biases)
         dW, db = linear_weight_grad_bf16(xb, dyb, True, None if fw is None else fw[0], None if fb is None else fb[0])

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMUFFT_ABI_VERSION 14
+#define LMUFFT_ABI_VERSION 15
 
 /* element types of the activations (x, h, gh, gx, m) */
 #define LMUFFT_F32 0
@@ -426,6 +426,14 @@ int lmufft_add_layernorm(const void* x, int x_dtype, const void* res, int res_dt
  * ---------------------------------------------------------------------- */
 int lmufft_linear_bf16(const void* x, const void* W, const float* bias, int64_t rows,
                        int32_t K, int32_t N, void* out, void* stream);
+
+/* Operands of a Linear layer's training step under bf16 autocast from its float32 master weight, one launch
+ * (autocast casts weight and bias at every call, and the input gradient needs W^T: four kernels per layer):
+ *   W [N][K] f32, bias [N] f32 or NULL;  Wb [N_pad][K] bf16 (rows >= N zero: N_pad pads an output width that is not
+ *   a multiple of 8);  WbT [K][ldT] bf16, columns 0 .. N_pad-1 written (ldT > N_pad: the layer is a column block of
+ *   a wider concatenated weight);  bias_rounded [N_pad] f32 (may be NULL) = the bias rounded to bf16, widened. */
+int lmufft_linear_wprep_bf16(const float* W, const float* bias, int32_t N, int32_t K, int32_t N_pad, void* Wb,
+                             void* WbT, int64_t ldT, float* bias_rounded, void* stream);
 
 /* The same GEMM followed, in its epilogue, by the residual add and layer norm of
  * the attention block: y = LN(bf16(x W^T + bias) + res) * gamma + beta
