@@ -284,10 +284,10 @@ def bench_full_step(args, dev, rank, world):
     """The reference's whole training step at its single-GPU configuration: mel-shaped input -> 3-layer encoder
     (attention, LMUFFT, layer norm, dropout 0.1) -> CTC head and loss -> backward -> clip 10 -> AdamW -> scheduler
     (configs/base_config.yaml:3-15, 29-36; src/training/distributed.py:139-234), bf16 autocast.  This package's
-    kernels run the LMUFFT layers, attention, the Linear layers and layer norms (forward and backward), the CTC loss
-    with its gradient and the gradient norm / clipping / AdamW step; dropout after the layer norms, residual adds,
-    dtype casts, the vocabulary projection and log-softmax are torch ops.  This line measures the model with the
-    hot path swapped in, not a roofline."""
+    kernels run the LMUFFT layers, attention, every Linear layer (the vocabulary projection included), the layer
+    norms with their dropout (forward and backward), the CTC loss with its gradient and the gradient norm /
+    clipping / AdamW step; the log-softmax, the loss mean and a few small casts are torch ops.  This line measures
+    the model with the hot path swapped in, not a roofline."""
     import torch
     import torch.distributed as dist
 
@@ -384,10 +384,9 @@ def bench_full_step(args, dev, rank, world):
                                f"seq_len {T}), batch {B} per GPU, bf16 autocast: forward + CTC loss + backward + clip 10 + "
                                "AdamW(1.5e-3, wd 0.01) + warm-up scheduler, eager launches",
                    "batch_per_gpu": B, "frames": T, "parallelism": f"dp{world}", "world_size": world,
-                   "hip_kernels": "LMUFFT, attention, Linear, layer norm (forward and backward), CTC loss + gradient, "
-                                  "gradient norm + clip + AdamW",
-                   "torch_ops": "dropout after the layer norms, residual adds, dtype casts, vocabulary projection, "
-                                "log-softmax",
+                   "hip_kernels": "LMUFFT, attention, Linear (incl. vocabulary projection), layer norm + dropout (forward "
+                                  "and backward), CTC loss + gradient, gradient norm + clip + AdamW",
+                   "torch_ops": "log-softmax, loss mean, input cast",
                    "activation_stream": "bf16 between blocks" if args.bf16_stream else "fp32 between blocks (autocast)",
                    "gradient_buckets": len(buckets.buckets)},
         "roofline": None,
