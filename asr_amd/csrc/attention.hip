@@ -527,6 +527,7 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? (TRAIN ? 3 : 4) : 1) void k_att
   const int qi = blockIdx.x * (32 * NW) + wave * 32 + r;
   const bool q_valid = qi < len;
   const int qc = min(qi, T - 1);
+  const bool wave_live = blockIdx.x * (32 * NW) + wave * 32 < T;  // wave-uniform
 
   attn_bf16x8 qf[NS];  // B fragments of the score contraction: Q[query r][16s + 8hh .. +7]
 #pragma unroll
@@ -579,6 +580,7 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? (TRAIN ? 3 : 4) : 1) void k_att
     stage();
     __syncthreads();
     if (j0 + KEYS < T) fetch(j0 + KEYS);
+    if (!wave_live) continue;  // a wave whose 32 queries all lie past T only helps staging the tiles
 
     attn_f16v st[NKT];
 #pragma unroll
@@ -738,6 +740,7 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 2 : 1) void k_attention_bwd_dq_
   const int qi = blockIdx.x * (32 * NW) + wave * 32 + r;
   const bool q_valid = qi < len;
   const int qc = min(qi, T - 1);
+  const bool wave_live = blockIdx.x * (32 * NW) + wave * 32 < T;  // wave-uniform
 
   attn_bf16x8 qf[NS], dof[NS];
   float D = 0.f;
@@ -800,6 +803,7 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 2 : 1) void k_attention_bwd_dq_
     stage();
     __syncthreads();
     if (j0 + 32 < T) fetch(j0 + 32);
+    if (!wave_live) continue;  // a wave whose 32 queries all lie past T only helps staging the tiles
 
     attn_f16v st, dp;
     [[maybe_unused]] uint32_t xpair = 0;
@@ -887,6 +891,7 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 2 : 1) void k_attention_bwd_dkv
   const int kj = blockIdx.x * (32 * NW) + wave * 32 + r;
   const bool k_valid = kj < len;
   const bool all_k_valid = __all(k_valid);
+  const bool wave_live = blockIdx.x * (32 * NW) + wave * 32 < T;  // wave-uniform
   const int kc = min(kj, T - 1);
 
   attn_bf16x8 kf[NS], vf[NS];
@@ -951,6 +956,7 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 2 : 1) void k_attention_bwd_dkv
     stage();
     __syncthreads();
     if (i0 + 32 < T) fetch(i0 + 32);
+    if (!wave_live) continue;  // a wave whose 32 keys all lie past T only helps staging the tiles
 
     attn_f16v st, dp;
 #pragma unroll
