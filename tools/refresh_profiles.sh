@@ -24,4 +24,8 @@ done
 timeout -k 10 240 python3 tools/mel_bench.py > $O/mel_bench.txt 2>&1
 timeout -k 10 240 python3 tools/infer_bench.py > $O/infer_bench.json 2> $O/infer_bench.err
 timeout -k 10 240 python3 tools/t3000.py > $O/t3000.txt 2>&1
+timeout -k 10 300 python3 bench.py --workload c2_full --steps 50 --warmup 5 --torch-profile > $O/bench_c2_full.json 2> $O/bench_c2_full_kernels.txt
+timeout -k 10 300 python3 bench.py --workload c2_full --steps 50 --warmup 5 --batch 96 > $O/bench_c3_batch96.json 2> $O/bench_c3_batch96.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c2_full -o c2 -- python3 bench.py --workload c2_full --steps 30 --warmup 5 > $O/stats_c2_full.log 2>&1
+timeout -k 10 240 python3 tools/attn_train_bench.py 0.1 > $O/attn_train_bench.txt 2>&1
 echo done > $O/DONE
