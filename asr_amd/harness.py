@@ -3,14 +3,18 @@ package's LMUFFT layers and CTC head, so that a reference checkpoint can be eval
 and greedy decodes can be compared token by token.
 
 The LMUFFT layers, the attention core, the layer norms, the mel frontend and the CTC head are HIP
-kernels of this package, and so are the input / output / attention projections for inference
-under bf16 autocast (fp32 projections are torch's linear).  Module and
+kernels of this package, and so are the input / output / attention projections under bf16
+autocast (fp32 projections are torch's linear).  In training under bf16 autocast (grad enabled)
+the same ops run this package's forward AND backward kernels -- attention with dropout on its
+weights, the Linear layers, layer norm with the dropout that follows it, the CTC loss -- behind
+autograd functions.  Module and
 parameter names follow the reference so that its state_dict loads unchanged:
   encoder.input_projection, encoder.attention_layers.{i}.attention.{w_q,w_k,w_v,w_o,layer_norm},
   encoder.lmu_layers.{i}, encoder.layer_norms.{i}, encoder.output_projection,
   decoder.ctc_projection
 (reference: src/models/lmu_encoder.py:23-47, 183-229; src/models/asr_model.py:69-102).
-Inference only: dropout is the identity.
+Dropout (on the attention weights and after the LMU blocks' layer norms, as the reference) is active
+in train() mode and the identity in eval().
 """
 from __future__ import annotations
 
@@ -33,7 +37,7 @@ from .lmu import LMUFFT
 # torch formulation counts its calls here ("hip:<op>" / "torch:<op>"), and inside `strict_kernels()`
 # a torch formulation raises instead of running -- so a benchmark cannot silently time hipBLASLt or
 # torch's attention.  (fp32 Linear layers are torch ops by design and are counted as "torch:linear";
-# strict mode therefore only makes sense for bf16 inference, where every op has a kernel here.)
+# strict mode therefore only makes sense under bf16 autocast, where every op has a kernel here.)
 PATHS: dict = {}
 _STRICT = [False]
 
@@ -56,7 +60,7 @@ def _took(kind: str, op: str) -> None:
     PATHS[key] = PATHS.get(key, 0) + 1
     if kind == "torch" and _STRICT[0]:
         raise RuntimeError(f"asr_amd.harness: `{op}` would run as a torch op here (strict_kernels is on); "
-                           "the HIP kernel needs a GPU tensor, inference mode (no grad) and supported widths / dtypes")
+                           "the HIP kernels need GPU tensors, bf16 autocast and supported widths / dtypes")
 
 
 def _bf16_inference() -> bool:
