@@ -362,37 +362,28 @@ __global__ __launch_bounds__(kPackThreads) void k_ctc_pack_targets(const int64_t
 
 // ---------------------------------------------------------------------------
 // CTC loss and its gradient (training).  The reference uses nn.CTCLoss(blank = vocab_size - 1,
-// reduction = 'mean', zero_infinity = True), src/models/asr_model.py:105, 130-156.  Per utterance, in the log
-// domain (states 0..2L: even = blank, odd = label (s-1)/2):
-//   alpha_t(s) = lp_t(c_s) + lse(alpha_{t-1}(s), alpha_{t-1}(s-1), [c_s != c_{s-2}] alpha_{t-1}(s-2))
-//   beta_t(s)  = lp_t(c_s) + lse(beta_{t+1}(s),  beta_{t+1}(s+1),  [c_s != c_{s+2}] beta_{t+1}(s+2))
-//   nll = -lse(alpha_{Tb-1}(2L), alpha_{Tb-1}(2L-1))
-//   grad_t(c) = w (exp lp_t(c) - exp(lse_{s: c_s = c}(alpha_t(s) + beta_t(s)) + nll - lp_t(c)))   for t < Tb, else 0
+// reduction = 'mean', zero_infinity = True), src/models/asr_model.py:105, 130-156.  Per utterance
+// (states 0..2L: even = blank, odd = label (s-1)/2; p_t = exp lp_t):
+//   alpha_t(s) = p_t(c_s) (alpha_{t-1}(s) + alpha_{t-1}(s-1) + [c_s != c_{s-2}] alpha_{t-1}(s-2))
+//   beta_t(s)  = p_t(c_s) (beta_{t+1}(s)  + beta_{t+1}(s+1)  + [c_s != c_{s+2}] beta_{t+1}(s+2))
+//   nll = -log(alpha_{Tb-1}(2L) + alpha_{Tb-1}(2L-1))
+//   grad_t(c) = w (p_t(c) - sum_{s: c_s = c} alpha_t(s) beta_t(s) / (p_t(c) exp(-nll)))   for t < Tb, else 0
 // -- the gradient torch's ctc_loss returns for log_probs (it is the gradient through the log-softmax that produced
 // them: its rows sum to zero), w = 1 / (B max(L, 1)) for the mean reduction.
 //
 // Two launches.  k_ctc_alpha_beta is the serial part: one workgroup per utterance, thread l owns blank state 2l
 // and label state 2l+1, and the two recursions -- which do not depend on each other -- run at the same time in two
-// halves of the workgroup (one after the other when 2 x 16 waves would not fit).  A step is one exchange of the
-// neighbour's value through double-buffered LDS and two log-sum-exps; the log-probabilities it needs are fetched
-// eight frames ahead, since nothing else hides a global load here.  Both sets of variables go to the workspace.
-// k_ctc_grad is the parallel part: one wave per frame adds alpha + beta + nll, and lane c forms class c's sum by
-// walking the list of its label positions (blank: a wave reduction) -- fixed orders, no atomics.
-//
-// The recursions run on doubles: |alpha| grows like T log V (about 1400 at 400 frames), where an fp32 ulp is 1e-4
-// and 400 roundings would put 1e-3 of relative error into every posterior.  Only the maximum and the sums are
-// double; the exponentials and the logarithm see differences of a few units and stay in fp32.
+// halves of the workgroup (one after the other when 2 x 16 waves would not fit).  The recursions run in the LINEAR
+// domain on doubles, rescaled every fourth frame by a power of two (exact): the state variables of frame t are stored
+// as alpha_t 2^-E_t with the integer E_t beside them.  A step is then one exchange of the neighbour's value through
+// double-buffered LDS, two additions and one multiplication -- the log-domain form (a maximum, three exponentials and
+// a logarithm on the dependent chain of every step) took three times as long.  A shift is the exponent of the
+// largest state of the frame before it, found by a DPP wave reduction.  A target of up to 63 labels is one wave per
+// recursion: there the neighbour's value comes by a DPP lane shift and the LDS is not used at all.  exp lp_t and the log-probabilities themselves are fetched sixteen frames ahead, since nothing else
+// hides a global load here.  k_ctc_grad is the parallel part: one wave per frame, lane c sums alpha beta over the
+// list of class c's label positions (blank: a wave reduction) in double and applies the scales -- fixed orders, no
+// atomics.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ double ctc_lse2(double a, double b) {
-  const double m = fmax(a, b);
-  if (m == -INFINITY) return -INFINITY;
-  return m + (double)__logf(__expf((float)(a - m)) + __expf((float)(b - m)));
-}
-__device__ __forceinline__ double ctc_lse3(double a, double b, double c) {
-  const double m = fmax(fmax(a, b), c);
-  if (m == -INFINITY) return -INFINITY;
-  return m + (double)__logf(__expf((float)(a - m)) + __expf((float)(b - m)) + __expf((float)(c - m)));
-}
 
 // other lanes' LDS stores feed this lane's next loads: the LDS serves a wave's instructions in order, the compiler
 // only has to keep them in order
@@ -413,75 +404,145 @@ __device__ __forceinline__ void ctc_sync() {
   }
 }
 
-constexpr int kCtcAhead = 8;  // frames of log-probabilities in flight per thread
+__device__ const float kCtcNegInf = -INFINITY;  // what a thread without a state "loads" as its log-probability
+constexpr int kCtcRescale = 4;  // frames between two rescalings (doubles hold 4 frames of any float probabilities)
+constexpr int kCtcAhead = 16;  // frames of log-probabilities in flight per thread (loads queue behind the stores of the
+                               // state variables: the distance has to cover a store's way to HBM)
+
+__device__ __forceinline__ int ctc_exponent(double v) { return (__double2hiint(v) >> 20) & 0x7FF; }  // biased
+// 2^-(e - 1023) for the biased exponent e of the largest state; 1 when every state is zero (or e is out of range)
+__device__ __forceinline__ double ctc_unscale(int e, int& shift) {
+  shift = (e >= 24 && e <= 2022) ? e - 1023 : 0;
+  return __hiloint2double((1023 - shift) << 20, 0);
+}
+// Largest value of the wave (uniform result), without the LDS crossbar: butterflies inside the rows of 16 lanes by
+// DPP, then the four rows through scalar registers.  All 64 lanes must be active.
+__device__ __forceinline__ int ctc_wave_max(int v) {
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false));  // row_half_mirror
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false));  // row_mirror
+  return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+// the value of lane - 1 (lane 0: zero) / of lane + 1 (lane 63: zero), by DPP wave shifts
+__device__ __forceinline__ double ctc_lane_below(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xF, 0xF, false);  // wave_shr:1
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double ctc_lane_above(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xF, 0xF, false);  // wave_shl:1
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
 
 // One recursion over the frames of an utterance.  FWD: alpha, frames 0 .. Tb-1; otherwise beta, frames Tb-1 .. 0.
-// xb / xl: [2][NT + 2] exchange buffers of the blank / label values, thread l at index l + 1, both ends -inf.
-// Every thread of the group makes Tb - 1 calls of ctc_sync.  Returns the buffer the last step wrote.
+// xb / xl: [2][NT + 2] exchange buffers of the blank / label values, thread l at index l + 1, both ends 0;
+// xe: [2][NW] the waves' largest exponents.  w: the state variables [T][2 NT], ex: the frames' cumulative shifts [T].
+// Every thread of the group makes Tb - 1 calls of ctc_sync.  Returns the buffer the last step wrote; E: the last
+// frame's cumulative shift.  When the recursion is one wave (NW = 1) the neighbours' values come by DPP lane shifts
+// and the LDS is not used at all.
 template <int NW, bool FWD>
 __device__ __forceinline__ int ctc_sweep(const float* __restrict__ lpb, int V, int blank, int my_label, int l, int L, int Tb,
-                                         bool skip, double* __restrict__ w, double (*xb)[64 * NW + 2],
-                                         double (*xl)[64 * NW + 2], double& vb, double& vl) {
+                                         bool skip, double* __restrict__ w, int* __restrict__ ex,
+                                         double (*xb)[64 * NW + 2], double (*xl)[64 * NW + 2], int (*xe)[NW],
+                                         double& vb, double& vl, int& E) {
   constexpr int NT = 64 * NW;
+  const int wave = l >> 6;
   const int t0 = FWD ? 0 : Tb - 1;
   {
     const float* row = lpb + (long)t0 * V;
     if (FWD) {
-      vb = l == 0 ? (double)row[blank] : -INFINITY;
-      vl = (l == 0 && L > 0) ? (double)row[my_label] : -INFINITY;
+      vb = l == 0 ? (double)__expf(row[blank]) : 0.0;
+      vl = (l == 0 && L > 0) ? (double)__expf(row[my_label]) : 0.0;
     } else {
-      vb = l == L ? (double)row[blank] : -INFINITY;
-      vl = l == L - 1 ? (double)row[my_label] : -INFINITY;
+      vb = l == L ? (double)__expf(row[blank]) : 0.0;
+      vl = l == L - 1 ? (double)__expf(row[my_label]) : 0.0;
     }
   }
+  E = 0;
   int cur = 0;
-  xb[0][l + 1] = vb;
-  xl[0][l + 1] = vl;
-  if (l == 0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) xb[i][0] = xl[i][0] = xb[i][NT + 1] = xl[i][NT + 1] = -INFINITY;
+  if (NW > 1) {
+    xb[0][l + 1] = vb;
+    xl[0][l + 1] = vl;
   }
+  if (l == 0) {
+    if (NW > 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) xb[i][0] = xl[i][0] = xb[i][NT + 1] = xl[i][NT + 1] = 0.0;
+    }
+    ex[t0] = 0;
+  }
+  int emax = ctc_wave_max(max(ctc_exponent(vb), ctc_exponent(vl)));
+  if (NW > 1 && (l & 63) == 0) xe[0][wave] = emax;
   *reinterpret_cast<double2*>(w + (long)t0 * 2 * NT + 2 * l) = make_double2(vb, vl);
+  // A thread without a blank (l > L) or label (l >= L) state reads -inf from one fixed cell instead of its row:
+  // its probability is 0 and so is its state, with no test inside the loop.
+  const float* colb = l <= L ? lpb + blank : &kCtcNegInf;
+  const float* coll = l < L ? lpb + my_label : &kCtcNegInf;
+  const long strb = l <= L ? V : 0, strl = l < L ? V : 0;
   float qb[kCtcAhead], ql[kCtcAhead];
 #pragma unroll
   for (int i = 0; i < kCtcAhead; ++i) {
     const int k = min(1 + i, Tb - 1);
-    const float* row = lpb + (long)(FWD ? k : Tb - 1 - k) * V;
-    qb[i] = row[blank];
-    ql[i] = row[my_label];
+    const long t = FWD ? k : Tb - 1 - k;
+    qb[i] = colb[t * strb];
+    ql[i] = coll[t * strl];
   }
-  ctc_sync<NW>();
+  if (NW > 1) ctc_sync<NW>();
+  static_assert(kCtcAhead % kCtcRescale == 0, "the unrolled block holds whole rescaling periods");
   for (int k0 = 1; k0 < Tb; k0 += kCtcAhead) {
     float nqb[kCtcAhead], nql[kCtcAhead];
 #pragma unroll
     for (int i = 0; i < kCtcAhead; ++i) {
       const int k = min(k0 + kCtcAhead + i, Tb - 1);
-      const float* row = lpb + (long)(FWD ? k : Tb - 1 - k) * V;
-      nqb[i] = row[blank];
-      nql[i] = row[my_label];
+      const long t = FWD ? k : Tb - 1 - k;
+      nqb[i] = colb[t * strb];
+      nql[i] = coll[t * strl];
     }
 #pragma unroll
     for (int i = 0; i < kCtcAhead; ++i) {
       const int k = k0 + i;
       if (k < Tb) {  // uniform over the workgroup
         const int t = FWD ? k : Tb - 1 - k;
+        double pb = (double)__expf(qb[i]), pl = (double)__expf(ql[i]);
+        if (i % kCtcRescale == 0) {  // the shift found at the end of the last period
+          if (NW > 1) {
+#pragma unroll
+            for (int j = 0; j < NW; ++j) emax = max(emax, xe[cur][j]);
+          }
+          int shift;
+          const double un = ctc_unscale(emax, shift);
+          E += shift;
+          pb *= un;
+          pl *= un;
+        }
         double nb, nl;
         if (FWD) {
-          const double pl = xl[cur][l];  // label state of thread l - 1
-          nb = l <= L ? ctc_lse2(vb, pl) + (double)qb[i] : -INFINITY;
-          nl = l < L ? ctc_lse3(vl, vb, skip ? pl : -INFINITY) + (double)ql[i] : -INFINITY;
+          const double prev = NW == 1 ? ctc_lane_below(vl) : xl[cur][l];  // label state of thread l - 1
+          nb = (vb + prev) * pb;
+          nl = (vl + vb + (skip ? prev : 0.0)) * pl;
         } else {
-          const double nxb = xb[cur][l + 2], nxl = xl[cur][l + 2];  // states of thread l + 1
-          nb = l <= L ? ctc_lse2(vb, vl) + (double)qb[i] : -INFINITY;
-          nl = l < L ? ctc_lse3(vl, nxb, skip ? nxl : -INFINITY) + (double)ql[i] : -INFINITY;
+          const double nxb = NW == 1 ? ctc_lane_above(vb) : xb[cur][l + 2];  // states of thread l + 1
+          const double nxl = NW == 1 ? ctc_lane_above(vl) : xl[cur][l + 2];
+          nb = (vb + vl) * pb;
+          nl = (vl + nxb + (skip ? nxl : 0.0)) * pl;
         }
         vb = nb;
         vl = nl;
         cur ^= 1;
-        if (!FWD) xb[cur][l + 1] = vb;
-        xl[cur][l + 1] = vl;
+        if (NW > 1) {
+          if (!FWD) xb[cur][l + 1] = vb;
+          xl[cur][l + 1] = vl;
+        }
+        if (i % kCtcRescale == kCtcRescale - 1) {  // the next step rescales: the largest state of this frame
+          emax = ctc_wave_max(max(ctc_exponent(vb), ctc_exponent(vl)));
+          if (NW > 1 && (l & 63) == 0) xe[cur][wave] = emax;
+        }
         *reinterpret_cast<double2*>(w + (long)t * 2 * NT + 2 * l) = make_double2(vb, vl);
-        ctc_sync<NW>();
+        if (wave == 0) ex[t] = E;  // every lane the same value to the same word
+        if (NW > 1) ctc_sync<NW>();
       }
     }
 #pragma unroll
@@ -493,7 +554,8 @@ __device__ __forceinline__ int ctc_sweep(const float* __restrict__ lpb, int V, i
   return cur;
 }
 
-// workspace of the two kernels: alpha [B][T][2 NT], beta [B][T][2 NT], nll [B], all doubles
+// workspace of the two kernels: alpha [B][T][2 NT], beta [B][T][2 NT], nll [B] (doubles), then the cumulative
+// shifts of alpha and of beta, [B][T] int32 each
 template <int NW, bool BOTH>
 __global__ __launch_bounds__(64 * NW * (BOTH ? 2 : 1)) void k_ctc_alpha_beta(
     const float* __restrict__ log_probs, const int64_t* __restrict__ targets, long ld, const int32_t* __restrict__ input_lengths,
@@ -502,6 +564,7 @@ __global__ __launch_bounds__(64 * NW * (BOTH ? 2 : 1)) void k_ctc_alpha_beta(
   constexpr int NT = 64 * NW;
   constexpr int ND = BOTH ? 2 : 1;
   __shared__ double xb[ND][2][NT + 2], xl[ND][2][NT + 2];
+  __shared__ int xe[ND][2][NW];
   __shared__ int lab[NT + 1];
   const int b = blockIdx.x;
   const int l = threadIdx.x & (NT - 1), half = BOTH ? threadIdx.x / NT : 0;
@@ -511,6 +574,8 @@ __global__ __launch_bounds__(64 * NW * (BOTH ? 2 : 1)) void k_ctc_alpha_beta(
   double* alpha = ws + (long)b * T * 2 * NT;
   double* beta = ws + ((long)B + b) * T * 2 * NT;
   double* nll_d = ws + (long)2 * B * T * 2 * NT;
+  int* ex_alpha = reinterpret_cast<int*>(nll_d + B) + (long)b * T;
+  int* ex_beta = ex_alpha + (long)B * T;
   const int my_label = l < L ? min(max((int)targets[(long)b * ld + l], 0), V - 1) : blank;
   if (half == 0) lab[l] = my_label;
   if (threadIdx.x == 0) lab[NT] = blank;
@@ -525,35 +590,45 @@ __global__ __launch_bounds__(64 * NW * (BOTH ? 2 : 1)) void k_ctc_alpha_beta(
   const bool skip_prev = l >= 1 && l < L && lab[l - 1] != my_label;  // label l may be entered from label l-1
   const bool skip_next = l + 1 < L && lab[l + 1] != my_label;        // label l may move on to label l+1
   double vb, vl;
+  int E;
   if (half == 0) {
-    const int cur = ctc_sweep<NW, true>(lpb, V, blank, my_label, l, L, Tb, skip_prev, alpha, xb[0], xl[0], vb, vl);
-    if (l == L) {  // vb = alpha(2L); alpha(2L-1) is the label value of thread L-1
-      const double ll = ctc_lse2(vb, xl[0][cur][L]);
+    const int cur = ctc_sweep<NW, true>(lpb, V, blank, my_label, l, L, Tb, skip_prev, alpha, ex_alpha, xb[0], xl[0], xe[0],
+                                        vb, vl, E);
+    const double below = NW == 1 ? ctc_lane_below(vl) : xl[0][cur][l];  // label value of thread l-1
+    if (l == L) {  // vb = alpha(2L), below = alpha(2L-1)
+      const double ll = log(vb + below) + (double)E * 0.6931471805599453;
       nll_out[b] = (float)-ll;
       nll_d[b] = -ll;
     }
   }
   if (!BOTH) __syncthreads();  // the exchange buffers are used again
-  if (half == ND - 1) ctc_sweep<NW, false>(lpb, V, blank, my_label, l, L, Tb, skip_next, beta, xb[ND - 1], xl[ND - 1], vb, vl);
+  if (half == ND - 1)
+    ctc_sweep<NW, false>(lpb, V, blank, my_label, l, L, Tb, skip_next, beta, ex_beta, xb[ND - 1], xl[ND - 1], xe[ND - 1], vb, vl,
+                         E);
 }
 
-constexpr int kCtcGradWaves = 4;    // one frame per wave at a time
 constexpr int kCtcGradFrames = 16;  // frames per workgroup
+// waves per workgroup, one frame per wave at a time (two for the longest targets: a wave's products take 16 KB of LDS)
+constexpr int ctc_grad_waves(int NW) { return NW >= 16 ? 2 : 4; }
 
 template <int NW>
-__global__ __launch_bounds__(64 * kCtcGradWaves) void k_ctc_grad(
+__global__ __launch_bounds__(64 * ctc_grad_waves(NW)) void k_ctc_grad(
     const float* __restrict__ log_probs, const int64_t* __restrict__ targets, long ld, const int32_t* __restrict__ input_lengths,
     const int32_t* __restrict__ target_lengths, int B, int T, int V, int blank, int mean, int zero_infinity,
     float* __restrict__ grad, const double* __restrict__ ws) {
   constexpr int NT = 64 * NW;
-  __shared__ float x[kCtcGradWaves][2 * NT];
+  constexpr int kCtcGradWaves = ctc_grad_waves(NW);
+  __shared__ double x[kCtcGradWaves][2 * NT];
   __shared__ int lab[NT];
   __shared__ int cls_start[65], cls_pos[NT];
   const int b = blockIdx.y, t_first = blockIdx.x * kCtcGradFrames;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int Tb = min(max(input_lengths[b], 0), T);
   const int L = min(max(target_lengths[b], 0), NT - 1);
-  const double nll = ws[(long)2 * B * T * 2 * NT + b];
+  const double* nll_d = ws + (long)2 * B * T * 2 * NT;
+  const int* ex_alpha = reinterpret_cast<const int*>(nll_d + B) + (long)b * T;
+  const int* ex_beta = ex_alpha + (long)B * T;
+  const double nll = nll_d[b];
   const bool dead = !(nll < (double)INFINITY);  // no valid alignment (or NaN)
   float* gb = grad + (long)b * T * V;
   const int t_end = min(t_first + kCtcGradFrames, T);
@@ -584,7 +659,7 @@ __global__ __launch_bounds__(64 * kCtcGradWaves) void k_ctc_grad(
   __syncthreads();
   const float w = mean ? 1.f / ((float)B * (float)max(L, 1)) : 1.f;
   const int S = 2 * L + 1;
-  float* xw = x[wave];
+  double* xw = x[wave];
   for (int t = t_first + wave; t < t_end; t += kCtcGradWaves) {
     float g = 0.f;
     if (t < Tb) {
@@ -594,31 +669,25 @@ __global__ __launch_bounds__(64 * kCtcGradWaves) void k_ctc_grad(
       } else {
         const double* a = ws + ((long)b * T + t) * 2 * NT;
         const double* bt = ws + (((long)B + b) * T + t) * 2 * NT;
-        // log of (path mass through the state) x p_t(class) over the total: a few units around lp, so fp32 from here
-        for (int s = lane; s < S; s += 64) xw[s] = (float)(a[s] + bt[s] + nll);
+        for (int s = lane; s < S; s += 64) xw[s] = a[s] * bt[s];  // (path mass through the state) x p_t(class), scaled
         ctc_wave_sync();
-        float lab_sum;
-        {  // blank class: states 0, 2, .., 2L over the lanes
-          float m = -INFINITY;
-          for (int i = lane; i <= L; i += 64) m = fmaxf(m, xw[2 * i]);
+        double sum = 0.0;
+        for (int i = lane; i <= L; i += 64) sum += xw[2 * i];  // blank class: states 0, 2, .., 2L over the lanes
 #pragma unroll
-          for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-          float e = 0.f;
-          if (m != -INFINITY)
-            for (int i = lane; i <= L; i += 64) e += __expf(xw[2 * i] - m);
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
-          lab_sum = m == -INFINITY ? -INFINITY : m + __logf(e);
-        }
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
         if (lane < V && lane != blank) {
-          const int p0 = cls_start[lane], p1 = cls_start[lane + 1];
-          float mm = -INFINITY;
-          for (int i = p0; i < p1; ++i) mm = fmaxf(mm, xw[2 * cls_pos[i] + 1]);
-          float ss = 0.f;
-          for (int i = p0; i < p1; ++i) ss += __expf(xw[2 * cls_pos[i] + 1] - mm);
-          lab_sum = mm == -INFINITY ? -INFINITY : mm + __logf(ss);
+          sum = 0.0;
+          for (int i = cls_start[lane]; i < cls_start[lane + 1]; ++i) sum += xw[2 * cls_pos[i] + 1];
         }
-        const float occ = lab_sum == -INFINITY ? 0.f : __expf(lab_sum - lpc);
+        // occupancy = sum 2^(E_t + F_t) exp(nll) / p_t(c): the mantissa as it is, everything else as one exponent --
+        // a few units below zero, so fp32 from here
+        float occ = 0.f;
+        if (sum > 0.0) {
+          const int e2 = ctc_exponent(sum) - 1022;  // sum = m 2^e2, m in [0.5, 1)
+          const double m = __hiloint2double((__double2hiint(sum) & 0x800FFFFF) | (1022 << 20), __double2loint(sum));
+          const double arg = (double)(ex_alpha[t] + ex_beta[t] + e2) * 0.6931471805599453 + nll - (double)lpc;
+          occ = (float)m * __expf((float)arg);
+        }
         g = w * (__expf(lpc) - occ);
         ctc_wave_sync();  // the next frame overwrites xw
       }
@@ -732,7 +801,8 @@ static int ctc_loss_waves(int Lmax) {
 
 size_t lmufft_ctc_loss_workspace_bytes(int32_t B, int32_t T, int32_t Lmax) {
   if (B <= 0 || T <= 0 || Lmax < 0 || Lmax + 1 > 1024) return 0;
-  return sizeof(double) * ((size_t)2 * B * T * 2 * 64 * (size_t)ctc_loss_waves(Lmax) + (size_t)B);
+  return sizeof(double) * ((size_t)2 * B * T * 2 * 64 * (size_t)ctc_loss_waves(Lmax) + (size_t)B) +
+         sizeof(int32_t) * (size_t)2 * B * T;
 }
 
 int lmufft_ctc_loss(const float* log_probs, const int64_t* targets, int64_t ld, const int32_t* input_lengths,
@@ -757,7 +827,7 @@ int lmufft_ctc_loss(const float* log_probs, const int64_t* targets, int64_t ld, 
   do {                                                                                                                  \
     hipLaunchKernelGGL((k_ctc_alpha_beta<NWV, BOTH>), dim3(B), dim3(64 * NWV * (BOTH ? 2 : 1)), 0, st, log_probs,       \
                        targets, (long)ld, input_lengths, target_lengths, B, T, V, blank, nll, (double*)workspace);      \
-    hipLaunchKernelGGL(k_ctc_grad<NWV>, ggrid, dim3(64 * kCtcGradWaves), 0, st, log_probs, targets, (long)ld,           \
+    hipLaunchKernelGGL(k_ctc_grad<NWV>, ggrid, dim3(64 * ctc_grad_waves(NWV)), 0, st, log_probs, targets, (long)ld,     \
                        input_lengths, target_lengths, B, T, V, blank, reduction_mean, zero_infinity, grad,              \
                        (const double*)workspace);                                                                       \
   } while (0)

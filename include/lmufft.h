@@ -342,8 +342,9 @@ int lmufft_ctc_pack_targets(const int64_t* targets, const int32_t* target_length
  *   with zero_infinity an utterance whose nll is infinite gets a zero gradient.
  * The loss of the 'mean' reduction is mean_b(nll_b / max(L_b, 1)), infinite terms replaced by 0 under
  * zero_infinity; multiply grad by the upstream gradient of the loss.
- * The forward/backward recursions accumulate in double (their values grow like T log V); the workspace
- * (16-byte aligned, lmufft_ctc_loss_workspace_bytes) holds the forward variables of every frame.
+ * The forward/backward recursions run on doubles in the linear domain, rescaled by an exact power of two at every
+ * frame; the workspace (16-byte aligned, lmufft_ctc_loss_workspace_bytes) holds both sets of variables and their
+ * scales for every frame.
  * ---------------------------------------------------------------------- */
 size_t lmufft_ctc_loss_workspace_bytes(int32_t B, int32_t T, int32_t Lmax);
 int lmufft_ctc_loss(const float* log_probs, const int64_t* targets, int64_t ld, const int32_t* input_lengths,
