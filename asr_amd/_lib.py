@@ -18,8 +18,9 @@ BF16 = 1
 CONV_AUTO = 0
 CONV_TOEPLITZ = 1
 CONV_FFT = 2
+CONV_SCAN = 3
 NOALLOC_SCRATCH_BYTES = 8 << 20
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class Shape(ctypes.Structure):
@@ -103,15 +104,27 @@ def _load():
     lib.lmufft_wprep_bf16.restype = ci
     lib.lmufft_wprep_bf16.argtypes = [sp, vp, vp, vp]
     lib.lmufft_forward_bf16.restype = ci
-    lib.lmufft_forward_bf16.argtypes = [sp] + [vp] * 11 + [ci, vp, sz, vp]
+    lib.lmufft_forward_bf16.argtypes = [sp] + [vp] * 12 + [ci, vp, sz, vp]
     lib.lmufft_forward_ln_bf16.restype = ci
-    lib.lmufft_forward_ln_bf16.argtypes = [sp] + [vp] * 13 + [ctypes.c_float, vp, ci, ci, vp, sz, vp]
+    lib.lmufft_forward_ln_bf16.argtypes = [sp] + [vp] * 14 + [ctypes.c_float, vp, ci, ci, vp, sz, vp]
     lib.lmufft_conv_forward_bf16.restype = ci
     lib.lmufft_conv_forward_bf16.argtypes = [sp, vp, vp, vp, vp]
     lib.lmufft_conv_backward_bf16.restype = ci
     lib.lmufft_conv_backward_bf16.argtypes = [sp, vp, vp, vp, vp, sz, vp]
     lib.lmufft_backward_bf16.restype = ci
-    lib.lmufft_backward_bf16.argtypes = [sp] + [vp] * 15 + [ci, vp, sz, vp]
+    lib.lmufft_backward_bf16.argtypes = [sp] + [vp] * 16 + [ci, vp, sz, vp]
+    lib.lmufft_scan_chunk.restype = ctypes.c_int32
+    lib.lmufft_scan_chunk.argtypes = []
+    lib.lmufft_scanprep_bytes.restype = sz
+    lib.lmufft_scanprep_bytes.argtypes = [ctypes.c_int32]
+    lib.lmufft_scanprep_build_host.restype = ci
+    lib.lmufft_scanprep_build_host.argtypes = [vp, vp, ctypes.c_int32, vp]
+    lib.lmufft_conv_scan_workspace_bytes.restype = sz
+    lib.lmufft_conv_scan_workspace_bytes.argtypes = [sp]
+    lib.lmufft_conv_forward_scan_bf16.restype = ci
+    lib.lmufft_conv_forward_scan_bf16.argtypes = [sp, vp, vp, vp, vp, sz, vp]
+    lib.lmufft_conv_backward_scan_bf16.restype = ci
+    lib.lmufft_conv_backward_scan_bf16.argtypes = [sp, vp, vp, vp, vp, sz, vp]
     u32, i32, i64, f32 = ctypes.c_uint32, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
     lib.lmufft_attention_fwd_train.restype = ci
     lib.lmufft_attention_fwd_train.argtypes = [vp, vp, vp, ci, i64, vp, i32, i32, i32, i32, f32, u32, u32, vp, vp, vp]
@@ -212,6 +225,12 @@ EXPORTS = (
     "lmufft_backward_bf16",
     "lmufft_conv_forward_bf16",
     "lmufft_conv_backward_bf16",
+    "lmufft_scan_chunk",
+    "lmufft_scanprep_bytes",
+    "lmufft_scanprep_build_host",
+    "lmufft_conv_scan_workspace_bytes",
+    "lmufft_conv_forward_scan_bf16",
+    "lmufft_conv_backward_scan_bf16",
     "lmufft_profile_enable",
     "lmufft_profile_reset",
     "lmufft_profile_count",

@@ -1148,7 +1148,7 @@ static WprepLayout wprep_layout(const lmufft_shape& s) {
 struct BwdPlanB {
   int S, rps, ntt, cb2_P;
   long slab_floats;
-  size_t off_gz, off_wslab, off_gupart, off_ga, total;
+  size_t off_gz, off_wslab, off_gupart, off_ga, off_scan, scan_bytes, total;
 };
 // slab of the weight-gradient kernel: gW_h | RB copies of gb_h | RU copies of gw_u | gb_u
 static SlabOutputs wgrad_outputs(const lmufft_shape& s, float* gW_h, float* gb_h, float* gw_u, float* gb_u) {
@@ -1187,11 +1187,16 @@ static BwdPlanB plan_backward_b(const lmufft_shape& s) {
   off += align256b(sizeof(float) * std::max((size_t)s.B * p.ntt * s.T, (size_t)p.cb2_P * s.B * s.T));
   p.off_ga = off;
   off += align256b(sizeof(float) * (size_t)rows);
+  p.off_scan = off;  // scratch of the state-space route (slabs of its adjoint GEMM)
+  p.scan_bytes = scan_workspace_bytes(s.B, s.T, s.M);
+  off += align256b(p.scan_bytes);
   p.total = off;
   return p;
 }
 
-size_t forward_workspace_bf16(const lmufft_shape&) { return 256; }
+size_t forward_workspace_bf16(const lmufft_shape& s) {
+  return 256 + scan_forward_workspace_bytes(std::max(s.B, 1), std::max(s.T, 1), s.M);
+}
 size_t conv_workspace_bf16(const lmufft_shape& s0) {
   lmufft_shape s = s0;
   s.D = std::max(s.D, 1);
@@ -1304,14 +1309,24 @@ static int conv_forward_bf16_any(const lmufft_shape& sh, const float* u, const b
   return 0;
 }
 
+// The state-space route runs when it is asked for, and under AUTO whenever the caller hands in `scanprep`.
+static int use_scan_route(int conv_algo, const void* scanprep, bool* scan) {
+  if (conv_algo != LMUFFT_CONV_AUTO && conv_algo != LMUFFT_CONV_TOEPLITZ && conv_algo != LMUFFT_CONV_SCAN)
+    return set_error("conv algorithm %d is not available for bf16", conv_algo);
+  if (conv_algo == LMUFFT_CONV_SCAN && !scanprep) return set_error("conv algorithm SCAN needs scanprep");
+  *scan = conv_algo == LMUFFT_CONV_SCAN || (conv_algo == LMUFFT_CONV_AUTO && scanprep);
+  return 0;
+}
+
 static int forward_bf16_impl(const lmufft_shape* s, const void* x_, const float* w_u, const float* b_u, void* wprep,
-                             const float* W_h, const float* b_h, const void* hprep, float* u, void* m_, void* h_,
-                             void* h_n_, int conv_algo, void* stream, const LnEpilogue& ln) {
+                             const float* W_h, const float* b_h, const void* hprep, const void* scanprep, float* u,
+                             void* m_, void* h_, void* h_n_, int conv_algo, void* workspace, size_t workspace_bytes,
+                             void* stream, const LnEpilogue& ln) {
   if (int rc = check_shape_b(s)) return rc;
   if (!x_ || !w_u || !b_u || !wprep || !b_h || !hprep || !u || !m_ || (!h_ && !ln.y) || !h_n_)
     return set_error("forward: NULL pointer");
-  if (conv_algo != LMUFFT_CONV_AUTO && conv_algo != LMUFFT_CONV_TOEPLITZ)
-    return set_error("conv algorithm %d is not available for bf16", conv_algo);
+  bool scan = false;
+  if (int rc = use_scan_route(conv_algo, scanprep, &scan)) return rc;
   if (!al16(wprep) || !al16(hprep)) return set_error("forward: wprep/hprep must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const bf16_t* x = (const bf16_t*)x_;
@@ -1339,7 +1354,11 @@ static int forward_bf16_impl(const lmufft_shape* s, const void* x_, const float*
                          prep_blocks);
   }
   LAUNCH_CHECKB("k_encode_fwd_bf16");
-  if (int rc = conv_forward_bf16_any(*s, u, Hb, hl.ldHb, m, st)) return rc;
+  if (scan) {
+    if (int rc = scan_conv_forward(*s, u, scanprep, m, workspace, workspace_bytes, st)) return rc;
+  } else if (int rc = conv_forward_bf16_any(*s, u, Hb, hl.ldHb, m, st)) {
+    return rc;
+  }
   {
     using TL = ProjTileB;
     const bool vec = (s->M % 8 == 0) && (s->D % 8 == 0) && (s->Hd % 8 == 0) && al16(m) && al16(x) && al16(h) &&
@@ -1442,36 +1461,33 @@ static int conv_backward_bf16_any(const lmufft_shape& sh, const bf16_t* gm, cons
 extern "C" {
 
 int lmufft_forward_bf16(const lmufft_shape* s, const void* x, const float* w_u, const float* b_u, void* wprep,
-                        const float* W_h, const float* b_h, const void* hprep, float* u, void* m, void* h, void* h_n,
-                        int conv_algo, void* workspace, size_t workspace_bytes, void* stream) {
-  (void)workspace;
-  (void)workspace_bytes;
+                        const float* W_h, const float* b_h, const void* hprep, const void* scanprep, float* u, void* m,
+                        void* h, void* h_n, int conv_algo, void* workspace, size_t workspace_bytes, void* stream) {
   if (!h) return set_error("forward: NULL pointer");
-  return forward_bf16_impl(s, x, w_u, b_u, wprep, W_h, b_h, hprep, u, m, h, h_n, conv_algo, stream,
-                           LnEpilogue{nullptr, nullptr, 0.f, nullptr, 0});
+  return forward_bf16_impl(s, x, w_u, b_u, wprep, W_h, b_h, hprep, scanprep, u, m, h, h_n, conv_algo, workspace,
+                           workspace_bytes, stream, LnEpilogue{nullptr, nullptr, 0.f, nullptr, 0});
 }
 
 int lmufft_forward_ln_bf16(const lmufft_shape* s, const void* x, const float* w_u, const float* b_u, void* wprep,
-                           const float* W_h, const float* b_h, const void* hprep, float* u, void* m, void* h,
-                           void* h_n, const float* gamma, const float* beta, float eps, void* y, int y_dtype,
-                           int conv_algo, void* workspace, size_t workspace_bytes, void* stream) {
-  (void)workspace;
-  (void)workspace_bytes;
+                           const float* W_h, const float* b_h, const void* hprep, const void* scanprep, float* u,
+                           void* m, void* h, void* h_n, const float* gamma, const float* beta, float eps, void* y,
+                           int y_dtype, int conv_algo, void* workspace, size_t workspace_bytes, void* stream) {
   if (!gamma || !beta || !y) return set_error("forward with layer norm: NULL pointer");
   if (y_dtype != LMUFFT_F32 && y_dtype != LMUFFT_BF16) return set_error("forward with layer norm: unknown dtype");
-  return forward_bf16_impl(s, x, w_u, b_u, wprep, W_h, b_h, hprep, u, m, h, h_n, conv_algo, stream,
-                           LnEpilogue{gamma, beta, eps, y, y_dtype == LMUFFT_BF16});
+  return forward_bf16_impl(s, x, w_u, b_u, wprep, W_h, b_h, hprep, scanprep, u, m, h, h_n, conv_algo, workspace,
+                           workspace_bytes, stream, LnEpilogue{gamma, beta, eps, y, y_dtype == LMUFFT_BF16});
 }
 
 int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u, const void* wprep,
-                         const void* hprep, const float* u, const void* m_, const void* h_, const void* gh_,
+                         const void* hprep, const void* scanprep, const float* u, const void* m_, const void* h_,
+                         const void* gh_,
                          const void* gh_n_, void* gx_, float* gw_u, float* gb_u, float* gW_h, float* gb_h,
                          void* gm_, int conv_algo, void* workspace, size_t workspace_bytes, void* stream) {
   if (int rc = check_shape_b(s)) return rc;
   if (!x_ || !w_u || !wprep || !hprep || !u || !m_ || !h_ || !gw_u || !gb_u || !gW_h || !gb_h || !gm_)
     return set_error("backward: NULL pointer");
-  if (conv_algo != LMUFFT_CONV_AUTO && conv_algo != LMUFFT_CONV_TOEPLITZ)
-    return set_error("conv algorithm %d is not available for bf16", conv_algo);
+  bool scan = false;
+  if (int rc = use_scan_route(conv_algo, scanprep, &scan)) return rc;
   const BwdPlanB p = plan_backward_b(*s);
   if (!workspace || workspace_bytes < p.total)
     return set_error("backward: workspace of %zu bytes needed, %zu given", p.total, workspace_bytes);
@@ -1547,7 +1563,11 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
   const bool dgrad_x_fast = gx && (s->Hd % 8 == 0) && (s->D % 8 == 0) && al16(gx);
   GaParts ga_parts = no_parts;
   // ga = (adjoint conv of gm) * (u > 0)
-  if (int rc = conv_backward_bf16_any(*s, gm, hl, HbT, p, gupart, u, ga, dgrad_x_fast, &ga_parts, st)) return rc;
+  if (scan) {
+    if (int rc = scan_conv_backward(*s, gm, scanprep, u, ga, ws + p.off_scan, p.scan_bytes, st)) return rc;
+  } else if (int rc = conv_backward_bf16_any(*s, gm, hl, HbT, p, gupart, u, ga, dgrad_x_fast, &ga_parts, st)) {
+    return rc;
+  }
   // gx = gz W_h[:, M:] + ga w_u
   if (gx)
     if (int rc = dgrad(DgradXGldsTile{}, DgradXTileB{}, "k_dgrad_x_bf16", gx, s->M, s->D, (const float*)ga, w_u, ga_parts))

@@ -59,6 +59,16 @@ int fft_conv_groups(int M);
 // gu[b][s], times (u[b][s] > 0) when u != NULL
 int fft_conv_backward(const lmufft_shape& s, const float* gm, const void* prep, const float* u, float* gu, void* ws,
                       hipStream_t st);
+// State-space ("scan") route of the bf16 causal convolution for long sequences (defined in scan_conv_bf16.hip).
+// `scanprep`: lmufft_scanprep_bytes(M) bytes built by lmufft_scanprep_build_host and copied to the device.
+bool scan_supported(int M);
+size_t scan_forward_workspace_bytes(int B, int T, int M);  // 0 when the route does not support M
+size_t scan_workspace_bytes(int B, int T, int M);          // either direction
+int scan_conv_forward(const lmufft_shape& s, const float* u, const void* scanprep, __bf16* m, void* ws, size_t ws_bytes,
+                      hipStream_t st);
+// gu[b][s], times (u[b][s] > 0) when u != NULL
+int scan_conv_backward(const lmufft_shape& s, const __bf16* gm, const void* scanprep, const float* u, float* gu,
+                       void* ws, size_t ws_bytes, hipStream_t st);
 // out[i] = sum_p part[p*n + i], masked by u[i] > 0 when u != NULL (defined in lmufft_f32.hip)
 int launch_sum_slabs_masked(const float* part, const float* u, float* out, long n, int P, hipStream_t st);
 

@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 
-_ALGOS = {"auto": _lib.CONV_AUTO, "toeplitz": _lib.CONV_TOEPLITZ, "fft": _lib.CONV_FFT}
+_ALGOS = {"auto": _lib.CONV_AUTO, "toeplitz": _lib.CONV_TOEPLITZ, "fft": _lib.CONV_FFT, "scan": _lib.CONV_SCAN}
 _DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
 
 
@@ -54,6 +54,33 @@ def prepare_impulse_bf16(H: torch.Tensor) -> torch.Tensor:
         rc = _lib.lib.lmufft_hprep_bf16(ctypes.byref(shp), _ptr(H), _ptr(buf), _stream(H.device))
     _lib.check(rc, "lmufft_hprep_bf16")
     return buf
+
+
+def scan_supported(M: int) -> bool:
+    """True when the state-space ("scan") convolution route of the bf16 path takes memory size M."""
+    return _lib.lib.lmufft_scanprep_bytes(int(M)) != 0
+
+
+def prepare_scan_bf16(A: torch.Tensor, B: torch.Tensor, device=None) -> torch.Tensor:
+    """Constants of the state-space convolution route (powers of A, the chunk's Toeplitz block, the
+    chunk-to-chunk transition), built once per (A, B) by the library on the host and copied to `device`.
+
+    A [M, M] and B [M, 1] are the module's buffers (src/lmu.py:240-241); H = [A^t B] is what the route
+    reproduces."""
+    import numpy as np
+
+    M = A.shape[0]
+    nbytes = _lib.lib.lmufft_scanprep_bytes(int(M))
+    if nbytes == 0:
+        raise RuntimeError(f"LMUFFT: the scan convolution route does not support memory_size {M} "
+                           "(multiples of 8 up to 256)")
+    device = A.device if device is None else device
+    a = np.ascontiguousarray(A.detach().float().cpu().numpy())
+    b = np.ascontiguousarray(B.detach().float().cpu().numpy().reshape(-1))
+    host = np.empty(nbytes, dtype=np.uint8)
+    rc = _lib.lib.lmufft_scanprep_build_host(a.ctypes.data, b.ctypes.data, int(M), host.ctypes.data)
+    _lib.check(rc, "lmufft_scanprep_build_host")
+    return torch.from_numpy(host).to(device)
 
 
 def fft_supported(T: int, M: int = 1) -> bool:
@@ -109,7 +136,7 @@ class _LMUFFTFunction(torch.autograd.Function):
     """(x, w_u, b_u, W_h, b_h, H) -> (h, h_n); reference: src/lmu.py:290-320."""
 
     @staticmethod
-    def forward(ctx, x, w_u, b_u, W_h, b_h, H, conv_algo, hprep, fftprep, grad_sink):
+    def forward(ctx, x, w_u, b_u, W_h, b_h, H, conv_algo, hprep, fftprep, grad_sink, scanprep=None):
         _require_gpu(x, "x")
         if x.dtype not in _DTYPES:
             raise RuntimeError(f"LMUFFT: x has dtype {x.dtype}; supported: float32, bfloat16")
@@ -163,11 +190,12 @@ class _LMUFFTFunction(torch.autograd.Function):
                 wprep = _workspace(_lib.lib.lmufft_wprep_bytes(ctypes.byref(shp)), dev)
                 rc = _lib.lib.lmufft_forward_bf16(
                     ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(b_u), _ptr(wprep), _ptr(W_h), _ptr(b_h), _ptr(hprep),
-                    _ptr(u), _ptr(m), _ptr(h), _ptr(h_n), conv_algo, _ptr(ws), ws.numel(), _stream(dev))
+                    _ptr(scanprep), _ptr(u), _ptr(m), _ptr(h), _ptr(h_n), conv_algo, _ptr(ws), ws.numel(),
+                    _stream(dev))
                 what = "lmufft_forward_bf16"
         _lib.check(rc, what)
         ctx.save_for_backward(x, w_u, W_h, H, u, m, h, hprep, wprep if dt != torch.float32 else None,
-                              fftprep if dt == torch.float32 else None)
+                              fftprep if dt == torch.float32 else None, scanprep if dt != torch.float32 else None)
         ctx.conv_algo = conv_algo
         ctx.grad_sink = grad_sink
         ctx.shape = (B, T, D, M, Hd, ldH)
@@ -176,13 +204,13 @@ class _LMUFFTFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gh, gh_n):
-        x, w_u, W_h, H, u, m, h, hprep, wprep, fftprep = ctx.saved_tensors
+        x, w_u, W_h, H, u, m, h, hprep, wprep, fftprep, scanprep = ctx.saved_tensors
         B, T, D, M, Hd, ldH = ctx.shape
         dev = x.device
         dt = x.dtype
         need_x = ctx.needs_input_grad[0]
         if gh is None and gh_n is None:
-            return (None,) * 10
+            return (None,) * 11
         if gh is not None:
             gh = gh.to(dt).contiguous()
         if gh_n is not None:
@@ -211,19 +239,20 @@ class _LMUFFTFunction(torch.autograd.Function):
                 what = "lmufft_backward_f32"
             else:
                 rc = _lib.lib.lmufft_backward_bf16(
-                    ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(wprep), _ptr(hprep), _ptr(u), _ptr(m), _ptr(h),
-                    _ptr(gh), _ptr(gh_n), _ptr(gx), _ptr(gw_u), _ptr(gb_u), _ptr(gW_h), _ptr(gb_h), _ptr(gm),
+                    ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(wprep), _ptr(hprep), _ptr(scanprep), _ptr(u), _ptr(m),
+                    _ptr(h), _ptr(gh), _ptr(gh_n), _ptr(gx), _ptr(gw_u), _ptr(gb_u), _ptr(gW_h), _ptr(gb_h), _ptr(gm),
                     ctx.conv_algo, _ptr(ws), ws.numel(), _stream(dev))
                 what = "lmufft_backward_bf16"
         _lib.check(rc, what)
         if direct:
             sink.commit()
-            return (gx,) + (None,) * 9
+            return (gx,) + (None,) * 10
         pd = ctx.param_dtypes
-        return gx, gw_u.to(pd[0]), gb_u.to(pd[1]), gW_h.to(pd[2]), gb_h.to(pd[3]), None, None, None, None, None
+        return gx, gw_u.to(pd[0]), gb_u.to(pd[1]), gW_h.to(pd[2]), gb_h.to(pd[3]), None, None, None, None, None, None
 
 
-def lmufft_layer(x, w_u, b_u, W_h, b_h, H, conv_algo="auto", hprep=None, fftprep=None, grad_sink=None):
+def lmufft_layer(x, w_u, b_u, W_h, b_h, H, conv_algo="auto", hprep=None, fftprep=None, grad_sink=None,
+                 scanprep=None):
     """h, h_n = LMUFFT forward with autograd support (HIP kernels only).
 
     x float32 -> exact-fp32 kernels; x bfloat16 -> bf16 kernels with fp32
@@ -231,8 +260,10 @@ def lmufft_layer(x, w_u, b_u, W_h, b_h, H, conv_algo="auto", hprep=None, fftprep
     `fftprep` = prepare_impulse_fft(H, T) enables the FFT convolution of the
     fp32 path (required for conv_algo="fft", built on the fly if None).
     `grad_sink` (a GradSink) receives the parameter gradients in place.
+    `scanprep` = prepare_scan_bf16(A, B) makes the bf16 path take the state-space convolution route
+    (conv_algo "auto" or "scan"; required for "scan").
     """
-    return _LMUFFTFunction.apply(x, w_u, b_u, W_h, b_h, H, _ALGOS[conv_algo], hprep, fftprep, grad_sink)
+    return _LMUFFTFunction.apply(x, w_u, b_u, W_h, b_h, H, _ALGOS[conv_algo], hprep, fftprep, grad_sink, scanprep)
 
 
 def lmufft_layer_norm_inference(x, w_u, b_u, W_h, b_h, H, ln_weight, ln_bias, eps=1e-5, out_dtype=torch.float32,
@@ -267,9 +298,9 @@ def lmufft_layer_norm_inference(x, w_u, b_u, W_h, b_h, H, ln_weight, ln_bias, ep
     with torch.cuda.device(dev):
         wprep = _workspace(_lib.lib.lmufft_wprep_bytes(ctypes.byref(shp)), dev)
         rc = _lib.lib.lmufft_forward_ln_bf16(
-            ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(b_u), _ptr(wprep), _ptr(W_h), _ptr(b_h), _ptr(hprep), _ptr(u),
-            _ptr(m), None, _ptr(h_n), _ptr(g), _ptr(b), float(eps), _ptr(y), _DTYPES[out_dtype], _lib.CONV_AUTO, None, 0,
-            _stream(dev))
+            ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(b_u), _ptr(wprep), _ptr(W_h), _ptr(b_h), _ptr(hprep), None,
+            _ptr(u), _ptr(m), None, _ptr(h_n), _ptr(g), _ptr(b), float(eps), _ptr(y), _DTYPES[out_dtype],
+            _lib.CONV_AUTO, None, 0, _stream(dev))
     _lib.check(rc, "lmufft_forward_ln_bf16")
     return y, h_n
 
@@ -361,13 +392,62 @@ def causal_conv_adjoint_bf16(gm, H, hprep=None, workspace=None, out=None):
     return gu
 
 
-def conv_pair_runner(u, H, conv_algo, dtype):
+def causal_conv_scan_bf16(u, scanprep, M, workspace=None):
+    """m = causal convolution of u [B, T] (fp32) with H = [A^t B], written as bf16 [B, T, M] by the
+    state-space route (no autograd; kernel-level entry point, src/lmu.py:303-312)."""
+    _require_gpu(u, "u")
+    u = u.contiguous().float()
+    B, T = u.shape
+    m = torch.empty((B, T, M), dtype=torch.bfloat16, device=u.device)
+    shp = _shape(B, T, 1, M, 1, T)
+    with torch.cuda.device(u.device):
+        if workspace is None:
+            workspace = _workspace(_lib.lib.lmufft_conv_scan_workspace_bytes(ctypes.byref(shp)), u.device)
+        rc = _lib.lib.lmufft_conv_forward_scan_bf16(ctypes.byref(shp), _ptr(u), _ptr(scanprep), _ptr(m),
+                                                   _ptr(workspace), workspace.numel(), _stream(u.device))
+    _lib.check(rc, "lmufft_conv_forward_scan_bf16")
+    return m
+
+
+def causal_conv_adjoint_scan_bf16(gm, scanprep, workspace=None):
+    """gu[b,s] = sum_{t>=s} sum_k H[k,t-s] gm[b,t,k] for bf16 gm by the state-space route (fp32 result)."""
+    _require_gpu(gm, "gm")
+    if gm.dtype != torch.bfloat16:
+        raise RuntimeError("causal_conv_adjoint_scan_bf16: gm must be bfloat16")
+    gm = gm.contiguous()
+    B, T, M = gm.shape
+    gu = torch.empty((B, T), dtype=torch.float32, device=gm.device)
+    shp = _shape(B, T, 1, M, 1, T)
+    with torch.cuda.device(gm.device):
+        if workspace is None:
+            workspace = _workspace(_lib.lib.lmufft_conv_scan_workspace_bytes(ctypes.byref(shp)), gm.device)
+        rc = _lib.lib.lmufft_conv_backward_scan_bf16(ctypes.byref(shp), _ptr(gm), _ptr(scanprep), _ptr(gu),
+                                                    _ptr(workspace), workspace.numel(), _stream(gm.device))
+    _lib.check(rc, "lmufft_conv_backward_scan_bf16")
+    return gu
+
+
+def conv_pair_runner(u, H, conv_algo, dtype, scanprep=None):
     """A callable that runs the causal convolution of u and the adjoint of its result through the
     C ABI's conv-only entry points with every buffer preallocated (benchmarks)."""
     dev = u.device
     B, T = u.shape
     M, ldH = H.shape
     shp = _shape(B, T, 1, M, 1, ldH)
+    if dtype == "bf16" and conv_algo == "scan":
+        m = torch.empty((B, T, M), dtype=torch.bfloat16, device=dev)
+        gu = torch.empty((B, T), dtype=torch.float32, device=dev)
+        ws = _workspace(_lib.lib.lmufft_conv_scan_workspace_bytes(ctypes.byref(shp)), dev)
+
+        def run():
+            st = _stream(dev)
+            _lib.check(_lib.lib.lmufft_conv_forward_scan_bf16(ctypes.byref(shp), _ptr(u), _ptr(scanprep), _ptr(m),
+                                                             _ptr(ws), ws.numel(), st), "lmufft_conv_forward_scan_bf16")
+            _lib.check(_lib.lib.lmufft_conv_backward_scan_bf16(ctypes.byref(shp), _ptr(m), _ptr(scanprep), _ptr(gu),
+                                                              _ptr(ws), ws.numel(), st), "lmufft_conv_backward_scan_bf16")
+            return m, gu
+
+        return run
     if dtype == "bf16":
         hprep = prepare_impulse_bf16(H)
         m = torch.empty((B, T, M), dtype=torch.bfloat16, device=dev)

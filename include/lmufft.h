@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMUFFT_ABI_VERSION 15
+#define LMUFFT_ABI_VERSION 16
 
 /* element types of the activations (x, h, gh, gx, m) */
 #define LMUFFT_F32 0
@@ -40,6 +40,7 @@ extern "C" {
 #define LMUFFT_CONV_AUTO 0
 #define LMUFFT_CONV_TOEPLITZ 1 /* blocked Toeplitz contraction on MFMA */
 #define LMUFFT_CONV_FFT 2      /* LDS-resident radix FFT */
+#define LMUFFT_CONV_SCAN 3     /* bf16 only: state-space chunks, two dense GEMMs (long sequences) */
 
 int lmufft_abi_version(void);
 
@@ -167,10 +168,13 @@ int lmufft_wprep_bf16(const lmufft_shape* s, const float* W_h, void* wprep, void
 /* W_h: NULL, or the fp32 weights [Hd][M+D] -- the call then rebuilds `wprep` from them itself,
  * in the same launch as the encoder kernel (one launch fewer per step than a separate
  * lmufft_wprep_bf16 call; `wprep` is written in that case). */
+/* scanprep: NULL, or the operands of the state-space convolution route (below).  conv_algo AUTO takes
+ * that route whenever scanprep is given and the Toeplitz kernels otherwise; SCAN requires it.  The
+ * workspace (lmufft_forward_workspace_bytes / lmufft_backward_workspace_bytes) is only read on that route. */
 int lmufft_forward_bf16(const lmufft_shape* s, const void* x, const float* w_u,
                         const float* b_u, void* wprep, const float* W_h, const float* b_h,
-                        const void* hprep, float* u, void* m, void* h, void* h_n,
-                        int conv_algo, void* workspace, size_t workspace_bytes,
+                        const void* hprep, const void* scanprep, float* u, void* m, void* h,
+                        void* h_n, int conv_algo, void* workspace, size_t workspace_bytes,
                         void* stream);
 
 /* The bf16 forward followed by the layer norm the encoder applies to the layer's output
@@ -181,8 +185,8 @@ int lmufft_forward_bf16(const lmufft_shape* s, const void* x, const float* w_u,
  * multiples of 8; otherwise it fails and the caller runs lmufft_add_layernorm after the layer. */
 int lmufft_forward_ln_bf16(const lmufft_shape* s, const void* x, const float* w_u,
                            const float* b_u, void* wprep, const float* W_h, const float* b_h,
-                           const void* hprep, float* u, void* m, void* h, void* h_n,
-                           const float* gamma, const float* beta, float eps, void* y,
+                           const void* hprep, const void* scanprep, float* u, void* m, void* h,
+                           void* h_n, const float* gamma, const float* beta, float eps, void* y,
                            int y_dtype, int conv_algo, void* workspace,
                            size_t workspace_bytes, void* stream);
 
@@ -195,8 +199,33 @@ int lmufft_conv_forward_bf16(const lmufft_shape* s, const float* u, const void* 
 int lmufft_conv_backward_bf16(const lmufft_shape* s, const void* gm, const void* hprep, float* gu,
                               void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------
+ * State-space ("scan") route of the bf16 causal convolution, for long sequences.  Same result as
+ * src/lmu.py:303-312 -- the reference's H is the impulse response H[:,t] = A^t B of
+ * x_t = A x_{t-1} + B u_t (src/lmu.py:275-283) -- evaluated in chunks of lmufft_scan_chunk() frames:
+ * a chunk needs from all earlier frames only the state at its start, so the convolution becomes one
+ * dense GEMM of [chunk state | chunk samples] rows against a constant matrix (powers of A, the
+ * chunk's own Toeplitz block) and a short recurrence over chunks; the adjoint is the transposed
+ * GEMM and the reverse recurrence.  Work per frame is M (M + chunk) multiply-adds instead of M T / 2.
+ * `scanprep` holds those constants.  They depend on the module's buffers A [M][M] and B [M]
+ * (src/lmu.py:240-241) only: allocate lmufft_scanprep_bytes(M) bytes of HOST memory (0 = this
+ * memory size is not supported: multiples of 8 up to 256), fill them with
+ * lmufft_scanprep_build_host (host pointers, double-precision powers; about a second for M = 192),
+ * copy the block to 16-byte aligned device memory once and pass that pointer as `scanprep`.
+ * The conv-only entry points mirror lmufft_conv_forward_bf16 / lmufft_conv_backward_bf16; both take
+ * a workspace of lmufft_conv_scan_workspace_bytes(s) (B, T, M are read).
+ * ---------------------------------------------------------------------- */
+int32_t lmufft_scan_chunk(void);
+size_t lmufft_scanprep_bytes(int32_t M);
+int lmufft_scanprep_build_host(const float* A_host, const float* B_host, int32_t M, void* scanprep_host);
+size_t lmufft_conv_scan_workspace_bytes(const lmufft_shape* s);
+int lmufft_conv_forward_scan_bf16(const lmufft_shape* s, const float* u, const void* scanprep, void* m,
+                                  void* workspace, size_t workspace_bytes, void* stream);
+int lmufft_conv_backward_scan_bf16(const lmufft_shape* s, const void* gm, const void* scanprep, float* gu,
+                                   void* workspace, size_t workspace_bytes, void* stream);
+
 int lmufft_backward_bf16(const lmufft_shape* s, const void* x, const float* w_u,
-                         const void* wprep, const void* hprep, const float* u,
+                         const void* wprep, const void* hprep, const void* scanprep, const float* u,
                          const void* m, const void* h, const void* gh,
                          const void* gh_n, void* gx, float* gw_u, float* gb_u,
                          float* gW_h, float* gb_h, void* gm, int conv_algo,

@@ -4,8 +4,8 @@ input = hidden = 384, memory 192 (the reference's layer, src/lmu.py:297-320, at 
 One batch item of the full-shape run is checked against the fp64 oracle (its FFT form, which the CPU
 tests tie to the direct causal sums; the O(T^2 M) direct sum takes minutes at this length), the
 parameter gradients -- sums over the whole batch -- on a two-utterance batch of the same length.
-fp32 takes `conv_algo="auto"` (the partitioned FFT route at this length), bf16 the Toeplitz-MFMA
-kernels."""
+fp32 takes `conv_algo="auto"` (the partitioned FFT route at this length), bf16 both of its routes:
+the state-space chunks that "auto" selects from 1024 frames on, and the Toeplitz-MFMA kernels."""
 import numpy as np
 import pytest
 import torch
@@ -17,11 +17,11 @@ pytestmark = pytest.mark.gpu
 B, T, D, M, HD, THETA = 32, 3000, 384, 192, 384, 1000.0
 
 
-def _layer(dev):
+def _layer(dev, conv_algo="auto"):
     from asr_amd import LMUFFT
 
     torch.manual_seed(4)
-    layer = LMUFFT(D, HD, M, T, THETA)
+    layer = LMUFFT(D, HD, M, T, THETA, conv_algo=conv_algo)
     torch.nn.init.xavier_uniform_(layer.W_u.weight)
     torch.nn.init.xavier_uniform_(layer.W_h.weight)
     torch.nn.init.zeros_(layer.W_u.bias)
@@ -85,8 +85,10 @@ def test_c4_fp32_full_shape():
     _close32(_np(layer.W_u.bias.grad), ref2["gb_u"], "gb_u", cancel=np.abs(ref2["ga"]).sum())
 
 
-def test_c4_bf16_full_shape():
-    """bf16 at T = 3000.  Against the oracle on the bf16-rounded operands and the kernel's own ReLU
+@pytest.mark.parametrize("conv_algo", ["auto", "toeplitz"])
+def test_c4_bf16_full_shape(conv_algo):
+    """bf16 at T = 3000, on the route conv_algo="auto" takes at this length (the state-space chunks) and
+    on the Toeplitz-MFMA kernels.  Against the oracle on the bf16-rounded operands and the kernel's own ReLU
     pattern every output is inside the bf16 bar.  (A comparison with the oracle on the UN-rounded
     operands reads very differently -- max error 0.20 of max|gx| and 0.07 of max|gW_h| at this shape:
     rounding x to bf16 moves the encoder's pre-activation x.w_u, a cancelling sum of 384 terms, by
@@ -97,7 +99,7 @@ def test_c4_bf16_full_shape():
     from tests.test_gpu_bf16 import _close, _termnorms
 
     dev = torch.device("cuda:0")
-    layer = _layer(dev)
+    layer = _layer(dev, conv_algo)
     g = torch.Generator(device=dev).manual_seed(1234 + 4)
     x = torch.randn(B, T, D, device=dev, generator=g).bfloat16().requires_grad_(True)
     gh = torch.randn(B, T, HD, device=dev, generator=g).bfloat16()
