@@ -34,6 +34,7 @@
 namespace lmufft {
 
 constexpr int kScanL = 128;  // frames per chunk
+constexpr int kScanUB = 32;  // chunks whose samples the state kernel stages in LDS at a time
 using ScanTile = TileB<128, 384, 64, 2, 4>;
 
 struct ScanLayout {
@@ -66,23 +67,43 @@ static ScanLayout scan_layout(int M) {
 bool scan_supported(int M) { return M >= 8 && M % 8 == 0 && M <= 256; }
 static inline int scan_chunks(int T) { return (T + kScanL - 1) / kScanL; }
 
+// Barrier between the steps of a recurrence: only LDS traffic has to be complete (a __syncthreads()
+// would also wait for every global store and load the wave has in flight, a memory round trip per step).
+__device__ __forceinline__ void scan_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
 // ---------------------------------------------------------------------------------------------
 // Chunk states of one utterance (one workgroup, four lanes per state component).
 //   Z_c = sum_i Hs[i] u[cL+i] for the full chunks, X'_0 = 0, X'_{c+1} = A^L X'_c + Z_c;
 //   row (b,c) of the GEMM operand = [ bf16(X'_c) | bf16(u[cL .. cL+L-1]) | 0 ].
+// LDS: S [nc][MP] holds Z_c in row c + 1 until the recurrence replaces it by X'_{c+1} (a step reads
+// row c whole and rewrites its own element of row c + 1), and the samples of kScanUB chunks at a time.
 // ---------------------------------------------------------------------------------------------
 template <int MP>
 __global__ __launch_bounds__(4 * MP) void k_scan_state_fwd(const float* __restrict__ u, const float* __restrict__ Hs,
-                                                           const float* __restrict__ AL, bf16_t* __restrict__ Arows,
+                                                           const float* __restrict__ ALT, bf16_t* __restrict__ Arows,
                                                            int T, int M, int Kp, int nc) {
-  constexpr int L = kScanL, Q = 4, PER = MP / Q, THREADS = 4 * MP;
+  constexpr int L = kScanL, Q = 4, PER = MP / Q, THREADS = 4 * MP, IQ = L / Q;
   extern __shared__ __attribute__((aligned(16))) float scan_sm[];
-  float* Zs = scan_sm;                    // [nc][MP]
-  float* Xs = scan_sm + (size_t)nc * MP;  // [2][MP]
+  float* S = scan_sm;                        // [nc][MP]
+  float* ublk = scan_sm + (size_t)nc * MP;   // [kScanUB][L]
   const int b = blockIdx.x, tid = threadIdx.x, k = tid >> 2, q = tid & 3;
   const float* ub = u + (long)b * T;
   bf16_t* Ab = Arows + (long)b * nc * Kp;
   const bool live = k < M;
+  // everything the loops below need from global memory is requested up front
+  float hreg[IQ];
+#pragma unroll
+  for (int ii = 0; ii < IQ; ++ii) hreg[ii] = live ? Hs[(q * IQ + ii) * M + k] : 0.f;
+  // row k of A^L, read from the transposed copy so that neighbouring lanes read neighbouring words
+  float a[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int kk = q * PER + j;
+    a[j] = (live && kk < M) ? ALT[(long)kk * M + k] : 0.f;
+  }
   {  // the chunk's own samples and the padding
     const int wcols = Kp - M;
     for (int idx = tid; idx < nc * wcols; idx += THREADS) {
@@ -91,41 +112,33 @@ __global__ __launch_bounds__(4 * MP) void k_scan_state_fwd(const float* __restri
       Ab[(long)c * Kp + M + i] = (bf16_t)((i < L && t < T) ? ub[t] : 0.f);
     }
   }
-  for (int c0 = 0; c0 < nc - 1; c0 += 8) {
-    float acc[8];
-#pragma unroll
-    for (int cc = 0; cc < 8; ++cc) acc[cc] = 0.f;
-    for (int ii = 0; ii < L / Q; ++ii) {
-      const int i = q * (L / Q) + ii;
-      const float h = live ? Hs[i * M + k] : 0.f;
-#pragma unroll
-      for (int cc = 0; cc < 8; ++cc) {
-        const float uv = (c0 + cc < nc - 1) ? ub[(c0 + cc) * L + i] : 0.f;
-        acc[cc] += h * uv;
-      }
+  for (int i = tid; i < MP; i += THREADS) S[i] = 0.f;  // X'_0
+  for (int c0 = 0; c0 < nc - 1; c0 += kScanUB) {
+    __syncthreads();  // the previous block of samples has been consumed
+    for (int idx = tid; idx < kScanUB * L; idx += THREADS) {
+      const int t = c0 * L + idx;
+      ublk[idx] = t < T ? ub[t] : 0.f;
     }
+    __syncthreads();
+    const int ccn = min(kScanUB, nc - 1 - c0);  // full chunks in this block
+    for (int cc = 0; cc < ccn; ++cc) {
+      const f32x4* uv = reinterpret_cast<const f32x4*>(ublk + cc * L + q * IQ);
+      float v0 = 0.f, v1 = 0.f;
 #pragma unroll
-    for (int cc = 0; cc < 8; ++cc) {
-      float v = acc[cc];
+      for (int i4 = 0; i4 < IQ / 4; i4 += 2) {
+        const f32x4 va = uv[i4], vb = uv[i4 + 1];
+        v0 += hreg[4 * i4] * va[0] + hreg[4 * i4 + 1] * va[1] + hreg[4 * i4 + 2] * va[2] + hreg[4 * i4 + 3] * va[3];
+        v1 += hreg[4 * i4 + 4] * vb[0] + hreg[4 * i4 + 5] * vb[1] + hreg[4 * i4 + 6] * vb[2] + hreg[4 * i4 + 7] * vb[3];
+      }
+      float v = v0 + v1;
       v += __shfl_xor(v, 1);
       v += __shfl_xor(v, 2);
-      if (q == 0 && c0 + cc < nc - 1) Zs[(c0 + cc) * MP + k] = v;
+      if (q == 0) S[(c0 + cc + 1) * MP + k] = v;  // Z_c waits in row c + 1
     }
   }
-  float a[PER];
-#pragma unroll
-  for (int j = 0; j < PER; ++j) {
-    const int kk = q * PER + j;
-    a[j] = (live && kk < M) ? AL[(long)k * M + kk] : 0.f;
-  }
-  for (int i = tid; i < 2 * MP; i += THREADS) Xs[i] = 0.f;
   __syncthreads();
-  float xk = 0.f;
-  int cur = 0;
-  for (int c = 0; c < nc; ++c) {
-    if (q == 0 && live) Ab[(long)c * Kp + k] = (bf16_t)xk;
-    if (c == nc - 1) break;
-    const f32x4* xv = reinterpret_cast<const f32x4*>(Xs + cur * MP + q * PER);
+  for (int c = 0; c + 1 < nc; ++c) {
+    const f32x4* xv = reinterpret_cast<const f32x4*>(S + c * MP + q * PER);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
     for (int j4 = 0; j4 < PER / 4; ++j4) {
@@ -138,10 +151,12 @@ __global__ __launch_bounds__(4 * MP) void k_scan_state_fwd(const float* __restri
     float s = (s0 + s1) + (s2 + s3);
     s += __shfl_xor(s, 1);
     s += __shfl_xor(s, 2);
-    xk = Zs[c * MP + k] + s;
-    if (q == 0) Xs[(cur ^ 1) * MP + k] = xk;
-    __syncthreads();
-    cur ^= 1;
+    if (q == 0) S[(c + 1) * MP + k] += s;
+    scan_lds_barrier();
+  }
+  for (int idx = tid; idx < nc * MP; idx += THREADS) {
+    const int c = idx / MP, kk = idx % MP;
+    if (kk < M) Ab[(long)c * Kp + kk] = (bf16_t)S[idx];
   }
 }
 
@@ -149,16 +164,16 @@ __global__ __launch_bounds__(4 * MP) void k_scan_state_fwd(const float* __restri
 // Costates of one utterance and the finished adjoint.  R [(b,c)][Kp] = [G_c | gu_intra | pad].
 //   Lambda_nc = 0, Lambda_c = G_c + (A^L)^T Lambda_{c+1};
 //   gu[cL+i] = gu_intra[c][i] + sum_k HsT[k][i] Lambda_{c+1}[k]   (times u > 0 when u != NULL).
+// LDS: Ls [ncp][MP], row c = Lambda_{c+1}; row c - 1 holds G_c until the recurrence adds to it.
 // ---------------------------------------------------------------------------------------------
 template <int MP>
 __global__ __launch_bounds__(4 * MP) void k_scan_state_bwd(const float* __restrict__ R, const float* __restrict__ HsT,
-                                                           const float* __restrict__ ALT, const float* __restrict__ u,
+                                                           const float* __restrict__ AL, const float* __restrict__ u,
                                                            float* __restrict__ gu, int T, int M, int Kp, int nc) {
   constexpr int L = kScanL, Q = 4, PER = MP / Q, THREADS = 4 * MP;
   extern __shared__ __attribute__((aligned(16))) float scan_sm[];
   const int ncp = (nc + 7) & ~7;
-  float* Ls = scan_sm;                     // [ncp][MP]: Ls[c] = Lambda_{c+1}
-  float* Xs = scan_sm + (size_t)ncp * MP;  // [2][MP]
+  float* Ls = scan_sm;  // [ncp][MP]
   const int b = blockIdx.x, tid = threadIdx.x, k = tid >> 2, q = tid & 3;
   const bool live = k < M;
   const float* Rb = R + (long)b * nc * Kp;
@@ -166,20 +181,15 @@ __global__ __launch_bounds__(4 * MP) void k_scan_state_bwd(const float* __restri
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
     const int kk = q * PER + j;
-    a[j] = (live && kk < M) ? ALT[(long)k * M + kk] : 0.f;
+    a[j] = (live && kk < M) ? AL[(long)kk * M + k] : 0.f;  // (A^L)^T [k][kk], neighbouring lanes neighbouring words
   }
-  for (int i = tid; i < 2 * MP; i += THREADS) Xs[i] = 0.f;
-  for (int i = nc * MP + tid; i < ncp * MP; i += THREADS) Ls[i] = 0.f;
+  for (int idx = tid; idx < ncp * MP; idx += THREADS) {
+    const int c = idx / MP + 1, kk = idx % MP;  // row c - 1 <- G_c; the rows from nc - 1 on are zero
+    Ls[idx] = (c < nc && kk < M) ? Rb[(long)c * Kp + kk] : 0.f;
+  }
   __syncthreads();
-  float lam = 0.f;
-  int cur = 0;
-  float g_next = (live && nc > 1) ? Rb[(long)(nc - 1) * Kp + k] : 0.f;
-  for (int c = nc - 1; c >= 0; --c) {
-    if (q == 0) Ls[c * MP + k] = lam;
-    if (c == 0) break;
-    const float g = g_next;
-    if (c > 1) g_next = live ? Rb[(long)(c - 1) * Kp + k] : 0.f;  // in flight during this step
-    const f32x4* xv = reinterpret_cast<const f32x4*>(Xs + cur * MP + q * PER);
+  for (int c = nc - 1; c >= 1; --c) {
+    const f32x4* xv = reinterpret_cast<const f32x4*>(Ls + c * MP + q * PER);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
     for (int j4 = 0; j4 < PER / 4; ++j4) {
@@ -192,32 +202,40 @@ __global__ __launch_bounds__(4 * MP) void k_scan_state_bwd(const float* __restri
     float s = (s0 + s1) + (s2 + s3);
     s += __shfl_xor(s, 1);
     s += __shfl_xor(s, 2);
-    lam = g + s;
-    if (q == 0) Xs[(cur ^ 1) * MP + k] = lam;
-    __syncthreads();
-    cur ^= 1;
+    if (q == 0) Ls[(c - 1) * MP + k] += s;
+    scan_lds_barrier();
   }
-  __syncthreads();
   // gu: lane group (i, q) sums its quarter of the state components for eight chunks at a time
   for (int i = tid >> 2; i < L; i += MP) {  // whole groups of four lanes stay together
+    float h[PER];
+#pragma unroll
+    for (int jj = 0; jj < PER; ++jj) {
+      const int kk = q * PER + jj;
+      h[jj] = kk < M ? HsT[(long)kk * L + i] : 0.f;
+    }
     for (int c0 = 0; c0 < nc; c0 += 8) {
-      float acc[8];
-#pragma unroll
-      for (int cc = 0; cc < 8; ++cc) acc[cc] = 0.f;
-      for (int jj = 0; jj < PER; ++jj) {
-        const int kk = q * PER + jj;
-        const float h = kk < M ? HsT[(long)kk * L + i] : 0.f;
-#pragma unroll
-        for (int cc = 0; cc < 8; ++cc) acc[cc] += h * Ls[(c0 + cc) * MP + kk];
-      }
+      float gi[8];
 #pragma unroll
       for (int cc = 0; cc < 8; ++cc) {
-        float v = acc[cc];
+        const int c = c0 + cc;
+        gi[cc] = (q == 0 && c < nc && c * L + i < T) ? Rb[(long)c * Kp + M + i] : 0.f;
+      }
+#pragma unroll 2
+      for (int cc = 0; cc < 8; ++cc) {
+        const f32x4* lv = reinterpret_cast<const f32x4*>(Ls + (c0 + cc) * MP + q * PER);
+        float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+        for (int j4 = 0; j4 < PER / 4; j4 += 2) {
+          const f32x4 va = lv[j4], vb = lv[j4 + 1];
+          v0 += h[4 * j4] * va[0] + h[4 * j4 + 1] * va[1] + h[4 * j4 + 2] * va[2] + h[4 * j4 + 3] * va[3];
+          v1 += h[4 * j4 + 4] * vb[0] + h[4 * j4 + 5] * vb[1] + h[4 * j4 + 6] * vb[2] + h[4 * j4 + 7] * vb[3];
+        }
+        float v = v0 + v1;
         v += __shfl_xor(v, 1);
         v += __shfl_xor(v, 2);
         const int c = c0 + cc, t = c * L + i;
         if (q == 0 && c < nc && t < T) {
-          float gval = Rb[(long)c * Kp + M + i] + v;
+          float gval = gi[cc] + v;
           if (u && !(u[(long)b * T + t] > 0.f)) gval = 0.f;
           gu[(long)b * T + t] = gval;
         }
@@ -443,14 +461,14 @@ int scan_conv_forward(const lmufft_shape& s, const float* u, const void* scanpre
   {
     const int rc = scan_dispatch_mp(s.M, [&](auto mp_c) -> int {
       constexpr int MP = decltype(mp_c)::value;
-      const size_t lds = sizeof(float) * (size_t)(p.nc + 2) * MP;
+      const size_t lds = sizeof(float) * ((size_t)p.nc * MP + kScanUB * kScanL);
       if (lds > 160 * 1024) return set_error("scan convolution: sequence too long (T=%d)", s.T);
       if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)k_scan_state_fwd<MP>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return set_error("cannot reserve %zu bytes of LDS for k_scan_state_fwd", lds);
       PROFS("k_scan_state_fwd");
       hipLaunchKernelGGL(k_scan_state_fwd<MP>, dim3(s.B), dim3(4 * MP), lds, st, u, (const float*)(sp + l.off_Hs),
-                         (const float*)(sp + l.off_AL), Arows, s.T, s.M, l.Kp, p.nc);
+                         (const float*)(sp + l.off_ALT), Arows, s.T, s.M, l.Kp, p.nc);
       return 0;
     });
     if (rc) return rc;
@@ -507,14 +525,14 @@ int scan_conv_backward(const lmufft_shape& s, const bf16_t* gm, const void* scan
   {
     const int rc = scan_dispatch_mp(s.M, [&](auto mp_c) -> int {
       constexpr int MP = decltype(mp_c)::value;
-      const size_t lds = sizeof(float) * (size_t)(((p.nc + 7) & ~7) + 2) * MP;
+      const size_t lds = sizeof(float) * (size_t)((p.nc + 7) & ~7) * MP;
       if (lds > 160 * 1024) return set_error("scan convolution: sequence too long (T=%d)", s.T);
       if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)k_scan_state_bwd<MP>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return set_error("cannot reserve %zu bytes of LDS for k_scan_state_bwd", lds);
       PROFS("k_scan_state_bwd");
       hipLaunchKernelGGL(k_scan_state_bwd<MP>, dim3(s.B), dim3(4 * MP), lds, st, Rsum,
-                         (const float*)(sp + l.off_HsT), (const float*)(sp + l.off_ALT), u, gu, s.T, s.M, l.Kp, p.nc);
+                         (const float*)(sp + l.off_HsT), (const float*)(sp + l.off_AL), u, gu, s.T, s.M, l.Kp, p.nc);
       return 0;
     });
     if (rc) return rc;

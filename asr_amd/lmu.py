@@ -69,8 +69,9 @@ def _AUTO_PREFERS_FFT(T, M):
 
 # bf16 path: sequence length from which conv_algo="auto" takes the state-space ("scan") route.  Its work per
 # frame is constant (M * (M + 128) multiply-adds) where the Toeplitz kernels' grows with T / 2; measured on
-# MI355X at batch 32, 192 memory channels, forward + adjoint: T=512 Toeplitz first, T>=1024 scan first.
-_SCAN_MIN_T = 1024
+# MI355X at batch 32, 192 memory channels, forward + adjoint, Toeplitz / scan: T=1024 51 / 78 us,
+# T=1536 77 / 88, T=2048 112 / 94, T=3000 214 / 121 (batch 8, T=3000: 125 / 101).
+_SCAN_MIN_T = 1792
 
 # (device, memory size, bytes of A and B) -> constants of the scan route; layers with the same (A, B) share them
 _SCANPREP_CACHE = {}

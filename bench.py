@@ -50,7 +50,7 @@ def parse_args():
     ap.add_argument("--hidden", type=int, default=384)
     ap.add_argument("--memory", type=int, default=192)
     ap.add_argument("--theta", type=float, default=1000.0)
-    ap.add_argument("--conv", default="auto", choices=["auto", "toeplitz", "fft"])
+    ap.add_argument("--conv", default="auto", choices=["auto", "toeplitz", "fft", "scan"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"],
                     help="activation / MFMA operand type (fp32 accumulation either way)")
     ap.add_argument("--unit", default="layer", choices=["layer", "conv"])
@@ -224,9 +224,13 @@ def bench_conv(args, dev):
     u = torch.relu(torch.randn(B, T, device=dev, generator=g))
     esize = 2 if args.dtype == "bf16" else 4
     routes = ["toeplitz"] if args.dtype == "bf16" else (["toeplitz", "fft"] if F.fft_supported(T, M) else ["toeplitz"])
+    scanprep = None
+    if args.dtype == "bf16" and F.scan_supported(M):
+        routes.append("scan")
+        scanprep = F.prepare_scan_bf16(A, Bm, device=dev)
     out = {}
     for route in routes:
-        run = F.conv_pair_runner(u, H, route, args.dtype)  # preallocated outputs and workspaces
+        run = F.conv_pair_runner(u, H, route, args.dtype, scanprep=scanprep)  # preallocated outputs and workspaces
         for _ in range(args.warmup):
             run()
         torch.cuda.synchronize(dev)

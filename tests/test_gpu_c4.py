@@ -5,7 +5,7 @@ One batch item of the full-shape run is checked against the fp64 oracle (its FFT
 tests tie to the direct causal sums; the O(T^2 M) direct sum takes minutes at this length), the
 parameter gradients -- sums over the whole batch -- on a two-utterance batch of the same length.
 fp32 takes `conv_algo="auto"` (the partitioned FFT route at this length), bf16 both of its routes:
-the state-space chunks that "auto" selects from 1024 frames on, and the Toeplitz-MFMA kernels."""
+the state-space chunks that "auto" selects for long sequences, and the Toeplitz-MFMA kernels."""
 import numpy as np
 import pytest
 import torch

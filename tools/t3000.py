@@ -23,7 +23,7 @@ layer.zero_grad()
 hb, _ = layer(xb); (hb * gh.bfloat16()).sum().backward()
 print("bf16 h", rel(hb.detach().float().cpu().numpy(), ref["h"]), "gx", rel(xb.grad.float().cpu().numpy(), ref["gx"]),
       "gW_h", rel(layer.W_h.weight.grad.cpu().numpy(), ref["gW_h"]), flush=True)
-for dt, algo in ((torch.bfloat16, "auto"), (torch.float32, "toeplitz"), (torch.float32, "fft")):
+for dt, algo in ((torch.bfloat16, "scan"), (torch.bfloat16, "toeplitz"), (torch.float32, "toeplitz"), (torch.float32, "fft")):
     layer.conv_algo = algo
     xx = torch.randn(32, T, D, device=dev).to(dt).requires_grad_(True)
     gg = torch.randn(32, T, Hd, device=dev).to(dt)
