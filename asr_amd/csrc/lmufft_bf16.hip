@@ -977,6 +977,30 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
       gbu += ga_reg[set];
     }
   };
+  // the part of a tile's LDS stores that is issued during k-step ks: the stores of a whole tile in one go
+  // (40 KB through the LDS store path) stood in front of the round's first fragment reads
+  auto store_part = [&](auto set_c, int st, int ks) __attribute__((always_inline)) {
+    constexpr int set = decltype(set_c)::value;
+    constexpr int KSN = TL::BK / 16;
+    bf16_t* sa = stage_A(st);
+    bf16_t* sb = stage_B(st);
+#pragma unroll
+    for (int i = 0; i < OpA::NV; ++i)
+      if (i % KSN == ks) {
+        const int idx = tid + i * kThreads;
+        *reinterpret_cast<bf16x8*>(&sa[(idx / (TL::BM / 8)) * OpA::LD + (idx % (TL::BM / 8)) * 8]) = ra[set][i];
+      }
+#pragma unroll
+    for (int i = 0; i < OpB::NV; ++i)
+      if (i % KSN == ks) {
+        const int idx = tid + i * kThreads;
+        *reinterpret_cast<bf16x8*>(&sb[(idx / (TL::BN / 8)) * OpB::LD + (idx % (TL::BN / 8)) * 8]) = rb[set][i];
+      }
+    if (ks == KSN - 1 && tid < TL::BK) {
+      stage_ga(st)[tid] = ga_reg[set];
+      gbu += ga_reg[set];
+    }
+  };
   auto read_frags = [&](bf16x8 (&af)[TL::TM], bf16x8 (&bfr)[TL::TN], int kl) {
 #pragma unroll
     for (int tm = 0; tm < TL::TM; ++tm) af[tm] = oa.frag32(w.wm0 + tm * 32, kl);
@@ -987,13 +1011,11 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
   // `set_c` and that set is refilled with the tile at k0 + 3 BK
   auto round = [&](auto set_c, int k0, int st) __attribute__((always_inline)) {
     [[maybe_unused]] const long long c0 = LMUFFT_CLOCK();
-    store(set_c, st ^ 1);  // that stage was last read before the previous barrier
     oa.S = stage_A(st);
     ob.S = stage_B(st);
     const float* gaS = stage_ga(st);
     bf16x8 fa[2][TL::TM], fb[2][TL::TN];
     read_frags(fa[0], fb[0], 0);
-    fetch(set_c, k0 + 3 * TL::BK);
     [[maybe_unused]] const long long c1 = LMUFFT_CLOCK();
 #pragma unroll
     for (int ks = 0; ks < TL::BK / 16; ++ks) {
@@ -1001,6 +1023,7 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
       bf16x8(&af)[TL::TM] = fa[ks & 1];
       bf16x8(&bfr)[TL::TN] = fb[ks & 1];
       if (ks + 1 < TL::BK / 16) read_frags(fa[(ks + 1) & 1], fb[(ks + 1) & 1], kl + 16);
+      store_part(set_c, st ^ 1, ks);  // that stage was last read before the previous barrier
 #pragma unroll
       for (int tm = 0; tm < TL::TM; ++tm)
 #pragma unroll
@@ -1035,6 +1058,7 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
       }
       --cnt_u;
     }
+    fetch(set_c, k0 + 3 * TL::BK);  // the set's registers are free once its tile has gone to LDS
     [[maybe_unused]] const long long c2 = LMUFFT_CLOCK();
     __syncthreads();
     [[maybe_unused]] const long long c3 = LMUFFT_CLOCK();

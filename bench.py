@@ -103,6 +103,9 @@ def kernel_work(name, B, T, D, M, Hd, s=4):
         "k_relu_bwd": (2.0 * rows * Hd, rows * 3 * Hd * s),
         "k_conv_fwd": (1.0 * B * T * (T + 1) * M, rows * M * s + rows * 4 + M * T * s),
         "k_conv_bwd": (1.0 * B * T * (T + 1) * M, rows * M * s + rows * 4 + M * T * s),
+        # state-space route (bf16): two dense GEMMs of K = M + 128 against a constant matrix of (M + 128) x 128 M
+        "k_scan_gemm_fwd": (2.0 * rows * M * (M + 128), rows * M * 2 + 128 * M * (M + 128) * 2),
+        "k_scan_gemm_adj": (2.0 * rows * M * (M + 128), rows * M * 2 + 128 * M * (M + 128) * 2),
         "k_encode_fwd": (2.0 * rows * D, rows * D * s + rows * 4),
         "k_encode_bwd": (2.0 * rows * D, rows * D * s + rows * 4),
     }

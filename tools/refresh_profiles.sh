@@ -21,6 +21,15 @@ for shape in "64 400" "16 400" "32 3000"; do
     timeout -k 10 240 python3 bench.py --unit conv --dtype $dt --batch $1 --frames $2 >> $O/bench_conv.jsonl 2>> $O/bench_conv.err
   done
 done
+# the long-utterance configuration (batch 32, 3000 frames, one layer) on both bf16 convolution routes, graph replay
+for c in scan toeplitz; do
+  timeout -k 10 240 python3 bench.py --batch 32 --frames 3000 --layers 1 --conv $c --steps 100 --no-cpu-baseline > $O/bench_c4_bf16_$c.json 2>> $O/bench_c4.err
+done
+timeout -k 10 240 python3 bench.py --batch 32 --frames 3000 --layers 1 --dtype f32 --steps 50 --no-cpu-baseline > $O/bench_c4_f32_auto.json 2>> $O/bench_c4.err
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c4_scan -o c4 -- python3 bench.py --batch 32 --frames 3000 --layers 1 --conv scan --steps 30 --no-cpu-baseline > $O/stats_c4_scan.log 2>&1
+for T in 1024 1536 2048; do
+  timeout -k 10 240 python3 bench.py --unit conv --dtype bf16 --batch 32 --frames $T >> $O/bench_conv_sweep.jsonl 2>> $O/bench_conv.err
+done
 timeout -k 10 240 python3 tools/mel_bench.py > $O/mel_bench.txt 2>&1
 timeout -k 10 240 python3 tools/infer_bench.py > $O/infer_bench.json 2> $O/infer_bench.err
 timeout -k 10 240 python3 tools/t3000.py > $O/t3000.txt 2>&1
