@@ -18,8 +18,10 @@
 // The recurrences over chunks (T/L steps of an M x M matrix-vector product in fp32) run one
 // workgroup per utterance with the matrix row in registers.
 //
-// Kernels: k_scan_state_fwd (chunk states -> GEMM rows), k_scan_gemm_fwd (writes m),
-//          k_scan_gemm_adj (split over (j,k) into fp32 slabs), k_scan_state_bwd (costates -> gu).
+// Kernels: k_scan_rows_fwd (per chunk: input of the recurrence, sample part of the GEMM rows),
+//          k_scan_state_fwd (chunk states -> state part of the GEMM rows), k_scan_gemm_fwd (writes m);
+//          k_scan_gemm_adj (split over (j,k) into fp32 slabs), k_scan_state_bwd (costates),
+//          k_scan_rows_bwd (per chunk: gu).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -34,7 +36,6 @@
 namespace lmufft {
 
 constexpr int kScanL = 128;  // frames per chunk
-constexpr int kScanUB = 32;  // chunks whose samples the state kernel stages in LDS at a time
 using ScanTile = TileB<128, 384, 64, 2, 4>;
 
 struct ScanLayout {
@@ -67,6 +68,83 @@ static ScanLayout scan_layout(int M) {
 bool scan_supported(int M) { return M >= 8 && M % 8 == 0 && M <= 256; }
 static inline int scan_chunks(int T) { return (T + kScanL - 1) / kScanL; }
 
+// ---------------------------------------------------------------------------------------------
+// The parts of the state computation that are parallel over chunks run on the whole chip, one
+// workgroup per (utterance, kScanCB chunks), four lanes per state component / frame; the recurrences
+// themselves (k_scan_state_fwd / _bwd) run one workgroup per utterance.
+//
+// k_scan_rows_fwd: Z_c = sum_i Hs[i] u[cL+i] (fp32, row (b,c) of Zbuf; needed for full chunks only) and the
+//   sample part of the GEMM operand rows: Arows[(b,c)][M ..] = [ bf16(u[cL .. cL+L-1]) | 0 ].
+// ---------------------------------------------------------------------------------------------
+constexpr int kScanCB = 8;  // chunks per workgroup of the row kernels
+
+// dst[idx] = *src(idx) for idx < n, eight loads per thread in flight at a time (a plain loop waits for
+// every load before it issues the next).  src(idx) returns an address that is always readable.
+template <int THREADS, class Src>
+__device__ __forceinline__ void scan_fill_lds(float* dst, int n, Src&& src) {
+  for (int base = threadIdx.x; base < n; base += 8 * THREADS) {
+    float v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int idx = base + r * THREADS;
+      v[r] = *src(idx < n ? idx : -1);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int idx = base + r * THREADS;
+      if (idx < n) dst[idx] = v[r];
+    }
+  }
+}
+
+// Sum over the four lanes of a group by DPP quad permutes (no LDS round trip).
+__device__ __forceinline__ float scan_quad_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));  // 1 0 3 2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));  // 2 3 0 1
+  return v;
+}
+
+template <int MP>
+__global__ __launch_bounds__(4 * MP) void k_scan_rows_fwd(const float* __restrict__ u, const float* __restrict__ Hs,
+                                                          bf16_t* __restrict__ Arows, float* __restrict__ Zbuf,
+                                                          int T, int M, int Kp, int nc) {
+  constexpr int L = kScanL, Q = 4, THREADS = 4 * MP, IQ = L / Q;
+  __shared__ __attribute__((aligned(16))) float ublk[kScanCB * L];
+  const int b = blockIdx.x, c0 = blockIdx.y * kScanCB, tid = threadIdx.x, k = tid >> 2, q = tid & 3;
+  const float* ub = u + (long)b * T;
+  const bool live = k < M;
+  // masked elements are read from a line of zeros: a select on the ADDRESS keeps the loads unconditional
+  // and all in flight together (a select on the value becomes a branch and a wait per load)
+  const float* zero = reinterpret_cast<const float*>(kZeroBytes);
+  float hreg[IQ];
+#pragma unroll
+  for (int ii = 0; ii < IQ; ++ii) hreg[ii] = *(live ? Hs + (q * IQ + ii) * M + k : zero);
+  scan_fill_lds<THREADS>(ublk, kScanCB * L, [&](int idx) { return (idx >= 0 && c0 * L + idx < T) ? ub + c0 * L + idx : zero; });
+  __syncthreads();
+  const int ccn = min(kScanCB, nc - c0);
+  {  // the chunks' own samples and the padding of their rows
+    const int wcols = Kp - M;
+    bf16_t* Ab = Arows + ((long)b * nc + c0) * Kp + M;
+    for (int idx = tid; idx < ccn * wcols; idx += THREADS) {
+      const int cc = idx / wcols, i = idx % wcols;
+      Ab[(long)cc * Kp + i] = (bf16_t)(i < L ? ublk[cc * L + i] : 0.f);
+    }
+  }
+  float* Zb = Zbuf + ((long)b * nc + c0) * MP;
+  for (int cc = 0; cc < ccn; ++cc) {
+    const f32x4* uv = reinterpret_cast<const f32x4*>(ublk + cc * L + q * IQ);
+    float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+    for (int i4 = 0; i4 < IQ / 4; i4 += 2) {
+      const f32x4 va = uv[i4], vb = uv[i4 + 1];
+      v0 += hreg[4 * i4] * va[0] + hreg[4 * i4 + 1] * va[1] + hreg[4 * i4 + 2] * va[2] + hreg[4 * i4 + 3] * va[3];
+      v1 += hreg[4 * i4 + 4] * vb[0] + hreg[4 * i4 + 5] * vb[1] + hreg[4 * i4 + 6] * vb[2] + hreg[4 * i4 + 7] * vb[3];
+    }
+    const float v = scan_quad_sum(v0 + v1);
+    if (q == 0) Zb[(long)cc * MP + k] = v;
+  }
+}
+
 // Barrier between the steps of a recurrence: only LDS traffic has to be complete (a __syncthreads()
 // would also wait for every global store and load the wave has in flight, a memory round trip per step).
 __device__ __forceinline__ void scan_lds_barrier() {
@@ -74,84 +152,55 @@ __device__ __forceinline__ void scan_lds_barrier() {
   __builtin_amdgcn_s_barrier();
 }
 
+// One step of a recurrence: s = (row of the transition matrix held in a[]) . (vector in LDS), the
+// lane's quarter of it, summed over the four lanes of the group.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int PER>
+__device__ __forceinline__ float scan_row_dot(const float (&a)[PER], const float* __restrict__ x_lds) {
+  // two-wide accumulators: the products compile to packed fp32 FMAs (half the vector instructions;
+  // the step is bound by them -- M * M multiply-adds on one CU)
+  const f32x4* xv = reinterpret_cast<const f32x4*>(x_lds);
+  f32x2 s0 = {0.f, 0.f}, s1 = {0.f, 0.f};
+#pragma unroll
+  for (int j4 = 0; j4 < PER / 4; ++j4) {
+    const f32x4 v = xv[j4];
+    s0 += f32x2{a[4 * j4], a[4 * j4 + 1]} * f32x2{v[0], v[1]};
+    s1 += f32x2{a[4 * j4 + 2], a[4 * j4 + 3]} * f32x2{v[2], v[3]};
+  }
+  const f32x2 s = s0 + s1;
+  return scan_quad_sum(s[0] + s[1]);
+}
+
 // ---------------------------------------------------------------------------------------------
-// Chunk states of one utterance (one workgroup, four lanes per state component).
-//   Z_c = sum_i Hs[i] u[cL+i] for the full chunks, X'_0 = 0, X'_{c+1} = A^L X'_c + Z_c;
-//   row (b,c) of the GEMM operand = [ bf16(X'_c) | bf16(u[cL .. cL+L-1]) | 0 ].
+// Chunk states of one utterance: X'_0 = 0, X'_{c+1} = A^L X'_c + Z_c; writes the state part of the GEMM
+// operand rows, Arows[(b,c)][0 .. M) = bf16(X'_c).
 // LDS: S [nc][MP] holds Z_c in row c + 1 until the recurrence replaces it by X'_{c+1} (a step reads
-// row c whole and rewrites its own element of row c + 1), and the samples of kScanUB chunks at a time.
+// row c whole and adds into its own element of row c + 1).
 // ---------------------------------------------------------------------------------------------
 template <int MP>
-__global__ __launch_bounds__(4 * MP) void k_scan_state_fwd(const float* __restrict__ u, const float* __restrict__ Hs,
-                                                           const float* __restrict__ ALT, bf16_t* __restrict__ Arows,
-                                                           int T, int M, int Kp, int nc) {
-  constexpr int L = kScanL, Q = 4, PER = MP / Q, THREADS = 4 * MP, IQ = L / Q;
+__global__ __launch_bounds__(4 * MP) void k_scan_state_fwd(const float* __restrict__ Zbuf, const float* __restrict__ ALT,
+                                                           bf16_t* __restrict__ Arows, int M, int Kp, int nc) {
+  constexpr int Q = 4, PER = MP / Q, THREADS = 4 * MP;
   extern __shared__ __attribute__((aligned(16))) float scan_sm[];
-  float* S = scan_sm;                        // [nc][MP]
-  float* ublk = scan_sm + (size_t)nc * MP;   // [kScanUB][L]
+  float* S = scan_sm;  // [nc][MP]
   const int b = blockIdx.x, tid = threadIdx.x, k = tid >> 2, q = tid & 3;
-  const float* ub = u + (long)b * T;
   bf16_t* Ab = Arows + (long)b * nc * Kp;
   const bool live = k < M;
-  // everything the loops below need from global memory is requested up front
-  float hreg[IQ];
-#pragma unroll
-  for (int ii = 0; ii < IQ; ++ii) hreg[ii] = live ? Hs[(q * IQ + ii) * M + k] : 0.f;
+  const float* zero = reinterpret_cast<const float*>(kZeroBytes);  // masked loads: select on the address
   // row k of A^L, read from the transposed copy so that neighbouring lanes read neighbouring words
   float a[PER];
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
     const int kk = q * PER + j;
-    a[j] = (live && kk < M) ? ALT[(long)kk * M + k] : 0.f;
+    a[j] = *((live && kk < M) ? ALT + (long)kk * M + k : zero);
   }
-  {  // the chunk's own samples and the padding
-    const int wcols = Kp - M;
-    for (int idx = tid; idx < nc * wcols; idx += THREADS) {
-      const int c = idx / wcols, i = idx % wcols;
-      const int t = c * L + i;
-      Ab[(long)c * Kp + M + i] = (bf16_t)((i < L && t < T) ? ub[t] : 0.f);
-    }
-  }
-  for (int i = tid; i < MP; i += THREADS) S[i] = 0.f;  // X'_0
-  for (int c0 = 0; c0 < nc - 1; c0 += kScanUB) {
-    __syncthreads();  // the previous block of samples has been consumed
-    for (int idx = tid; idx < kScanUB * L; idx += THREADS) {
-      const int t = c0 * L + idx;
-      ublk[idx] = t < T ? ub[t] : 0.f;
-    }
-    __syncthreads();
-    const int ccn = min(kScanUB, nc - 1 - c0);  // full chunks in this block
-    for (int cc = 0; cc < ccn; ++cc) {
-      const f32x4* uv = reinterpret_cast<const f32x4*>(ublk + cc * L + q * IQ);
-      float v0 = 0.f, v1 = 0.f;
-#pragma unroll
-      for (int i4 = 0; i4 < IQ / 4; i4 += 2) {
-        const f32x4 va = uv[i4], vb = uv[i4 + 1];
-        v0 += hreg[4 * i4] * va[0] + hreg[4 * i4 + 1] * va[1] + hreg[4 * i4 + 2] * va[2] + hreg[4 * i4 + 3] * va[3];
-        v1 += hreg[4 * i4 + 4] * vb[0] + hreg[4 * i4 + 5] * vb[1] + hreg[4 * i4 + 6] * vb[2] + hreg[4 * i4 + 7] * vb[3];
-      }
-      float v = v0 + v1;
-      v += __shfl_xor(v, 1);
-      v += __shfl_xor(v, 2);
-      if (q == 0) S[(c0 + cc + 1) * MP + k] = v;  // Z_c waits in row c + 1
-    }
-  }
+  const float* Zb = Zbuf + (long)b * nc * MP;
+  scan_fill_lds<THREADS>(S, nc * MP, [&](int idx) { return idx < MP ? zero : Zb + idx - MP; });  // row c + 1 <- Z_c
   __syncthreads();
   for (int c = 0; c + 1 < nc; ++c) {
-    const f32x4* xv = reinterpret_cast<const f32x4*>(S + c * MP + q * PER);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-    for (int j4 = 0; j4 < PER / 4; ++j4) {
-      const f32x4 v = xv[j4];
-      s0 += a[4 * j4] * v[0];
-      s1 += a[4 * j4 + 1] * v[1];
-      s2 += a[4 * j4 + 2] * v[2];
-      s3 += a[4 * j4 + 3] * v[3];
-    }
-    float s = (s0 + s1) + (s2 + s3);
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    if (q == 0) S[(c + 1) * MP + k] += s;
+    const float z = S[(c + 1) * MP + k];  // read ahead of the dot product
+    const float s = scan_row_dot<PER>(a, S + c * MP + q * PER);
+    if (q == 0) S[(c + 1) * MP + k] = z + s;
     scan_lds_barrier();
   }
   for (int idx = tid; idx < nc * MP; idx += THREADS) {
@@ -161,84 +210,83 @@ __global__ __launch_bounds__(4 * MP) void k_scan_state_fwd(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
-// Costates of one utterance and the finished adjoint.  R [(b,c)][Kp] = [G_c | gu_intra | pad].
-//   Lambda_nc = 0, Lambda_c = G_c + (A^L)^T Lambda_{c+1};
-//   gu[cL+i] = gu_intra[c][i] + sum_k HsT[k][i] Lambda_{c+1}[k]   (times u > 0 when u != NULL).
-// LDS: Ls [ncp][MP], row c = Lambda_{c+1}; row c - 1 holds G_c until the recurrence adds to it.
+// Costates of one utterance.  R [(b,c)][Kp] = [G_c | gu_intra | pad];
+//   Lambda_nc = 0, Lambda_c = G_c + (A^L)^T Lambda_{c+1};  row (b,c) of Lbuf = Lambda_{c+1}.
+// LDS: Ls [nc][MP], row c = Lambda_{c+1}; row c - 1 holds G_c until the recurrence adds to it.
 // ---------------------------------------------------------------------------------------------
 template <int MP>
-__global__ __launch_bounds__(4 * MP) void k_scan_state_bwd(const float* __restrict__ R, const float* __restrict__ HsT,
-                                                           const float* __restrict__ AL, const float* __restrict__ u,
-                                                           float* __restrict__ gu, int T, int M, int Kp, int nc) {
-  constexpr int L = kScanL, Q = 4, PER = MP / Q, THREADS = 4 * MP;
+__global__ __launch_bounds__(4 * MP) void k_scan_state_bwd(const float* __restrict__ R, const float* __restrict__ AL,
+                                                           float* __restrict__ Lbuf, int M, int Kp, int nc) {
+  constexpr int Q = 4, PER = MP / Q, THREADS = 4 * MP;
   extern __shared__ __attribute__((aligned(16))) float scan_sm[];
-  const int ncp = (nc + 7) & ~7;
-  float* Ls = scan_sm;  // [ncp][MP]
+  float* Ls = scan_sm;  // [nc][MP]
   const int b = blockIdx.x, tid = threadIdx.x, k = tid >> 2, q = tid & 3;
   const bool live = k < M;
+  const float* zero = reinterpret_cast<const float*>(kZeroBytes);  // masked loads: select on the address
   const float* Rb = R + (long)b * nc * Kp;
   float a[PER];
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
     const int kk = q * PER + j;
-    a[j] = (live && kk < M) ? AL[(long)kk * M + k] : 0.f;  // (A^L)^T [k][kk], neighbouring lanes neighbouring words
+    a[j] = *((live && kk < M) ? AL + (long)kk * M + k : zero);  // (A^L)^T [k][kk], neighbouring lanes neighbouring words
   }
-  for (int idx = tid; idx < ncp * MP; idx += THREADS) {
-    const int c = idx / MP + 1, kk = idx % MP;  // row c - 1 <- G_c; the rows from nc - 1 on are zero
-    Ls[idx] = (c < nc && kk < M) ? Rb[(long)c * Kp + kk] : 0.f;
-  }
+  scan_fill_lds<THREADS>(Ls, nc * MP, [&](int idx) {
+    const int c = idx / MP + 1, kk = idx % MP;  // row c - 1 <- G_c; row nc - 1 = Lambda_nc = 0
+    return (idx >= 0 && c < nc && kk < M) ? Rb + (long)c * Kp + kk : zero;
+  });
   __syncthreads();
   for (int c = nc - 1; c >= 1; --c) {
-    const f32x4* xv = reinterpret_cast<const f32x4*>(Ls + c * MP + q * PER);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-    for (int j4 = 0; j4 < PER / 4; ++j4) {
-      const f32x4 v = xv[j4];
-      s0 += a[4 * j4] * v[0];
-      s1 += a[4 * j4 + 1] * v[1];
-      s2 += a[4 * j4 + 2] * v[2];
-      s3 += a[4 * j4 + 3] * v[3];
-    }
-    float s = (s0 + s1) + (s2 + s3);
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    if (q == 0) Ls[(c - 1) * MP + k] += s;
+    const float g = Ls[(c - 1) * MP + k];  // read ahead of the dot product
+    const float s = scan_row_dot<PER>(a, Ls + c * MP + q * PER);
+    if (q == 0) Ls[(c - 1) * MP + k] = g + s;
     scan_lds_barrier();
   }
-  // gu: lane group (i, q) sums its quarter of the state components for eight chunks at a time
+  float* Lb = Lbuf + (long)b * nc * MP;
+  for (int idx = tid; idx < nc * MP; idx += THREADS) Lb[idx] = Ls[idx];
+}
+
+// k_scan_rows_bwd: gu[cL+i] = gu_intra[c][i] + sum_k HsT[k][i] Lambda_{c+1}[k]  (times u > 0 when u != NULL),
+//   lane group (i, q) sums its quarter of the state components.
+template <int MP>
+__global__ __launch_bounds__(4 * MP) void k_scan_rows_bwd(const float* __restrict__ R, const float* __restrict__ Lbuf,
+                                                          const float* __restrict__ HsT, const float* __restrict__ u,
+                                                          float* __restrict__ gu, int T, int M, int Kp, int nc) {
+  constexpr int L = kScanL, Q = 4, PER = MP / Q, THREADS = 4 * MP;
+  __shared__ __attribute__((aligned(16))) float Ls[kScanCB * MP];
+  const int b = blockIdx.x, c0 = blockIdx.y * kScanCB, tid = threadIdx.x, q = tid & 3;
+  const int ccn = min(kScanCB, nc - c0);
+  const float* zero = reinterpret_cast<const float*>(kZeroBytes);  // masked loads: select on the address
+  const float* Lb = Lbuf + ((long)b * nc + c0) * MP;
+  scan_fill_lds<THREADS>(Ls, kScanCB * MP, [&](int idx) { return (idx >= 0 && idx < ccn * MP) ? Lb + idx : zero; });
+  const float* Rb = R + ((long)b * nc + c0) * Kp;
+  __syncthreads();
   for (int i = tid >> 2; i < L; i += MP) {  // whole groups of four lanes stay together
     float h[PER];
 #pragma unroll
     for (int jj = 0; jj < PER; ++jj) {
       const int kk = q * PER + jj;
-      h[jj] = kk < M ? HsT[(long)kk * L + i] : 0.f;
+      h[jj] = *(kk < M ? HsT + (long)kk * L + i : zero);
     }
-    for (int c0 = 0; c0 < nc; c0 += 8) {
-      float gi[8];
+    float gi[kScanCB];
 #pragma unroll
-      for (int cc = 0; cc < 8; ++cc) {
-        const int c = c0 + cc;
-        gi[cc] = (q == 0 && c < nc && c * L + i < T) ? Rb[(long)c * Kp + M + i] : 0.f;
-      }
+    for (int cc = 0; cc < kScanCB; ++cc)
+      gi[cc] = *((q == 0 && cc < ccn && (c0 + cc) * L + i < T) ? Rb + (long)cc * Kp + M + i : zero);
 #pragma unroll 2
-      for (int cc = 0; cc < 8; ++cc) {
-        const f32x4* lv = reinterpret_cast<const f32x4*>(Ls + (c0 + cc) * MP + q * PER);
-        float v0 = 0.f, v1 = 0.f;
+    for (int cc = 0; cc < kScanCB; ++cc) {
+      const f32x4* lv = reinterpret_cast<const f32x4*>(Ls + cc * MP + q * PER);
+      float v0 = 0.f, v1 = 0.f;
 #pragma unroll
-        for (int j4 = 0; j4 < PER / 4; j4 += 2) {
-          const f32x4 va = lv[j4], vb = lv[j4 + 1];
-          v0 += h[4 * j4] * va[0] + h[4 * j4 + 1] * va[1] + h[4 * j4 + 2] * va[2] + h[4 * j4 + 3] * va[3];
-          v1 += h[4 * j4 + 4] * vb[0] + h[4 * j4 + 5] * vb[1] + h[4 * j4 + 6] * vb[2] + h[4 * j4 + 7] * vb[3];
-        }
-        float v = v0 + v1;
-        v += __shfl_xor(v, 1);
-        v += __shfl_xor(v, 2);
-        const int c = c0 + cc, t = c * L + i;
-        if (q == 0 && c < nc && t < T) {
-          float gval = gi[cc] + v;
-          if (u && !(u[(long)b * T + t] > 0.f)) gval = 0.f;
-          gu[(long)b * T + t] = gval;
-        }
+      for (int j4 = 0; j4 < PER / 4; j4 += 2) {
+        const f32x4 va = lv[j4], vb = lv[j4 + 1];
+        v0 += h[4 * j4] * va[0] + h[4 * j4 + 1] * va[1] + h[4 * j4 + 2] * va[2] + h[4 * j4 + 3] * va[3];
+        v1 += h[4 * j4 + 4] * vb[0] + h[4 * j4 + 5] * vb[1] + h[4 * j4 + 6] * vb[2] + h[4 * j4 + 7] * vb[3];
+      }
+      const float v = scan_quad_sum(v0 + v1);
+      const int t = (c0 + cc) * L + i;
+      if (q == 0 && cc < ccn && t < T) {
+        float gval = gi[cc] + v;
+        if (u && !(u[(long)b * T + t] > 0.f)) gval = 0.f;
+        gu[(long)b * T + t] = gval;
       }
     }
   }
@@ -395,7 +443,7 @@ __global__ __launch_bounds__(ScanTile::THREADS) void k_scan_gemm_adj(const bf16_
 
 struct ScanPlan {
   int nc, rows, row_tiles, col_tiles, S, kper;
-  size_t off_arows, off_slabs, off_R, total;
+  size_t off_arows, off_zbuf, off_slabs, off_R, total;  // zbuf: Z rows forward, costate rows backward
 };
 static ScanPlan scan_plan(int B, int T, int M) {
   const ScanLayout l = scan_layout(M);
@@ -412,6 +460,8 @@ static ScanPlan scan_plan(int B, int T, int M) {
   size_t off = 0;
   p.off_arows = off;
   off += scan_al256(2 * (size_t)p.rows * l.Kp);
+  p.off_zbuf = off;
+  off += scan_al256(4 * (size_t)p.rows * 256);
   p.off_slabs = off;
   off += scan_al256(4 * (size_t)p.S * p.rows * l.Kp);
   p.off_R = off;
@@ -458,17 +508,23 @@ int scan_conv_forward(const lmufft_shape& s, const float* u, const void* scanpre
   const ScanLayout l = scan_layout(s.M);
   const char* sp = (const char*)scanprep;
   bf16_t* Arows = (bf16_t*)((char*)ws + p.off_arows);
+  float* Zbuf = (float*)((char*)ws + p.off_zbuf);
   {
     const int rc = scan_dispatch_mp(s.M, [&](auto mp_c) -> int {
       constexpr int MP = decltype(mp_c)::value;
-      const size_t lds = sizeof(float) * ((size_t)p.nc * MP + kScanUB * kScanL);
+      const size_t lds = sizeof(float) * (size_t)p.nc * MP;
       if (lds > 160 * 1024) return set_error("scan convolution: sequence too long (T=%d)", s.T);
       if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)k_scan_state_fwd<MP>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return set_error("cannot reserve %zu bytes of LDS for k_scan_state_fwd", lds);
+      {
+        PROFS("k_scan_rows_fwd");
+        hipLaunchKernelGGL(k_scan_rows_fwd<MP>, dim3(s.B, (p.nc + kScanCB - 1) / kScanCB), dim3(4 * MP), 0, st, u,
+                           (const float*)(sp + l.off_Hs), Arows, Zbuf, s.T, s.M, l.Kp, p.nc);
+      }
       PROFS("k_scan_state_fwd");
-      hipLaunchKernelGGL(k_scan_state_fwd<MP>, dim3(s.B), dim3(4 * MP), lds, st, u, (const float*)(sp + l.off_Hs),
-                         (const float*)(sp + l.off_ALT), Arows, s.T, s.M, l.Kp, p.nc);
+      hipLaunchKernelGGL(k_scan_state_fwd<MP>, dim3(s.B), dim3(4 * MP), lds, st, (const float*)Zbuf,
+                         (const float*)(sp + l.off_ALT), Arows, s.M, l.Kp, p.nc);
       return 0;
     });
     if (rc) return rc;
@@ -522,21 +578,27 @@ int scan_conv_backward(const lmufft_shape& s, const bf16_t* gm, const void* scan
     if (int rc = launch_sum_slabs_masked(slabs, nullptr, R, (long)p.rows * l.Kp, p.S, st)) return rc;
     Rsum = R;
   }
+  float* Lbuf = (float*)((char*)ws + p.off_zbuf);
   {
     const int rc = scan_dispatch_mp(s.M, [&](auto mp_c) -> int {
       constexpr int MP = decltype(mp_c)::value;
-      const size_t lds = sizeof(float) * (size_t)((p.nc + 7) & ~7) * MP;
+      const size_t lds = sizeof(float) * (size_t)p.nc * MP;
       if (lds > 160 * 1024) return set_error("scan convolution: sequence too long (T=%d)", s.T);
       if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)k_scan_state_bwd<MP>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return set_error("cannot reserve %zu bytes of LDS for k_scan_state_bwd", lds);
-      PROFS("k_scan_state_bwd");
-      hipLaunchKernelGGL(k_scan_state_bwd<MP>, dim3(s.B), dim3(4 * MP), lds, st, Rsum,
-                         (const float*)(sp + l.off_HsT), (const float*)(sp + l.off_AL), u, gu, s.T, s.M, l.Kp, p.nc);
+      {
+        PROFS("k_scan_state_bwd");
+        hipLaunchKernelGGL(k_scan_state_bwd<MP>, dim3(s.B), dim3(4 * MP), lds, st, Rsum,
+                           (const float*)(sp + l.off_AL), Lbuf, s.M, l.Kp, p.nc);
+      }
+      PROFS("k_scan_rows_bwd");
+      hipLaunchKernelGGL(k_scan_rows_bwd<MP>, dim3(s.B, (p.nc + kScanCB - 1) / kScanCB), dim3(4 * MP), 0, st, Rsum,
+                         (const float*)Lbuf, (const float*)(sp + l.off_HsT), u, gu, s.T, s.M, l.Kp, p.nc);
       return 0;
     });
     if (rc) return rc;
-    LAUNCH_CHECKS("k_scan_state_bwd");
+    LAUNCH_CHECKS("k_scan_rows_bwd");
   }
   return 0;
 }
