@@ -63,6 +63,13 @@ __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 // the ADDRESS lets every staging load of a tile stay in flight behind the MFMAs.
 static __device__ __attribute__((aligned(32))) unsigned int kZeroBytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
+// *p when ok, else 0 -- as a select on the ADDRESS (masked elements read a line of zeros).  Written as
+// `ok ? *p : 0.f` the load sits in a branch of its own with an s_waitcnt vmcnt(0) behind it, so a run
+// of masked loads becomes as many serial memory round trips; this form leaves them all in flight.
+__device__ __forceinline__ float load_or_zero(const float* p, bool ok) {
+  return *(ok ? p : reinterpret_cast<const float*>(kZeroBytes));
+}
+
 // base[idx .. idx+3]; elements at or beyond `limit` (position pos + j) and the
 // whole vector when !ok read as zero.  With VEC the caller guarantees
 // idx % 4 == 0, limit % 4 == 0 and a 16-byte aligned base.

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(LinearTile::THREADS) void k_linear_glds_bf16(const 
   gemm_loop_glds<TL>(oa, ob, acc, 0, K, w);
 
   float bcol[TL::TN];
-  preload_cols<TL>(bcol, w, [&](int nn) { return (bias && n0 + nn < N) ? bias[n0 + nn] : 0.f; });
+  preload_cols<TL>(bcol, w, [&](int nn) { return load_or_zero(bias + n0 + nn, bias && n0 + nn < N); });
   bf16_t* tile = reinterpret_cast<bf16_t*>(smem_raw);
   store_tile_bf16<TL>(acc, w, tile, out, N, m0, n0, rows, N,
                       [&](int, int tn, int, int, int, float v) { return v + bcol[tn]; });
@@ -492,14 +492,14 @@ __global__ __launch_bounds__(256) void k_linear_wprep(const float* __restrict__ 
       const int n = (int)(i / g1), k0 = (int)(i % g1) * 8;
       bf16x8 o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(n < N ? W[(long)n * K + k0 + e] : 0.f);
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)load_or_zero(W + (long)n * K + k0 + e, n < N);  // all eight in flight
       *reinterpret_cast<bf16x8*>(Wb + (long)n * K + k0) = o;
     } else if (i < n1 + n2) {
       const long r = i - n1;
       const int j = (int)(r % K), n0 = (int)(r / K) * 8;
       bf16x8 o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(n0 + e < N ? W[(long)(n0 + e) * K + j] : 0.f);
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)load_or_zero(W + (long)(n0 + e) * K + j, n0 + e < N);
       *reinterpret_cast<bf16x8*>(WbT + (long)j * ldT + n0) = o;
     } else {
       const int n = (int)(i - n1 - n2);

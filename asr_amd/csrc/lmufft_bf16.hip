@@ -65,6 +65,8 @@ __device__ __forceinline__ void prep_weights_blocks(const WeightPrep& q, int blo
   bf16_t* __restrict__ WbT = q.WbT;
   const int Hd = q.Hd, MD = q.MD, ldW = q.ldW, ldWT = q.ldWT;
   // a thread writes eight consecutive bf16 (one 16-byte store); ldW and ldWT are multiples of 8.
+  // Its eight loads are unconditional (load_or_zero), so they are in flight together: as eight
+  // branches with a wait each they were the tail of the encoder kernel these blocks ride on.
   // Wb: eight consecutive k of one row.  WbT: eight consecutive n of one column j, with
   // consecutive threads on consecutive j, so that the strided reads of W coalesce across lanes.
   const int g1 = ldW / 8, g2 = ldWT / 8;
@@ -75,13 +77,13 @@ __device__ __forceinline__ void prep_weights_blocks(const WeightPrep& q, int blo
     if (i < n1) {
       const int n = (int)(i / g1), k0 = (int)(i % g1) * 8;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(k0 + e < MD ? W[(long)n * MD + k0 + e] : 0.f);
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)load_or_zero(W + (long)n * MD + k0 + e, k0 + e < MD);
       *reinterpret_cast<bf16x8*>(Wb + (long)n * ldW + k0) = o;
     } else {
       const long r = i - n1;
       const int j = (int)(r % MD), n0 = (int)(r / MD) * 8;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(n0 + e < Hd ? W[(long)(n0 + e) * MD + j] : 0.f);
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)load_or_zero(W + (long)(n0 + e) * MD + j, n0 + e < Hd);
       *reinterpret_cast<bf16x8*>(WbT + (long)j * ldWT + n0) = o;
     }
   }
@@ -137,16 +139,30 @@ __global__ __launch_bounds__(kThreads) void k_encode_fwd_bf16(const bf16_t* __re
       const bf16_t* xr = x + row * D;
       const bf16_t* xr2 = x + (two ? row2 : row) * D;
       float s = 0.f, s2 = 0.f;
-      for (int c = sub * 8; c < D; c += 128) {
-        const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xr + c);
-        const bf16x8 xv2 = *reinterpret_cast<const bf16x8*>(xr2 + c);
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(w_u + c);
-        const f32x4 w1 = *reinterpret_cast<const f32x4*>(w_u + c + 4);
+      // four 128-column passes at a time with every load issued before the first use (a plain loop over
+      // the passes waits for each pass's loads in turn: three dependent trips to memory per row at D = 384);
+      // passes beyond D read a line of zeros
+      const bf16_t* zx = reinterpret_cast<const bf16_t*>(kZeroBytes);
+      const float* zw = reinterpret_cast<const float*>(kZeroBytes);
+      for (int c0 = sub * 8; c0 < D; c0 += 512) {
+        bf16x8 xv[4], xv2[4];
+        f32x4 w0[4], w1[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          s += (float)xv[j] * w0[j] + (float)xv[4 + j] * w1[j];
-          s2 += (float)xv2[j] * w0[j] + (float)xv2[4 + j] * w1[j];
+        for (int i = 0; i < 4; ++i) {
+          const int c = c0 + 128 * i;
+          const bool ok = c < D;
+          xv[i] = *reinterpret_cast<const bf16x8*>(ok ? xr + c : zx);
+          xv2[i] = *reinterpret_cast<const bf16x8*>(ok ? xr2 + c : zx);
+          w0[i] = *reinterpret_cast<const f32x4*>(ok ? w_u + c : zw);
+          w1[i] = *reinterpret_cast<const f32x4*>(ok ? w_u + c + 4 : zw);
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            s += (float)xv[i][j] * w0[i][j] + (float)xv[i][4 + j] * w1[i][j];
+            s2 += (float)xv2[i][j] * w0[i][j] + (float)xv2[i][4 + j] * w1[i][j];
+          }
       }
 #pragma unroll
       for (int off = 8; off > 0; off >>= 1) {
@@ -313,7 +329,7 @@ __global__ __launch_bounds__(kThreads) void k_proj_fwd_bf16(const bf16_t* __rest
   gemm_loop_kc<TL>(oa, ob, acc, 0, K, w);
 
   float bcol[TL::TN];
-  preload_cols<TL>(bcol, w, [&](int nn) { return n0 + nn < Hd ? bias[n0 + nn] : 0.f; });
+  preload_cols<TL>(bcol, w, [&](int nn) { return load_or_zero(bias + n0 + nn, n0 + nn < Hd); });
   tile_epilogue_ix<TL>(acc, w, [&](int, int tn, int, int mm, int nn, float v) {
     const long row = m0 + mm;
     const int n = n0 + nn;
@@ -384,7 +400,7 @@ __global__ __launch_bounds__(ProjGldsTile::THREADS) void k_proj_fwd_glds_bf16(
   LMUFFT_STAMP(4, 1);
 
   float bcol[TL::TN];
-  preload_cols<TL>(bcol, w, [&](int nn) { return n0 + nn < Hd ? bias[n0 + nn] : 0.f; });
+  preload_cols<TL>(bcol, w, [&](int nn) { return load_or_zero(bias + n0 + nn, n0 + nn < Hd); });
   bf16_t* tile = reinterpret_cast<bf16_t*>(smem_raw);
   store_tile_bf16<TL>(acc, w, tile, h, Hd, m0, n0, rows, Hd,
                       [&](int, int tn, int, int, int, float v) { return fmaxf(v + bcol[tn], 0.f); });
@@ -532,8 +548,8 @@ __global__ __launch_bounds__(kThreads) void k_dgrad_bf16(const bf16_t* __restric
   gemm_loop_kc<TL>(oa, ob, acc, 0, Hd, w);
 
   float wcol[TL::TN], grow[TL::TM][16];
-  preload_cols<TL>(wcol, w, [&](int nn) { return (ga && n0 + nn < ncols) ? w_u[n0 + nn] : 0.f; });
-  preload_rows<TL>(grow, w, [&](int mm) { return (ga && m0 + mm < rows) ? ga[m0 + mm] : 0.f; });
+  preload_cols<TL>(wcol, w, [&](int nn) { return load_or_zero(w_u + n0 + nn, ga && n0 + nn < ncols); });
+  preload_rows<TL>(grow, w, [&](int mm) { return load_or_zero(ga + m0 + mm, ga && m0 + mm < rows); });
   tile_epilogue_ix<TL>(acc, w, [&](int tm, int tn, int i, int mm, int nn, float v) {
     const long row = m0 + mm;
     const int j = n0 + nn;
@@ -575,7 +591,7 @@ __global__ __launch_bounds__(TL::THREADS) void k_dgrad_glds_bf16(const bf16_t* _
 #pragma unroll
     for (int i = 0; i < kGaPer; ++i) {
       const int p = ga_grp + i * kGaGroups;
-      ga_part[i] = (p < gp.P && m0 + ga_row < rows) ? gp.part[(long)p * gp.stride + m0 + ga_row] : 0.f;
+      ga_part[i] = load_or_zero(gp.part + (long)p * gp.stride + m0 + ga_row, p < gp.P && m0 + ga_row < rows);
     }
   }
 
@@ -622,12 +638,12 @@ __global__ __launch_bounds__(TL::THREADS) void k_dgrad_glds_bf16(const bf16_t* _
     __syncthreads();
     if (threadIdx.x < TL::BM) sc[ga_row] = v;
     __syncthreads();
-    preload_cols<TL>(wcol, w, [&](int nn) { return n0 + nn < ncols ? w_u[n0 + nn] : 0.f; });
+    preload_cols<TL>(wcol, w, [&](int nn) { return load_or_zero(w_u + n0 + nn, n0 + nn < ncols); });
     preload_rows<TL>(grow, w, [&](int mm) { return sc[mm]; });
     __syncthreads();  // the epilogue reuses the same LDS
   } else {
-    preload_cols<TL>(wcol, w, [&](int nn) { return (ga && n0 + nn < ncols) ? w_u[n0 + nn] : 0.f; });
-    preload_rows<TL>(grow, w, [&](int mm) { return (ga && m0 + mm < rows) ? ga[m0 + mm] : 0.f; });
+    preload_cols<TL>(wcol, w, [&](int nn) { return load_or_zero(w_u + n0 + nn, ga && n0 + nn < ncols); });
+    preload_rows<TL>(grow, w, [&](int mm) { return load_or_zero(ga + m0 + mm, ga && m0 + mm < rows); });
   }
   bf16_t* tile = reinterpret_cast<bf16_t*>(smem_raw);
   store_tile_bf16<TL>(acc, w, tile, out, ncols, m0, n0, rows, ncols,

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(kThreads) void k_proj_fwd(const float* __restrict__
   gemm_tile<TL>(smem, acc, la, lb, 0, K, w);
 
   float bcol[TL::TN];
-  preload_cols<TL>(bcol, w, [&](int nn) { return n0 + nn < Hd ? bias[n0 + nn] : 0.f; });
+  preload_cols<TL>(bcol, w, [&](int nn) { return load_or_zero(bias + n0 + nn, n0 + nn < Hd); });
   tile_epilogue_ix<TL>(acc, w, [&](int, int tn, int, int mm, int nn, float v) {
     const long row = m0 + mm;
     const int n = n0 + nn;
@@ -264,8 +264,8 @@ __global__ __launch_bounds__(kThreads) void k_dgrad(const float* __restrict__ h,
   gemm_tile<TL>(smem, acc, la, lb, 0, Hd, w);
 
   float wcol[TL::TN], grow[TL::TM][16];
-  preload_cols<TL>(wcol, w, [&](int nn) { return (ga && n0 + nn < ncols) ? w_u[n0 + nn] : 0.f; });
-  preload_rows<TL>(grow, w, [&](int mm) { return (ga && m0 + mm < rows) ? ga[m0 + mm] : 0.f; });
+  preload_cols<TL>(wcol, w, [&](int nn) { return load_or_zero(w_u + n0 + nn, ga && n0 + nn < ncols); });
+  preload_rows<TL>(grow, w, [&](int mm) { return load_or_zero(ga + m0 + mm, ga && m0 + mm < rows); });
   tile_epilogue_ix<TL>(acc, w, [&](int tm, int tn, int i, int mm, int nn, float v) {
     const long row = m0 + mm;
     const int j = n0 + nn;
