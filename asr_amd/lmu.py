@@ -69,9 +69,9 @@ def _AUTO_PREFERS_FFT(T, M):
 
 # bf16 path: sequence length from which conv_algo="auto" takes the state-space ("scan") route.  Its work per
 # frame is constant (M * (M + 128) multiply-adds) where the Toeplitz kernels' grows with T / 2; measured on
-# MI355X at batch 32, 192 memory channels, forward + adjoint, Toeplitz / scan: T=1024 51 / 78 us,
-# T=1536 77 / 88, T=2048 112 / 94, T=3000 214 / 121 (batch 8, T=3000: 125 / 101).
-_SCAN_MIN_T = 1792
+# MI355X at batch 32, 192 memory channels, forward + adjoint, Toeplitz / scan: T=1024 51 / 72 us,
+# T=1536 76 / 77, T=2048 111 / 83, T=3000 215 / 104.
+_SCAN_MIN_T = 1600
 
 # (device, memory size, bytes of A and B) -> constants of the scan route; layers with the same (A, B) share them
 _SCANPREP_CACHE = {}
