@@ -31,6 +31,8 @@ typedef float attn_f4 __attribute__((ext_vector_type(4)));
 typedef __bf16 attn_bf16;
 
 constexpr int kAttnKeys = 32;       // keys per tile
+// what masked loads read (the address is selected, not the value: the load stays unconditional)
+static __device__ __attribute__((aligned(16))) unsigned int attn_zero_line[4] = {0, 0, 0, 0};
 
 template <class T>
 __device__ __forceinline__ float attn_ld(const T* p) { return (float)*p; }
@@ -246,7 +248,8 @@ __global__ __launch_bounds__(64 * NW) void k_attention_bwd_dq(const TIO* __restr
   }
   D += __shfl_xor(D, 32);
   if (hh == 0 && q_in) dsum[bh * T + qi] = D;
-  const float m = q_in ? stats[2 * (bh * T + qi)] : 0.f, invl = q_in ? stats[2 * (bh * T + qi) + 1] : 0.f;
+  const float* sp = q_in ? stats + 2 * (bh * T + qi) : reinterpret_cast<const float*>(attn_zero_line);
+  const float m = sp[0], invl = sp[1];
 
   attn_f16v dqa[DT];
 #pragma unroll
@@ -393,9 +396,14 @@ __global__ __launch_bounds__(64 * NW) void k_attention_bwd_dkv(const TIO* __rest
     }
     if (tid < kAttnKeys) {  // rows past T get weight 0 through 1/l = 0
       const int qq = i0 + tid;
-      mst = qq < T ? stats[2 * (bh * T + qq)] : 0.f;
-      lst = qq < T ? stats[2 * (bh * T + qq) + 1] : 0.f;
-      dst = qq < T ? dsum[bh * T + qq] : 0.f;
+      // rows past T read a line of zeros: with the select on the address the three loads are unconditional and
+      // stay in flight behind the tile's own prefetch (as selects on the value each sat in a branch with a wait
+      // for EVERY outstanding load behind it, once per query tile)
+      const float* zp = reinterpret_cast<const float*>(attn_zero_line);
+      const float* sp = qq < T ? stats + 2 * (bh * T + qq) : zp;
+      mst = sp[0];
+      lst = sp[1];
+      dst = *(qq < T ? dsum + bh * T + qq : zp);
     }
   };
   auto stage = [&]() {
@@ -926,9 +934,14 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 2 : 1) void k_attention_bwd_dkv
     }
     if (tid < 32) {  // rows past T get weight 0 through 1/l = 0
       const int qq = i0 + tid;
-      mst = qq < T ? stats[2 * (bh * T + qq)] : 0.f;
-      lst = qq < T ? stats[2 * (bh * T + qq) + 1] : 0.f;
-      dst = qq < T ? dsum[bh * T + qq] : 0.f;
+      // rows past T read a line of zeros: with the select on the address the three loads are unconditional and
+      // stay in flight behind the tile's own prefetch (as selects on the value each sat in a branch with a wait
+      // for EVERY outstanding load behind it, once per query tile)
+      const float* zp = reinterpret_cast<const float*>(attn_zero_line);
+      const float* sp = qq < T ? stats + 2 * (bh * T + qq) : zp;
+      mst = sp[0];
+      lst = sp[1];
+      dst = *(qq < T ? dsum + bh * T + qq : zp);
     }
   };
   auto stage = [&]() {

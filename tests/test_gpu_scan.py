@@ -25,6 +25,7 @@ SHAPES = [
     (2, 700, 8, 20.0),       # the smallest memory
     (1, 2048, 256, 1000.0),  # the largest memory, whole chunks only
     (33, 640, 192, 1000.0),  # more rows than one 128-row tile, batch not a multiple of anything
+    (1, 16384, 192, 1000.0), # the longest sequence the layer's other long-sequence route takes: 128 chunks
 ]
 
 
