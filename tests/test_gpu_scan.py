@@ -55,27 +55,37 @@ def test_scan_conv_forward_and_adjoint(B, T, M, theta):
     # (1) the kernels against the numpy evaluation of the same route: one bf16 rounding of the result,
     #     fp32 accumulation, the state rounded from fp32 instead of fp64
     emu = scan_forward_numpy(u.astype(np.float64), sec, M, L)
-    absemu = scan_forward_numpy(np.abs(u).astype(np.float64), {**sec, "Wc": np.abs(sec["Wc"]), "AL": np.abs(sec["AL"]),
-                                                              "Hs": np.abs(sec["Hs"])}, M, L)
-    bad = np.abs(m - emu) > 2.0 ** -8 * np.abs(emu) + 2.0 ** -9 * 1e-1 * absemu + 1e-30
-    assert bad.mean() < 1e-3, (float(bad.mean()), float(np.abs(m - emu).max()))
+    long_seq = T > 4096  # the all-positive evaluation that scales the element-wise bars grows like 10^chunks
+    if long_seq:
+        assert np.sqrt(((m - emu) ** 2).mean()) <= 2.0 ** -8 * np.sqrt((emu ** 2).mean())
+    else:
+        absemu = scan_forward_numpy(np.abs(u).astype(np.float64), {**sec, "Wc": np.abs(sec["Wc"]), "AL": np.abs(sec["AL"]),
+                                                                  "Hs": np.abs(sec["Hs"])}, M, L)
+        bad = np.abs(m - emu) > 2.0 ** -8 * np.abs(emu) + 2.0 ** -9 * 1e-1 * absemu + 1e-30
+        assert bad.mean() < 1e-3, (float(bad.mean()), float(np.abs(m - emu).max()))
     # (2) the bf16 bar against the oracle on the un-rounded impulse response
     ub = round_bf16(u)
     ref = orc.causal_conv_direct(ub, H) if T <= 1000 else orc.causal_conv_fft(ub, H)
     term = np.sqrt(np.maximum(orc.causal_conv_direct(ub ** 2, H ** 2) if T <= 1000 else orc.causal_conv_fft(ub ** 2, H ** 2), 0))
     err = np.abs(m - ref)
-    assert np.all(err <= 2e-2 * (np.abs(ref) + 2 * term) + 1e-30), float((err / (2e-2 * (np.abs(ref) + 2 * term) + 1e-30)).max())
+    # (beyond 1000 frames the oracle is its FFT form, whose own round-off is ~1e-16 of the largest value: the floor)
+    floor = 1e-30 if T <= 1000 else 1e-12 * np.abs(ref).max()
+    assert np.all(err <= 2e-2 * (np.abs(ref) + 2 * term) + floor), float((err / (2e-2 * (np.abs(ref) + 2 * term) + floor)).max())
     assert np.sqrt((err ** 2).mean()) <= 5e-3 * np.sqrt((ref ** 2).mean())
 
     gu = causal_conv_adjoint_scan_bf16(torch.from_numpy(gm).to(dev).bfloat16(), sp).cpu().numpy().astype(np.float64)
     gemu = scan_adjoint_numpy(gm, sec, M, L)
-    gabs = scan_adjoint_numpy(np.abs(gm), {**sec, "Wc": np.abs(sec["Wc"]), "ALT": np.abs(sec["ALT"]),
-                                           "HsT": np.abs(sec["HsT"])}, M, L)
-    assert np.all(np.abs(gu - gemu) <= 1e-5 * np.abs(gemu) + 4e-6 * gabs + 1e-30), float(np.abs(gu - gemu).max())
+    if long_seq:
+        assert np.sqrt(((gu - gemu) ** 2).mean()) <= 1e-5 * np.sqrt((gemu ** 2).mean())
+    else:
+        gabs = scan_adjoint_numpy(np.abs(gm), {**sec, "Wc": np.abs(sec["Wc"]), "ALT": np.abs(sec["ALT"]),
+                                               "HsT": np.abs(sec["HsT"])}, M, L)
+        assert np.all(np.abs(gu - gemu) <= 1e-5 * np.abs(gemu) + 4e-6 * gabs + 1e-30), float(np.abs(gu - gemu).max())
     gref = orc.anticausal_corr_direct(gm, H) if T <= 1000 else orc.anticausal_corr_fft(gm, H)
     gterm = np.sqrt(np.maximum(orc.anticausal_corr_direct(gm ** 2, H ** 2) if T <= 1000 else orc.anticausal_corr_fft(gm ** 2, H ** 2), 0))
     gerr = np.abs(gu - gref)
-    assert np.all(gerr <= 2e-2 * (np.abs(gref) + 2 * gterm) + 1e-30)
+    gfloor = 1e-30 if T <= 1000 else 1e-12 * np.abs(gref).max()
+    assert np.all(gerr <= 2e-2 * (np.abs(gref) + 2 * gterm) + gfloor)
     assert np.sqrt((gerr ** 2).mean()) <= 5e-3 * np.sqrt((gref ** 2).mean())
 
 
