@@ -126,6 +126,9 @@ class LMUFFT(nn.Module):
         A, B = self.A, self.B
         key = (A.device, A.shape[0], A._version, B._version, A.data_ptr(), B.data_ptr())
         if getattr(self, "_scanprep", None) is None or self._scanprep[0] != key:
+            if A.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("LMUFFT: the state-space convolution route reads A and B on the host at its first "
+                                   "call; run the layer once at this sequence length before capturing a HIP graph")
             content = (str(A.device), A.shape[0], A.detach().float().cpu().numpy().tobytes(),
                        B.detach().float().cpu().numpy().tobytes())
             hit = _SCANPREP_CACHE.get(content)
