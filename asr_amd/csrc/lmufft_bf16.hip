@@ -573,11 +573,18 @@ __global__ __launch_bounds__(TL::THREADS) void k_dgrad_glds_bf16(const bf16_t* _
                                                                  const bf16_t* __restrict__ WbT,
                                                                  bf16_t* __restrict__ out,
                                                                  const float* __restrict__ ga,
-                                                                 const float* __restrict__ w_u, int rows, int Hd,
-                                                                 int ldWT, int j_begin, int ncols, GaParts gp) {
+                                                                 const float* __restrict__ w_u, int rows_all, int Hd,
+                                                                 int ldWT, int j_begin, int ncols, GaParts gp,
+                                                                 int rpw, int col_tiles) {
+  // A workgroup owns rpw <= BM rows (rpw is chosen so that the grid fills the chip: the tile's remaining rows
+  // are computed on zeros and not stored) and one column tile; the column tiles of a row range are neighbours
+  // on one XCD (1-D grid, xcd_slot), so that the rows they share come from HBM once.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int n0 = blockIdx.x * TL::BN;
-  const long m0 = (long)blockIdx.y * TL::BM;
+  const XcdSlot slot = xcd_slot(col_tiles);
+  const int n0 = slot.member * TL::BN;
+  const long m0 = (long)slot.group * rpw;
+  if (m0 >= rows_all) return;
+  const int rows = (int)min((long)rows_all, m0 + rpw);  // rows at or beyond it belong to the next workgroup
 
   // Encoder-activation gradient from the adjoint convolution's partial slabs, for this tile's rows:
   // ga[row] = (u[row] > 0) sum_p part[p][row].  The partial loads are issued here and summed after
@@ -652,7 +659,10 @@ __global__ __launch_bounds__(TL::THREADS) void k_dgrad_glds_bf16(const bf16_t* _
 
 using DgradMTileB = TileB<64, 192, 64, 2, 2>;    // memory columns (M = 192): one column tile
 using DgradXTileB = TileB<128, 128, 64, 2, 2>;   // register-staged fallback for the input columns
-using DgradXGldsTile = TileB<128, 384, 64, 2, 4>;  // input columns, LDS-DMA form, eight waves
+// input columns, LDS-DMA form, eight waves.  256 x 192: a workgroup's operand ingest per output is smallest
+// when its rows and columns are about equal in number (the whole weight panel passes through every CU);
+// 128 x 384 pulled 393 KB per 128 rows, this tile with 200-row ranges 301 KB per 200.
+using DgradXGldsTile = TileB<256, 192, 64, 4, 2>;
 
 // ---------------------------------------------------------------------------
 // gu partial slabs: P[i][tau] = sum_k gm[t0+i][k] H[k][tau], summed along the
@@ -1576,7 +1586,13 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
     using TF = decltype(fallback_tag);
     const bool fast = (s->Hd % 8 == 0) && (ncols % 8 == 0) && al16(out);
     if (fast) {
-      const dim3 grid(cdivb(ncols, TG::BN), cdivb(rows, TG::BM));
+      // rows per workgroup: the whole tile when that already gives a workgroup per CU, otherwise the row
+      // ranges are shortened until the grid fills the chip (batch 64 x 400 frames: 200 rows, 256 workgroups)
+      const int col_tiles = cdivb(ncols, TG::BN);
+      int rpw = TG::BM;
+      if ((long)cdivb(rows, TG::BM) * col_tiles < 256)
+        rpw = std::min<long>(TG::BM, (cdivb(rows, std::max(1, 256 / col_tiles)) + 7) / 8 * 8);
+      const dim3 grid(xcd_grid(cdivb(rows, rpw), col_tiles));
       const size_t lds = 2 * (size_t)(TG::BM + TG::BN) * kGldsRowBytes;
       static_assert(2 * (TG::BM + TG::BN) * kGldsRowBytes >= TG::BM * (TG::BN + 8) * 2, "epilogue tile fits");
       if (hipFuncSetAttribute((const void*)k_dgrad_glds_bf16<TG>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1584,7 +1600,7 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
         return set_error("cannot reserve %zu bytes of LDS for k_dgrad_glds_bf16", lds);
       PROFB(name);
       hipLaunchKernelGGL(k_dgrad_glds_bf16<TG>, grid, dim3(TG::THREADS), lds, st, (const bf16_t*)gz, WbT, out, ga_,
-                         wu_, (int)rows, s->Hd, wl.ldWT, j_begin, ncols, gparts);
+                         wu_, (int)rows, s->Hd, wl.ldWT, j_begin, ncols, gparts, rpw, col_tiles);
     } else {
       const dim3 grid(cdivb(ncols, TF::BN), cdivb(rows, TF::BM));
       const size_t lds = sizeof(bf16_t) * (size_t)(TF::BM + TF::BN) * (TF::BK + 8);
