@@ -15,7 +15,8 @@ import sys
 def classify(name, seq):
     n = name
     if "k_dgrad_glds_bf16" in n or "k_dgrad_bf16" in n:
-        return "k_dgrad_m_bf16" if ("ELi192E" in n or ", 192," in n) else "k_dgrad_x_bf16"
+        # memory columns: 64 x 192 tiles; input columns: 256 x 192 (LDS-DMA form) or 128 x 128 (fallback)
+        return "k_dgrad_m_bf16" if ("ILi64ELi192E" in n or "<64, 192," in n) else "k_dgrad_x_bf16"
     if "k_dgrad" in n:  # fp32: one kernel, launched for gm then for gx
         seq["dgrad"] += 1
         return "k_dgrad_m" if seq["dgrad"] % 2 == 1 else "k_dgrad_x"
