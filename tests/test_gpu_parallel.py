@@ -172,3 +172,53 @@ def test_distributed_data_parallel_wrapper_one_rank(nccl_one_rank):
     for l, r in zip(layers, ref):
         for (n, p), q in zip(l.named_parameters(), r.parameters()):
             _close(p.grad, q.grad, n, rtol=1e-4)
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_graph_with_captured_exchange_matches_eager(nccl_one_rank, overlap):
+    """capture_graph_exchange: the whole step and its RCCL all-reduces in one HIP graph (one-rank group, so the
+    exchange changes nothing): replays reproduce the eager step's gradients bit for bit, twice in a row."""
+    from asr_amd import LMUFFT
+    from asr_amd.parallel import GradBuckets
+
+    dev = nccl_one_rank
+    torch.manual_seed(5)
+    layers = [LMUFFT(64, 64, 32, 50, 40.0).to(dev) for _ in range(3)]
+    buckets = GradBuckets(list(reversed(layers)), overlap=overlap, exchange_single_rank=True)
+    x = torch.randn(4, 50, 64, device=dev).bfloat16().requires_grad_(True)
+    gy = torch.randn(4, 50, 64, device=dev).bfloat16()
+    st = {}
+
+    def seg_first():
+        ins, outs = [], []
+        y = x
+        for i, l in enumerate(layers):
+            xin = y if i == 0 else y.detach().requires_grad_(True)
+            y, _ = l(xin)
+            ins.append(xin)
+            outs.append(y)
+        st["ins"], st["outs"] = ins, outs
+        outs[-1].backward(gy)
+
+    def seg_back(k):
+        return lambda: st["outs"][k].backward(st["ins"][k + 1].grad)
+
+    segments = [seg_first] + [seg_back(k) for k in range(len(layers) - 2, -1, -1)]
+    for _ in range(2):
+        buckets.zero_grad()
+        x.grad = None
+        for s in segments:
+            s()
+        buckets.finish()
+    want = buckets.arena.clone()
+    gx = x.grad.clone()
+    st.clear()
+    x.grad = None
+    step = buckets.capture_graph_exchange(segments, overlap=overlap)
+    for _ in range(2):
+        buckets.arena.zero_()
+        step()
+        torch.cuda.synchronize()
+        assert torch.equal(buckets.arena, want)
+        assert torch.equal(x.grad, gx)
+    buckets.remove()
