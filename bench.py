@@ -549,11 +549,12 @@ def main():
         st.clear()
         x.grad = None
         try:
-            if buckets._distributed() and not args.host_exchange:
-                # the exchange captured inside the step's graph; if RCCL refuses the capture, launch it from the host
+            if not args.host_exchange:
+                # one graph for the whole step, the exchange (if there is a process group) captured inside it; if
+                # RCCL refuses the capture, the segments become graphs of their own and the host launches it
                 try:
                     step = buckets.capture_graph_exchange(segments, overlap=overlap)
-                    launch_mode = "one hip graph, all-reduces captured inside it"
+                    launch_mode = "one hip graph" + (", all-reduces captured inside it" if buckets._distributed() else "")
                 except Exception as e:
                     print(f"[bench] capturing the all-reduces failed ({type(e).__name__}: {e}); launching them "
                           "from the host between segment graphs", file=sys.stderr)
