@@ -20,7 +20,7 @@ CONV_TOEPLITZ = 1
 CONV_FFT = 2
 CONV_SCAN = 3
 NOALLOC_SCRATCH_BYTES = 8 << 20
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 class Shape(ctypes.Structure):
@@ -113,6 +113,10 @@ def _load():
     lib.lmufft_conv_backward_bf16.argtypes = [sp, vp, vp, vp, vp, sz, vp]
     lib.lmufft_backward_bf16.restype = ci
     lib.lmufft_backward_bf16.argtypes = [sp] + [vp] * 16 + [ci, vp, sz, vp]
+    lib.lmufft_backward_data_bf16.restype = ci
+    lib.lmufft_backward_data_bf16.argtypes = [sp] + [vp] * 12 + [ci, vp, sz, vp]
+    lib.lmufft_backward_weights_bf16.restype = ci
+    lib.lmufft_backward_weights_bf16.argtypes = [sp] + [vp] * 6 + [vp, sz, vp]
     lib.lmufft_scan_chunk.restype = ctypes.c_int32
     lib.lmufft_scan_chunk.argtypes = []
     lib.lmufft_scanprep_bytes.restype = sz
@@ -223,6 +227,8 @@ EXPORTS = (
     "lmufft_forward_bf16",
     "lmufft_forward_ln_bf16",
     "lmufft_backward_bf16",
+    "lmufft_backward_data_bf16",
+    "lmufft_backward_weights_bf16",
     "lmufft_conv_forward_bf16",
     "lmufft_conv_backward_bf16",
     "lmufft_scan_chunk",

@@ -1528,20 +1528,26 @@ int lmufft_forward_ln_bf16(const lmufft_shape* s, const void* x, const float* w_
                            workspace_bytes, stream, LnEpilogue{gamma, beta, eps, y, y_dtype == LMUFFT_BF16});
 }
 
-int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u, const void* wprep,
-                         const void* hprep, const void* scanprep, const float* u, const void* m_, const void* h_,
-                         const void* gh_,
-                         const void* gh_n_, void* gx_, float* gw_u, float* gb_u, float* gW_h, float* gb_h,
-                         void* gm_, int conv_algo, void* workspace, size_t workspace_bytes, void* stream) {
+}  // extern "C"
+
+// parts: 1 = everything up to gx (leaves gz and ga in the workspace), 2 = the parameter gradients from
+// the workspace's gz and ga, 3 = both
+static int backward_bf16_parts(int parts, const lmufft_shape* s, const void* x_, const float* w_u, const void* wprep,
+                               const void* hprep, const void* scanprep, const float* u, const void* m_,
+                               const void* h_, const void* gh_, const void* gh_n_, void* gx_, float* gw_u,
+                               float* gb_u, float* gW_h, float* gb_h, void* gm_, int conv_algo, void* workspace,
+                               size_t workspace_bytes, void* stream) {
   if (int rc = check_shape_b(s)) return rc;
-  if (!x_ || !w_u || !wprep || !hprep || !u || !m_ || !h_ || !gw_u || !gb_u || !gW_h || !gb_h || !gm_)
-    return set_error("backward: NULL pointer");
+  if (!x_ || !m_) return set_error("backward: NULL pointer");
+  if ((parts & 1) && (!w_u || !wprep || !hprep || !u || !h_ || !gm_)) return set_error("backward: NULL pointer");
+  if ((parts & 2) && (!gw_u || !gb_u || !gW_h || !gb_h)) return set_error("backward: NULL pointer");
   bool scan = false;
-  if (int rc = use_scan_route(conv_algo, scanprep, &scan)) return rc;
+  if (parts & 1)
+    if (int rc = use_scan_route(conv_algo, scanprep, &scan)) return rc;
   const BwdPlanB p = plan_backward_b(*s);
   if (!workspace || workspace_bytes < p.total)
     return set_error("backward: workspace of %zu bytes needed, %zu given", p.total, workspace_bytes);
-  if (!al16(workspace) || !al16(hprep) || !al16(wprep))
+  if (!al16(workspace) || ((parts & 1) && (!al16(hprep) || !al16(wprep))))
     return set_error("backward: workspace/hprep/wprep must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const bf16_t* x = (const bf16_t*)x_;
@@ -1553,18 +1559,19 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
   bf16_t* gm = (bf16_t*)gm_;
   char* ws = (char*)workspace;
   const WprepLayout wl = wprep_layout(*s);
-  const bf16_t* WbT = (const bf16_t*)((const char*)wprep + wl.off_WbT);
+  const bf16_t* WbT = wprep ? (const bf16_t*)((const char*)wprep + wl.off_WbT) : nullptr;
   float* wslab = (float*)(ws + p.off_wslab);
   float* gupart = (float*)(ws + p.off_gupart);
   float* ga = (float*)(ws + p.off_ga);
   const long rows = (long)s->B * s->T;
   const int MD = s->M + s->D;
   const HprepLayout hl = hprep_layout(s->M, s->ldH);
-  const bf16_t* HbT = (const bf16_t*)((const char*)hprep + hl.off_HbT);
+  const bf16_t* HbT = hprep ? (const bf16_t*)((const char*)hprep + hl.off_HbT) : nullptr;
   bf16_t* gz = (bf16_t*)(ws + p.off_gz);
   const bool vec_h = (s->Hd % 8 == 0) && (s->Hd / 8 <= kThreads) && al16(h) && (!gh || al16(gh)) &&
                      (!gh_n || al16(gh_n));
 
+  if (parts & 1) {
   {  // gz = relu'(h) * (gh + gh_n)
     const long work = vec_h ? rows * (s->Hd / 8) : rows * s->Hd;
     const dim3 grid(std::min<long>((work + kThreads - 1) / kThreads, 8192));
@@ -1625,10 +1632,14 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
     return rc;
   }
   // gx = gz W_h[:, M:] + ga w_u
-  if (gx)
+  if (gx) {
     if (int rc = dgrad(DgradXGldsTile{}, DgradXTileB{}, "k_dgrad_x_bf16", gx, s->M, s->D, (const float*)ga, w_u, ga_parts))
       return rc;
-  {  // gW_h, gb_h, gw_u, gb_u
+  } else if (ga_parts.part) {  // no input gradient wanted: nobody has summed the adjoint's slabs into ga yet
+    if (int rc = launch_sum_slabs_masked(ga_parts.part, u, ga, rows, ga_parts.P, st)) return rc;
+  }
+  }  // parts & 1
+  if (parts & 2) {  // gW_h, gb_h, gw_u, gb_u
     using TL = WgradTileB;
     const bool vec = (s->Hd % 8 == 0) && (s->M % 8 == 0) && (s->D % 8 == 0) && al16(m) && al16(x);
     const dim3 grid(xcd_grid(p.S, cdivb(MD, TL::BN) * cdivb(s->Hd, TL::BM)));
@@ -1650,6 +1661,31 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x_, const float* w_u
     if (int rc = launch_reduce_slabs(wslab, p.S, wgrad_outputs(*s, gW_h, gb_h, gw_u, gb_u), st)) return rc;
   }
   return 0;
+}
+
+extern "C" {
+
+int lmufft_backward_bf16(const lmufft_shape* s, const void* x, const float* w_u, const void* wprep,
+                         const void* hprep, const void* scanprep, const float* u, const void* m, const void* h,
+                         const void* gh, const void* gh_n, void* gx, float* gw_u, float* gb_u, float* gW_h,
+                         float* gb_h, void* gm, int conv_algo, void* workspace, size_t workspace_bytes, void* stream) {
+  return backward_bf16_parts(3, s, x, w_u, wprep, hprep, scanprep, u, m, h, gh, gh_n, gx, gw_u, gb_u, gW_h, gb_h, gm,
+                             conv_algo, workspace, workspace_bytes, stream);
+}
+
+int lmufft_backward_data_bf16(const lmufft_shape* s, const void* x, const float* w_u, const void* wprep,
+                              const void* hprep, const void* scanprep, const float* u, const void* m, const void* h,
+                              const void* gh, const void* gh_n, void* gx, void* gm, int conv_algo, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  return backward_bf16_parts(1, s, x, w_u, wprep, hprep, scanprep, u, m, h, gh, gh_n, gx, nullptr, nullptr, nullptr,
+                             nullptr, gm, conv_algo, workspace, workspace_bytes, stream);
+}
+
+int lmufft_backward_weights_bf16(const lmufft_shape* s, const void* x, const void* m, float* gw_u, float* gb_u,
+                                 float* gW_h, float* gb_h, void* workspace, size_t workspace_bytes, void* stream) {
+  return backward_bf16_parts(2, s, x, nullptr, nullptr, nullptr, nullptr, nullptr, m, nullptr, nullptr, nullptr,
+                             nullptr, gw_u, gb_u, gW_h, gb_h, nullptr, LMUFFT_CONV_AUTO, workspace, workspace_bytes,
+                             stream);
 }
 
 // Weight and bias gradient of a Linear layer, dW[out][in] = sum_rows dy[row][out] x[row][in], db[out] = sum_rows

@@ -106,6 +106,35 @@ def prepare_impulse_fft(H: torch.Tensor, T: int) -> torch.Tensor:
     return buf
 
 
+# Weight gradients running on the side stream: per device, (event recorded after them, tensors they read or
+# write -- kept alive until the join).  See _LMUFFTFunction.backward and join_async_weight_grads.
+_ASYNC_WGRAD = {}
+_WGRAD_STREAMS = {}
+
+
+def _wgrad_stream(device):
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    st = _WGRAD_STREAMS.get(key)
+    if st is None:
+        st = _WGRAD_STREAMS[key] = torch.cuda.Stream(device)
+    return st
+
+
+def join_async_weight_grads(device=None) -> None:
+    """Make the current stream of `device` (default: every device with work outstanding) wait for the weight
+    gradients that layers with `async_weight_grad` launched on the side stream.  GradBuckets calls this before it
+    exchanges or hands out gradients; call it yourself before reading `.grad` of such a layer otherwise."""
+    for key in list(_ASYNC_WGRAD):
+        if device is not None:
+            dkey = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+            if key != dkey:
+                continue
+        pending = _ASYNC_WGRAD.pop(key)
+        cur = torch.cuda.current_stream(torch.device(*key))
+        for done, _keep in pending:
+            cur.wait_event(done)
+
+
 class GradSink:
     """Destination of one layer's parameter gradients inside a flat exchange buffer.
 
@@ -136,7 +165,8 @@ class _LMUFFTFunction(torch.autograd.Function):
     """(x, w_u, b_u, W_h, b_h, H) -> (h, h_n); reference: src/lmu.py:290-320."""
 
     @staticmethod
-    def forward(ctx, x, w_u, b_u, W_h, b_h, H, conv_algo, hprep, fftprep, grad_sink, scanprep=None):
+    def forward(ctx, x, w_u, b_u, W_h, b_h, H, conv_algo, hprep, fftprep, grad_sink, scanprep=None,
+                async_wgrad=False):
         _require_gpu(x, "x")
         if x.dtype not in _DTYPES:
             raise RuntimeError(f"LMUFFT: x has dtype {x.dtype}; supported: float32, bfloat16")
@@ -197,6 +227,7 @@ class _LMUFFTFunction(torch.autograd.Function):
         ctx.save_for_backward(x, w_u, W_h, H, u, m, h, hprep, wprep if dt != torch.float32 else None,
                               fftprep if dt == torch.float32 else None, scanprep if dt != torch.float32 else None)
         ctx.conv_algo = conv_algo
+        ctx.async_wgrad = bool(async_wgrad)
         ctx.grad_sink = grad_sink
         ctx.shape = (B, T, D, M, Hd, ldH)
         ctx.set_materialize_grads(False)
@@ -210,7 +241,7 @@ class _LMUFFTFunction(torch.autograd.Function):
         dt = x.dtype
         need_x = ctx.needs_input_grad[0]
         if gh is None and gh_n is None:
-            return (None,) * 11
+            return (None,) * 12
         if gh is not None:
             gh = gh.to(dt).contiguous()
         if gh_n is not None:
@@ -237,6 +268,27 @@ class _LMUFFTFunction(torch.autograd.Function):
                     _ptr(h), _ptr(gh), _ptr(gh_n), _ptr(gx), _ptr(gw_u), _ptr(gb_u), _ptr(gW_h), _ptr(gb_h),
                     _ptr(gm), ctx.conv_algo, _ptr(ws), ws.numel(), _stream(dev))
                 what = "lmufft_backward_f32"
+            elif ctx.async_wgrad and direct:
+                # The parameter gradients depend on nothing after gx and nothing below this layer depends on
+                # them: they run on a side stream, beside the backward of the layers below, and are joined by
+                # whoever consumes the gradient bucket (join_async_weight_grads).  Only with a gradient sink:
+                # gradients handed back to autograd are accumulated on this stream at once.
+                rc = _lib.lib.lmufft_backward_data_bf16(
+                    ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(wprep), _ptr(hprep), _ptr(scanprep), _ptr(u), _ptr(m),
+                    _ptr(h), _ptr(gh), _ptr(gh_n), _ptr(gx), _ptr(gm), ctx.conv_algo, _ptr(ws), ws.numel(),
+                    _stream(dev))
+                _lib.check(rc, "lmufft_backward_data_bf16")
+                side = _wgrad_stream(dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    rc = _lib.lib.lmufft_backward_weights_bf16(
+                        ctypes.byref(shp), _ptr(x), _ptr(m), _ptr(gw_u), _ptr(gb_u), _ptr(gW_h), _ptr(gb_h), _ptr(ws),
+                        ws.numel(), _stream(dev))
+                    done = torch.cuda.Event()
+                    done.record(side)
+                key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+                _ASYNC_WGRAD.setdefault(key, []).append((done, (x, m, ws, gw_u, gb_u, gW_h, gb_h)))
+                what = "lmufft_backward_weights_bf16"
             else:
                 rc = _lib.lib.lmufft_backward_bf16(
                     ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(wprep), _ptr(hprep), _ptr(scanprep), _ptr(u), _ptr(m),
@@ -246,13 +298,14 @@ class _LMUFFTFunction(torch.autograd.Function):
         _lib.check(rc, what)
         if direct:
             sink.commit()
-            return (gx,) + (None,) * 10
+            return (gx,) + (None,) * 11
         pd = ctx.param_dtypes
-        return gx, gw_u.to(pd[0]), gb_u.to(pd[1]), gW_h.to(pd[2]), gb_h.to(pd[3]), None, None, None, None, None, None
+        return (gx, gw_u.to(pd[0]), gb_u.to(pd[1]), gW_h.to(pd[2]), gb_h.to(pd[3]), None, None, None, None, None, None,
+                None)
 
 
 def lmufft_layer(x, w_u, b_u, W_h, b_h, H, conv_algo="auto", hprep=None, fftprep=None, grad_sink=None,
-                 scanprep=None):
+                 scanprep=None, async_weight_grad=False):
     """h, h_n = LMUFFT forward with autograd support (HIP kernels only).
 
     x float32 -> exact-fp32 kernels; x bfloat16 -> bf16 kernels with fp32
@@ -262,8 +315,11 @@ def lmufft_layer(x, w_u, b_u, W_h, b_h, H, conv_algo="auto", hprep=None, fftprep
     `grad_sink` (a GradSink) receives the parameter gradients in place.
     `scanprep` = prepare_scan_bf16(A, B) makes the bf16 path take the state-space convolution route
     (conv_algo "auto" or "scan"; required for "scan").
+    `async_weight_grad` (bf16 path, with a grad_sink only): the parameter gradients are launched on a side stream
+    and joined by the sink's owner (join_async_weight_grads).
     """
-    return _LMUFFTFunction.apply(x, w_u, b_u, W_h, b_h, H, _ALGOS[conv_algo], hprep, fftprep, grad_sink, scanprep)
+    return _LMUFFTFunction.apply(x, w_u, b_u, W_h, b_h, H, _ALGOS[conv_algo], hprep, fftprep, grad_sink, scanprep,
+                                 async_weight_grad)
 
 
 def lmufft_layer_norm_inference(x, w_u, b_u, W_h, b_h, H, ln_weight, ln_bias, eps=1e-5, out_dtype=torch.float32,

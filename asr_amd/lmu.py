@@ -112,6 +112,9 @@ class LMUFFT(nn.Module):
         self._hprep = None  # (key, bf16 copies of H), rebuilt when H changes
         self._fftprep = {}  # T -> (key, spectra of H[:, :T]) for the FFT route
         self.grad_sink = None  # set by asr_amd.parallel.GradBuckets: gradients land in its flat buffer
+        # bf16 path, with a grad_sink: run the parameter gradients on a side stream, beside the backward of the
+        # layers below (GradBuckets joins them before it exchanges or hands out gradients)
+        self.async_weight_grad = False
 
     _FFTPREP_MAX = 8  # cached FFT-route spectra (one per distinct sequence length)
 
@@ -187,7 +190,8 @@ class LMUFFT(nn.Module):
                 fftprep = self._impulse_fft(T)
         return lmufft_layer(x, self.W_u.weight, self.W_u.bias, self.W_h.weight, self.W_h.bias, self.H,
                             conv_algo=self.conv_algo, hprep=hprep, fftprep=fftprep,
-                            grad_sink=self.grad_sink, scanprep=scanprep)
+                            grad_sink=self.grad_sink, scanprep=scanprep,
+                            async_weight_grad=self.async_weight_grad)
 
 
     # hidden sizes whose rows fit one projection tile: the layer norm can ride on the projection kernel

@@ -258,7 +258,15 @@ class GradBuckets:
     def _launch(self, bi: int) -> None:
         self._launched[bi] = True
         if self._distributed():
+            self._join_side_streams()
             self._all_reduce(self.buckets[bi])
+
+    @staticmethod
+    def _join_side_streams() -> None:
+        # weight gradients that layers with `async_weight_grad` run on a side stream write into the buckets
+        from .functional import join_async_weight_grads
+
+        join_async_weight_grads()
 
     # -- step protocol ----------------------------------------------------------------------
     @contextlib.contextmanager
@@ -288,6 +296,7 @@ class GradBuckets:
 
     def finish(self) -> None:
         """Launch what has not been launched, wait for the all-reduces, turn sums into means."""
+        self._join_side_streams()
         if not self._replay:
             missing = [bi for bi in range(len(self.buckets)) if self._pending[bi] > 0]
             if missing:
@@ -325,6 +334,7 @@ class GradBuckets:
                 # every parameter enters the capture with `.grad = None` (capture_pipeline re-arms the
                 # step first), so the captured kernels overwrite the slices and a replay needs no clearing
                 fn()
+                self._join_side_streams()  # a segment graph ends with every stream it forked joined
         finally:
             self._capturing = False
         return graph, list(self._ready_log)

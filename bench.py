@@ -74,6 +74,8 @@ def parse_args():
     ap.add_argument("--host-exchange", action="store_true",
                     help="launch the all-reduces from the host between segment graphs instead of capturing them in the "
                          "step's graph")
+    ap.add_argument("--async-wgrad", action="store_true",
+                    help="run every layer's parameter gradients on a side stream, beside the backward of the layers below")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying HIP graphs")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -491,6 +493,7 @@ def main():
         torch.nn.init.xavier_uniform_(l.W_h.weight)
         torch.nn.init.zeros_(l.W_u.bias)
         torch.nn.init.zeros_(l.W_h.bias)
+        l.async_weight_grad = bool(args.async_wgrad)
         layers.append(l.to(dev))
     overlap = args.overlap and not args.no_overlap
     buckets = GradBuckets(list(reversed(layers)), bucket_mb=args.bucket_mb, overlap=overlap,

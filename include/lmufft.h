@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMUFFT_ABI_VERSION 16
+#define LMUFFT_ABI_VERSION 17
 
 /* element types of the activations (x, h, gh, gx, m) */
 #define LMUFFT_F32 0
@@ -230,6 +230,24 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x, const float* w_u,
                          const void* gh_n, void* gx, float* gw_u, float* gb_u,
                          float* gW_h, float* gb_h, void* gm, int conv_algo,
                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* The bf16 backward in two calls, for callers that run the parameter gradients on another stream than the
+ * rest (they depend on nothing after the input gradient, so they can run beside whatever consumes gx):
+ *   lmufft_backward_data_bf16    everything of lmufft_backward_bf16 up to gx and gm; leaves the masked
+ *                                upstream gradient and the encoder-activation gradient in `workspace`;
+ *   lmufft_backward_weights_bf16 gw_u, gb_u, gW_h, gb_h from x, m and that SAME workspace, untouched in
+ *                                between; the caller orders it after the data call (an event, if it
+ *                                runs on another stream) and keeps x, m and the workspace alive until
+ *                                it has finished.
+ * lmufft_backward_bf16 is the two back to back on one stream. */
+int lmufft_backward_data_bf16(const lmufft_shape* s, const void* x, const float* w_u,
+                              const void* wprep, const void* hprep, const void* scanprep,
+                              const float* u, const void* m, const void* h, const void* gh,
+                              const void* gh_n, void* gx, void* gm, int conv_algo, void* workspace,
+                              size_t workspace_bytes, void* stream);
+int lmufft_backward_weights_bf16(const lmufft_shape* s, const void* x, const void* m, float* gw_u,
+                                 float* gb_u, float* gW_h, float* gb_h, void* workspace,
+                                 size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Log-mel frontend.  Replaces AudioPreprocessor.extract_mel_features and

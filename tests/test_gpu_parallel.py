@@ -222,3 +222,60 @@ def test_graph_with_captured_exchange_matches_eager(nccl_one_rank, overlap):
         assert torch.equal(buckets.arena, want)
         assert torch.equal(x.grad, gx)
     buckets.remove()
+
+
+def test_async_weight_grad_matches_synchronous():
+    """Layers with `async_weight_grad` run their parameter gradients on a side stream (C ABI
+    lmufft_backward_data_bf16 + lmufft_backward_weights_bf16); GradBuckets joins them.  Eager steps and a
+    replayed one-graph step give the synchronous step's gradients bit for bit."""
+    from asr_amd import LMUFFT
+    from asr_amd.parallel import GradBuckets
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(9)
+    layers = [LMUFFT(64, 64, 32, 80, 40.0).to(dev) for _ in range(3)]
+    buckets = GradBuckets(list(reversed(layers)), overlap=False)
+    x = torch.randn(6, 80, 64, device=dev).bfloat16().requires_grad_(True)
+    gy = torch.randn(6, 80, 64, device=dev).bfloat16()
+    st = {}
+
+    def seg_first():
+        ins, outs = [], []
+        y = x
+        for i, l in enumerate(layers):
+            xin = y if i == 0 else y.detach().requires_grad_(True)
+            y, _ = l(xin)
+            ins.append(xin)
+            outs.append(y)
+        st["ins"], st["outs"] = ins, outs
+        outs[-1].backward(gy)
+
+    def seg_back(k):
+        return lambda: st["outs"][k].backward(st["ins"][k + 1].grad)
+
+    segments = [seg_first] + [seg_back(k) for k in range(len(layers) - 2, -1, -1)]
+
+    def eager():
+        buckets.zero_grad()
+        x.grad = None
+        for s in segments:
+            s()
+        buckets.finish()
+        torch.cuda.synchronize()
+        return buckets.arena.clone(), x.grad.clone()
+
+    want, gx = eager()
+    for l in layers:
+        l.async_weight_grad = True
+    for _ in range(2):
+        got, gx2 = eager()
+        assert torch.equal(got, want) and torch.equal(gx2, gx)
+    st.clear()
+    x.grad = None
+    step = buckets.capture_graph_exchange(segments, overlap=False)
+    for _ in range(2):
+        buckets.arena.zero_()
+        step()
+        torch.cuda.synchronize()
+        assert torch.equal(buckets.arena, want) and torch.equal(x.grad, gx)
+    buckets.remove()
