@@ -167,3 +167,16 @@ def test_fft_adjoint_equals_direct_adjoint():
     d, f = orc.lmufft_backward(*args), orc.lmufft_backward(*args, conv="fft")
     for k in ("gx", "gw_u", "gb_u", "gW_h", "gb_h", "h"):
         np.testing.assert_allclose(d[k], f[k], rtol=1e-8, atol=1e-10, err_msg=k)
+
+
+def test_long_sequence_matches_reference(golden_dir):
+    """The reference's LMUFFT at 2048 frames (tests/golden/make_golden_long.py): the oracle's FFT form -- the one
+    the long-sequence GPU tests use -- against the reference's own outputs and autograd gradients."""
+    g = _load(golden_dir, "long2048_f32")
+    out = orc.lmufft_backward(g["x"], g["w_u"], g["b_u"], g["W_h"], g["b_h"], g["H"], g["gh"], None, conv="fft")
+    np.testing.assert_allclose(out["h"], g["h"], rtol=1e-4, atol=2e-5 * float(np.abs(g["h"]).max()))
+    np.testing.assert_allclose(out["h"][:, -1, :], g["h_n"], rtol=1e-4, atol=2e-5 * float(np.abs(g["h"]).max()))
+    for k in ("gx", "gw_u", "gb_u", "gW_h", "gb_h"):
+        ref = g[k]
+        # the reference ran in fp32: its own round-off on sums of 4096 terms is what separates the two
+        np.testing.assert_allclose(out[k], ref, rtol=2e-4, atol=1e-4 * max(1.0, float(np.abs(ref).max())), err_msg=k)
