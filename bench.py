@@ -395,6 +395,26 @@ def bench_full_step(args, dev, rank, world):
         return None
     hip_ms = sum(v["total_ms_per_step"] for v in per_kernel.values())
     first, last = float(losses[0].detach()), float(losses[-1].detach())
+    # roofline of the entry with the largest share of the step (event-bracketed entry points; "k_attention_bwd" is
+    # the two backward sweeps of one attention layer together).  Algorithmic work per launch at this shape:
+    heads, dk, C = 6, args.hidden // 6, args.hidden
+    attn_fwd_flops = 4.0 * B * heads * T * T * dk          # scores and context
+    rows = B * T
+    work = {
+        "k_attention_bwd": (2.5 * attn_fwd_flops, rows * C * 2 * 8),         # q k v ctx dctx in, dq dk dv out
+        "k_attention_fwd_train": (attn_fwd_flops, rows * C * 2 * 4),
+        "k_linear_wgrad_bf16": (2.0 * rows * C * C, rows * C * 2 * 2 + C * C * 4),
+        "k_wgrad_bf16": kernel_work("k_wgrad_bf16", B, T, C, args.memory, C, 2),
+        "k_linear_ws_bf16": (2.0 * rows * C * C, rows * C * 2 * 2 + C * C * 2),
+        "k_layernorm_bwd": (10.0 * rows * C, rows * C * (4 + 4 + 2 + 4)),
+    }
+    roofline = None
+    if per_kernel:
+        dom = max(per_kernel, key=lambda k: per_kernel[k]["total_ms_per_step"])
+        if dom in work:
+            roofline = roofline_of(dom, per_kernel, work[dom], "bf16", 1.0)
+            roofline["note"] = ("algorithmic work of one launch of the entry point at this shape; the Linear entries "
+                                "are priced at the 384 -> 384 layer")
     return {
         "metric": "full train step frames/sec (whole model, hot path swapped in)",
         "value": world * B * T / (elapsed / args.steps), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -409,7 +429,7 @@ def bench_full_step(args, dev, rank, world):
                    "torch_ops": "log-softmax, loss mean, input cast",
                    "activation_stream": "bf16 between blocks" if args.bf16_stream else "fp32 between blocks (autocast)",
                    "gradient_buckets": len(buckets.buckets)},
-        "roofline": None,
+        "roofline": roofline,
         "hip_kernel_ms_per_step": hip_ms,
         "loss_first_last": [first, last],
         "kernels": per_kernel,
