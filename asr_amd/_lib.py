@@ -20,7 +20,7 @@ CONV_TOEPLITZ = 1
 CONV_FFT = 2
 CONV_SCAN = 3
 NOALLOC_SCRATCH_BYTES = 8 << 20
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 
 class Shape(ctypes.Structure):
@@ -144,6 +144,8 @@ def _load():
     lib.lmufft_layernorm_dropout_bwd.restype = ci
     lib.lmufft_layernorm_dropout_bwd.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, vp, f32, i64, i32, f32, u32, u32, vp, vp,
                                                  vp, vp, vp, sz, vp]
+    lib.lmufft_dropout_epoch.restype = ci
+    lib.lmufft_dropout_epoch.argtypes = [vp]
     lib.lmufft_linear_wprep_bf16.restype = ci
     lib.lmufft_linear_wprep_bf16.argtypes = [vp, vp, i32, i32, i32, vp, vp, i64, vp, vp]
     lib.lmufft_linear_wgrad_workspace_bytes.restype = sz
@@ -207,6 +209,7 @@ EXPORTS = (
     "lmufft_layernorm_bwd",
     "lmufft_add_layernorm_dropout",
     "lmufft_layernorm_dropout_bwd",
+    "lmufft_dropout_epoch",
     "lmufft_linear_bf16",
     "lmufft_linear_ln_bf16",
     "lmufft_linear_wprep_bf16",

@@ -13,6 +13,7 @@ from typing import Optional
 import torch
 
 from . import _lib
+from .dropout import check_capturable
 
 _DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
 SUPPORTED_HEAD_WIDTHS = (32, 64, 128)
@@ -177,7 +178,9 @@ def masked_attention_train(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, nu
     """masked_attention with autograd and dropout on the attention weights (what MultiHeadAttention.forward does
     in training, src/models/lmu_encoder.py:72-90).  `seeds` = (seed0, seed1), two 32-bit integers naming the
     dropout mask of this call; by default torch's seed and a per-process call counter, so runs that start from
-    the same torch.manual_seed and make the same calls draw the same masks."""
+    the same torch.manual_seed and make the same calls draw the same masks.  Under HIP graph capture the seeds are
+    frozen into the graph; the library adds the device's dropout epoch counter to them at run time
+    (asr_amd.dropout), which the captured step increments -- without a registered counter such a capture raises."""
     global _dropout_calls
     for name, t in (("q", q), ("k", k), ("v", v)):
         if not t.is_cuda:
@@ -197,6 +200,7 @@ def masked_attention_train(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, nu
         raise ValueError(f"dropout probability has to be in [0, 1), got {p_drop}")
     if lengths is not None:
         lengths = lengths.to(device=q.device, dtype=torch.int32).contiguous()
+    check_capturable(q.device, p_drop, seeds is not None)
     if seeds is None:
         _dropout_calls += 1
         seeds = (torch.initial_seed() & 0xFFFFFFFF, _dropout_calls & 0xFFFFFFFF)
@@ -225,6 +229,7 @@ def masked_attention_train_packed(qkv: torch.Tensor, num_heads: int, lengths: Op
         raise ValueError(f"dropout probability has to be in [0, 1), got {p_drop}")
     if lengths is not None:
         lengths = lengths.to(device=qkv.device, dtype=torch.int32).contiguous()
+    check_capturable(qkv.device, p_drop, seeds is not None)
     if seeds is None:
         _dropout_calls += 1
         seeds = (torch.initial_seed() & 0xFFFFFFFF, _dropout_calls & 0xFFFFFFFF)

@@ -53,6 +53,7 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? (TRAIN ? 2 : 4) : 1) void k_att
                                                                 TIO* __restrict__ ctx, int T, int H, int ld,
                                                                 float scale, AttnDropout dr = AttnDropout{0, 0, 0, 1.f},
                                                                 float* __restrict__ stats = nullptr) {
+  hash_resolve_epoch(dr);
   static_assert(DK % 32 == 0 && DK <= 128, "head width: 32, 64, 96 or 128");
   constexpr int KP = DK + 1;   // K tile pitch: lane = key, banks (key + d) distinct
   constexpr int VP = DK + 8;   // V tile pitch: lane = d, the two lane halves 4 rows apart land 32 banks apart
@@ -225,6 +226,7 @@ __global__ __launch_bounds__(64 * NW) void k_attention_bwd_dq(const TIO* __restr
                                                               const int* __restrict__ lengths, TIO* __restrict__ dq,
                                                               float* __restrict__ dsum, int T, int H, int ld, int ldg,
                                                               float scale, AttnDropout dr) {
+  hash_resolve_epoch(dr);
   constexpr int KP = DK + 1, DT = DK / 32, NS = DK / 2;
   __shared__ float Ks[kAttnKeys * KP];
   __shared__ float Vs[kAttnKeys * KP];
@@ -351,6 +353,7 @@ __global__ __launch_bounds__(64 * NW) void k_attention_bwd_dkv(const TIO* __rest
                                                                const int* __restrict__ lengths, TIO* __restrict__ dk,
                                                                TIO* __restrict__ dv, int T, int H, int ld, int ldg,
                                                                float scale, AttnDropout dr) {
+  hash_resolve_epoch(dr);
   constexpr int KP = DK + 1, DT = DK / 32, NS = DK / 2;
   __shared__ float Qs[kAttnKeys * KP];
   __shared__ float Gs[kAttnKeys * KP];  // dO tile
@@ -514,6 +517,7 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? (TRAIN ? 3 : 4) : 1) void k_att
                                                                      int ld, float scale,
                                                                      AttnDropout dr = AttnDropout{0, 0, 0, 1.f},
                                                                      float* __restrict__ stats = nullptr) {
+  hash_resolve_epoch(dr);
   static_assert(DK % 32 == 0 && DK <= 128, "head width: 32, 64, 96 or 128");
   constexpr int KP = DK + 8;          // K tile [key][d], 16-byte padded rows: conflict-free b128 fragments
   constexpr int NKT = 1;              // 32-key score tiles per round (2 was measured slower: 0.31 against 0.26 ms at
@@ -732,6 +736,7 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 2 : 1) void k_attention_bwd_dq_
                                                                    const int* __restrict__ lengths, attn_bf16* __restrict__ dq,
                                                                    float* __restrict__ dsum, int T, int H, int ld, int ldg,
                                                                    float scale, AttnDropout dr) {
+  hash_resolve_epoch(dr);
   constexpr int KP = DK + 8, VP = DK <= 96 ? 96 : 160, DT = DK / 32, NS = DK / 16, OP = DK + 1;
   __shared__ __attribute__((aligned(16))) attn_bf16 Ks[32 * KP];
   __shared__ __attribute__((aligned(16))) attn_bf16 Vs[32 * KP];
@@ -881,6 +886,7 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 2 : 1) void k_attention_bwd_dkv
                                                                     const int* __restrict__ lengths, attn_bf16* __restrict__ dk,
                                                                     attn_bf16* __restrict__ dv, int T, int H, int ld, int ldg,
                                                                     float scale, AttnDropout dr) {
+  hash_resolve_epoch(dr);
   constexpr int KP = DK + 8, VP = DK <= 96 ? 96 : 160, DT = DK / 32, NS = DK / 16, OP = DK + 1;
   __shared__ __attribute__((aligned(16))) attn_bf16 Qs[32 * KP];
   __shared__ __attribute__((aligned(16))) attn_bf16 Gs[32 * KP];

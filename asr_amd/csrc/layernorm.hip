@@ -76,6 +76,7 @@ __global__ __launch_bounds__(kLnThreads) void k_add_layernorm(const void* x, con
                                                               const float* __restrict__ beta, float eps, long rows,
                                                               int C, void* out, HashDropout dr = HashDropout{0, 0, 0, 1.f},
                                                               void* twin = nullptr) {
+  hash_resolve_epoch(dr);
   const int sub = threadIdx.x & 31;                                  // lane inside the row's half-wave
   const long row0 = (long)blockIdx.x * (kLnThreads / 32) + (threadIdx.x >> 5);
   const long row_step = (long)gridDim.x * (kLnThreads / 32);
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(kLnThreads) void k_layernorm_bwd(const void* x, int
                                                               int gb, const float* __restrict__ gamma, float eps, long rows,
                                                               int C, void* dx, void* dres, float* __restrict__ partial,
                                                               HashDropout dr, const void* dy2, int g2b) {
+  hash_resolve_epoch(dr);
   extern __shared__ __attribute__((aligned(16))) float red[];  // [8 row slots][2][C]
   const int sub = threadIdx.x & 31, slot = threadIdx.x >> 5;
   const long row0 = (long)blockIdx.x * (kLnThreads / 32) + slot;
@@ -346,6 +348,25 @@ extern "C" int lmufft_add_layernorm(const void* x, int x_dtype, const void* res,
                                     void* stream) {
   return add_layernorm_any(x, x_dtype, res, res_dtype, gamma, beta, eps, rows, C, out, out_dtype,
                            make_hash_dropout(0.f, 0, 0), nullptr, stream);
+}
+
+// The registered dropout epoch counter of every device (lmufft_dropout_epoch).
+namespace lmufft {
+static const uint32_t* g_dropout_epoch[64] = {nullptr};
+const uint32_t* dropout_epoch_ptr() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  return g_dropout_epoch[dev];
+}
+}  // namespace lmufft
+
+extern "C" int lmufft_dropout_epoch(const uint32_t* epoch_dev) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return lmufft::set_error("dropout epoch: no current device");
+  if (dev < 0 || dev >= 64) return lmufft::set_error("dropout epoch: device index %d out of range", dev);
+  if (epoch_dev && (reinterpret_cast<uintptr_t>(epoch_dev) & 3)) return lmufft::set_error("dropout epoch: pointer must be 4-byte aligned");
+  lmufft::g_dropout_epoch[dev] = epoch_dev;
+  return 0;
 }
 
 extern "C" int lmufft_add_layernorm_dropout(const void* x, int x_dtype, const void* res, int res_dtype, const float* gamma,

@@ -79,9 +79,13 @@ int launch_sum_slabs_masked(const float* part, const float* u, float* out, long 
 //   keep <=> ((x >> 16 (col & 1)) & 0xFFFF) >= threshold,   threshold = round(p * 65536) in [1, 65535].
 // The row part (HashRow) is computed once per row, a hash costs an add, a xor and the finaliser, and serves two
 // elements.  The forward and the backward of a call recompute the same decisions.  threshold = 0: no dropout.
+// `epoch` (may be NULL) points at one 32-bit counter in device memory that is added to seed1 when the kernel RUNS:
+// a training step replayed from a HIP graph has its seeds frozen at capture, and draws fresh masks only because
+// the graph itself increments that counter (lmufft_dropout_epoch).
 struct HashDropout {
   uint32_t seed0, seed1, threshold;
   float inv_keep;  // 1 / (1 - p)
+  const uint32_t* epoch;
 };
 struct HashRow {
   uint32_t lo, c;  // lo32(g);  seed0 ^ ((hi32(g) + seed1) * 0x9E3779B1)
@@ -94,6 +98,11 @@ __device__ __forceinline__ uint32_t hash_fmix32(uint32_t x) {
   x ^= x >> 16;
   return x;
 }
+// First statement of every kernel that takes a HashDropout by value: folds the device-side epoch into seed1.
+__device__ __forceinline__ void hash_resolve_epoch(HashDropout& dr) {
+  if (dr.epoch) dr.seed1 += *dr.epoch;
+  dr.epoch = nullptr;
+}
 __device__ __forceinline__ HashRow hash_row(const HashDropout& dr, unsigned long long row, unsigned pairs_per_row) {
   const unsigned long long g = row * pairs_per_row;
   return HashRow{(uint32_t)g, dr.seed0 ^ (((uint32_t)(g >> 32) + dr.seed1) * 0x9E3779B1u)};
@@ -105,10 +114,12 @@ __device__ __forceinline__ bool hash_keep(const HashDropout& dr, const HashRow& 
   const uint32_t x = hash_pair(hr, col >> 1);
   return (col & 1) ? hash_keep_hi(dr, x) : hash_keep_lo(dr, x);
 }
+const uint32_t* dropout_epoch_ptr();  // the current device's counter, or NULL (lmufft_dropout_epoch; layernorm.hip)
 inline HashDropout make_hash_dropout(float p_drop, uint32_t seed0, uint32_t seed1) {
   HashDropout dr;
   dr.seed0 = seed0;
   dr.seed1 = seed1;
+  dr.epoch = p_drop > 0.f ? dropout_epoch_ptr() : nullptr;
   const double t = (double)p_drop * 65536.0 + 0.5;
   dr.threshold = p_drop > 0.f ? (uint32_t)(t < 1.0 ? 1.0 : (t > 65535.0 ? 65535.0 : t)) : 0u;
   dr.inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;

@@ -248,8 +248,13 @@ class _LMUFFTFunction(torch.autograd.Function):
             gh_n = gh_n.to(dt).contiguous()
         gx = torch.empty_like(x) if need_x else None
         sink = ctx.grad_sink
-        if sink is not None and sink.filled and sink.on_late is not None:
-            sink.on_late()  # raises when the bucket has already been handed to the all-reduce
+        if sink is not None and sink.filled:
+            if sink.on_late is not None:
+                sink.on_late()  # raises when the bucket has already been handed to the all-reduce
+            # A further backward of the same step: autograd will ADD the gradients returned below into
+            # `.grad` -- the sink's views -- on this stream.  If the first backward's weight gradient is
+            # still running on the side stream it is writing those same views: wait for it first.
+            join_async_weight_grads(dev)
         direct = sink is not None and sink.usable(ctx.needs_input_grad[1:5])
         if direct:
             gw_u, gb_u, gW_h, gb_h = sink.views

@@ -12,6 +12,7 @@ from typing import Optional
 import torch
 
 from . import _lib
+from .dropout import check_capturable
 from .parallel import adopt, grad_slot
 
 _DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
@@ -160,6 +161,7 @@ def add_layer_norm_train(x: torch.Tensor, residual: Optional[torch.Tensor], weig
     if out_dtype is None:
         out_dtype = torch.float32 if torch.is_autocast_enabled() else (
             x.dtype if residual is None else torch.promote_types(x.dtype, residual.dtype))
+    check_capturable(x.device, p_drop, seeds is not None)
     if seeds is None:
         if p_drop > 0:
             _dropout_calls += 1

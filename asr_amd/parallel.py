@@ -322,10 +322,23 @@ class GradBuckets:
         self._handles = []
 
     # -- HIP graph replay -------------------------------------------------------------------
-    def _capture(self, fn: Callable, pool=None):
+    def _dropout_epoch_bump(self):
+        """The first node of a captured step: increments the device's dropout epoch counter, so that every replay
+        draws fresh dropout masks (asr_amd.dropout).  Returns the callable to run inside the capture; the counter
+        itself is created here, outside it."""
+        from .dropout import bump_dropout_epoch, dropout_epoch
+
+        dev = self.buckets[0].device
+        if dev.type != "cuda":
+            return lambda: None
+        dropout_epoch(dev)
+        return lambda: bump_dropout_epoch(dev)
+
+    def _capture(self, fn: Callable, pool=None, first: bool = True):
         graph = torch.cuda.CUDAGraph()
         self._ready_log = []
         self._capturing = True
+        bump = self._dropout_epoch_bump() if first else (lambda: None)
         try:
             # thread_local: calls made meanwhile by other threads (e.g. the process group's
             # watchdog) neither break nor join the capture.  The segments share one memory pool:
@@ -333,6 +346,7 @@ class GradBuckets:
             with torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"):
                 # every parameter enters the capture with `.grad = None` (capture_pipeline re-arms the
                 # step first), so the captured kernels overwrite the slices and a replay needs no clearing
+                bump()
                 fn()
                 self._join_side_streams()  # a segment graph ends with every stream it forked joined
         finally:
@@ -359,7 +373,7 @@ class GradBuckets:
         self.zero_grad()
         graphs, ready = [], []
         for i, fn in enumerate(fns):
-            g, r = self._capture(fn, pool=graphs[0].pool() if graphs else None)
+            g, r = self._capture(fn, pool=graphs[0].pool() if graphs else None, first=not graphs)
             graphs.append(g)
             ready.append(r)
         done = sorted(bi for r in ready for bi in r)
@@ -393,13 +407,17 @@ class GradBuckets:
         the same collectives from the host between its segment graphs, which costs a short step more than the
         exchange can hide (three stacked layers, batch 64 x 400 frames, one rank with the RCCL path on: 0.392 ms
         without exchange, 0.474 ms with per-bucket host launches, 0.420 ms with one host launch per step).
-        Same preconditions as capture_pipeline.  Every rank must capture and replay the same sequence."""
+        Same preconditions as capture_pipeline.  Every rank must capture and replay the same sequence.
+        Dropout inside the step: its seeds are frozen at capture; the graph's first node increments the device's
+        dropout epoch counter, which the kernels add to the seeds when they run, so replays draw fresh masks."""
         self.zero_grad()
         graph = torch.cuda.CUDAGraph()
         saved = self.overlap
         self.overlap = overlap
+        bump = self._dropout_epoch_bump()
         try:
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                bump()
                 for fn in fns:
                     fn()
                 self.finish()  # launches what is left and waits: the waits become the graph's joins

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMUFFT_ABI_VERSION 17
+#define LMUFFT_ABI_VERSION 18
 
 /* element types of the activations (x, h, gh, gx, m) */
 #define LMUFFT_F32 0
@@ -352,6 +352,18 @@ int lmufft_layernorm_dropout_bwd(const void* x, int x_dtype, const void* res, in
                                  int64_t rows, int32_t C, float p_drop, uint32_t seed0, uint32_t seed1, void* dx,
                                  void* dres, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
                                  void* stream);
+
+/* ------------------------------------------------------------------------
+ * Dropout masks under HIP graph replay.  The reference draws a fresh mask at every call of nn.Dropout
+ * (src/models/lmu_encoder.py:45, 86, 232, 274-277); the seeds of lmufft_attention_fwd_train / lmufft_attention_bwd /
+ * lmufft_add_layernorm_dropout / lmufft_layernorm_dropout_bwd are by-value arguments, which a captured graph
+ * freezes.  lmufft_dropout_epoch registers, for the CURRENT device, one 32-bit counter in device memory (NULL
+ * unregisters): every dropout kernel launched on that device afterwards adds its value, read when the kernel runs,
+ * to seed1.  A step captured in a graph increments the counter inside the graph (any captured device-side add), so
+ * every replay draws new masks; the forward and the backward of one step read the same value.  The counter must stay
+ * allocated while such kernels can run.  No counterpart call in the reference.
+ * ---------------------------------------------------------------------- */
+int lmufft_dropout_epoch(const uint32_t* epoch_dev);
 
 /* ------------------------------------------------------------------------
  * Weight and bias gradient of a Linear layer under bf16 autocast (training).  Replaces what autograd runs

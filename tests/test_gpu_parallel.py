@@ -279,3 +279,36 @@ def test_async_weight_grad_matches_synchronous():
         torch.cuda.synchronize()
         assert torch.equal(buckets.arena, want) and torch.equal(x.grad, gx)
     buckets.remove()
+
+
+def test_async_weight_grad_with_accumulated_backwards():
+    """Two backwards in one step (gradient accumulation) on a layer with `async_weight_grad`: the first backward's
+    weight gradient runs on the side stream and writes the bucket; the second returns its gradients to autograd,
+    which adds them into the same memory on the main stream -- only after the side stream has been joined.  The
+    accumulated gradients equal the synchronous step's bit for bit, at a size where the side-stream kernel is
+    still running when the second backward starts."""
+    from asr_amd import LMUFFT
+    from asr_amd.parallel import GradBuckets
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(13)
+    layer = LMUFFT(384, 384, 192, 400, 1000.0).to(dev)
+    buckets = GradBuckets([layer], overlap=False)
+    xs = [torch.randn(32, 400, 384, device=dev).bfloat16() for _ in range(2)]
+    gys = [torch.randn(32, 400, 384, device=dev).bfloat16() for _ in range(2)]
+
+    def step():
+        buckets.zero_grad()
+        with buckets.accumulate():
+            for x, gy in zip(xs, gys):
+                y, _ = layer(x)
+                y.backward(gy)
+        buckets.finish()
+        torch.cuda.synchronize()
+        return buckets.arena.clone()
+
+    want = step()
+    layer.async_weight_grad = True
+    for _ in range(3):
+        assert torch.equal(step(), want)
+    buckets.remove()

@@ -148,14 +148,23 @@ def test_layer_scan_equals_toeplitz():
         h, h_n = lay(x)
         (h.float() * gh.float()).sum().backward()
         out[algo] = [h.float(), h_n.float(), x.grad.float()] + [p.grad.float() for p in lay.parameters()]
-    # Outputs agree to bf16 rounding noise.  The gradients additionally see the few hidden units whose
-    # pre-activation lies within that noise of zero and lands on the other side of relu on the other route
-    # (each moves a whole term of gx / gW_h), hence the wider bar here; tests/test_gpu_c4.py holds the route
-    # to the bf16 bar against the oracle evaluated on the kernels' own relu pattern.
-    for a, b, name in zip(out["scan"], out["toeplitz"], ("h", "h_n", "gx", "gw_u", "gb_u", "gW_h", "gb_h")):
+    # The outputs of the two routes agree to bf16 rounding noise.  Their gradients are NOT compared with each other:
+    # a few hidden units whose pre-activation lies within that noise of zero land on the other side of relu on the
+    # other route, and each moves a whole term of gx / gW_h.  Instead every route is held, at the bf16 bar, to the
+    # oracle evaluated on the bf16-rounded operands and on that route's own relu pattern.
+    from tests.test_gpu_bf16 import _bf, _close, _termnorms
+
+    for a, b, name in zip(out["scan"][:2], out["toeplitz"][:2], ("h", "h_n")):
         rms = b.pow(2).mean().sqrt()
-        bar = 2e-2 if name in ("h", "h_n") else 6e-2
-        assert (a - b).pow(2).mean().sqrt() <= bar * rms + 1e-6, (name, float((a - b).pow(2).mean().sqrt()), float(rms))
+        assert (a - b).pow(2).mean().sqrt() <= 2e-2 * rms + 1e-6, (name, float((a - b).pow(2).mean().sqrt()), float(rms))
+    npy = lambda t: t.detach().float().cpu().numpy()  # noqa: E731
+    for algo, lay in layers.items():
+        sd = {k: npy(v) for k, v in lay.state_dict().items() if k != "fft_H"}
+        ref = orc.lmufft_backward(npy(x0), sd["W_u.weight"], sd["W_u.bias"], _bf(sd["W_h.weight"]), sd["W_h.bias"],
+                                  _bf(sd["H"]), npy(gh), None, h_mask=npy(out[algo][0]) > 0, conv="fft")
+        tn = _termnorms(npy(x0), sd["W_u.weight"], sd["W_h.weight"], sd["H"], ref, conv="fft")
+        for got, name in zip(out[algo], ("h", "h_n", "gx", "gw_u", "gb_u", "gW_h", "gb_h")):
+            _close(npy(got).reshape(ref[name].shape), ref[name], f"{name} {algo}", tn[name])
     with pytest.raises(RuntimeError):
         layers["scan"](x0.float())
     lay = layers["scan"]
@@ -198,17 +207,53 @@ def test_long_sequence_layer_matches_reference_golden(golden_dir):
         ref = g[name].astype(np.float64)
         tol = 1e-4 * np.abs(ref) + 1e-5 * np.abs(ref).max() + 1e-6 * cond.get(name, 0.0)
         assert np.all(np.abs(got - ref) <= tol), (name, float(np.abs(got - ref).max()), float(np.abs(ref).max()))
-    # bf16, both routes
+    # bf16, both routes.  The chain that ties the kernels' numbers to the reference's at the stated rtol 2e-2:
+    #   (1) h against the golden itself;
+    #   (2) every gradient against the oracle evaluated on the bf16-rounded operands and on the KERNEL's ReLU
+    #       patterns (hidden units and encoder), at the bf16 bar -- the patterns agree by construction;
+    #   (3) the same against the oracle on the UN-rounded operands (the reference's arithmetic: the CPU suite holds
+    #       that evaluation, on the reference's own patterns, to long2048_f32.npz at the fp32 bar), again on the
+    #       kernel's patterns;
+    #   (4) the patterns themselves: they differ from the reference's only on a few per cent of the units, all of
+    #       them units whose pre-activation lies within bf16 rounding noise of zero;
+    #   (5) gx of the golden itself on the frames whose patterns agree in everything gx[b, t] depends on: the
+    #       encoder unit of the frame and the hidden units of the frame and of every LATER frame of the utterance
+    #       (the adjoint convolution carries those into ga[b, t]).
+    from tests.test_gpu_bf16 import _close, _termnorms
+
     A, Bm = legendre_state_space(M, float(theta))
     sp = prepare_scan_bf16(A, Bm, device=dev)
-    fwd = orc.lmufft_forward(orc.round_bf16(g["x"]), g["w_u"], g["b_u"], orc.round_bf16(g["W_h"]), g["b_h"], g["H"], conv="fft")
-    mx = np.concatenate([fwd["m"], orc.round_bf16(g["x"]).astype(np.float64)], axis=-1)
-    term_h = np.sqrt((mx ** 2) @ (orc.round_bf16(g["W_h"]).astype(np.float64) ** 2).T)
+    xb, Wb, Hb, ghb = orc.round_bf16(g["x"]), orc.round_bf16(g["W_h"]), orc.round_bf16(g["H"]), orc.round_bf16(g["gh"])
+    fwd = orc.lmufft_forward(xb, g["w_u"], g["b_u"], Wb, g["b_h"], g["H"], conv="fft")
+    mx = np.concatenate([fwd["m"], xb.astype(np.float64)], axis=-1)
+    term_h = np.sqrt((mx ** 2) @ (Wb.astype(np.float64) ** 2).T)
+    fwd0 = orc.lmufft_forward(g["x"], g["w_u"], g["b_u"], g["W_h"], g["b_h"], g["H"], conv="fft")  # the reference's patterns
+    z0 = fwd0["m"] @ g["W_h"][:, :M].T.astype(np.float64) + g["x"].astype(np.float64) @ g["W_h"][:, M:].T.astype(np.float64) + g["b_h"]
+    a0 = g["x"].astype(np.float64) @ g["w_u"].T.astype(np.float64)[:, 0] + float(g["b_u"][0])
+    term_a = np.sqrt((g["x"].astype(np.float64) ** 2) @ (g["w_u"].astype(np.float64) ** 2).T[:, 0])
     for algo, prep in (("scan", sp), ("toeplitz", None)):
         out = run(torch.bfloat16, algo, prep)
         ref_h = g["h"].astype(np.float64)
-        assert np.all(np.abs(out[0] - ref_h) <= 2e-2 * (np.abs(ref_h) + 2 * term_h)), (algo, "h")
-        for got, name in zip(out[2:], names):
-            ref = g[name].astype(np.float64)
-            rms = np.sqrt(((got - ref) ** 2).mean()) / np.sqrt((ref ** 2).mean())
-            assert rms <= 8e-2, (algo, name, float(rms))
+        assert np.all(np.abs(out[0] - ref_h) <= 2e-2 * (np.abs(ref_h) + 2 * term_h)), (algo, "h")          # (1)
+        h_mask = out[0] > 0
+        refk = orc.lmufft_backward(xb, g["w_u"], g["b_u"], Wb, g["b_h"], Hb, ghb, None, h_mask=h_mask, conv="fft")
+        tn = _termnorms(xb, g["w_u"], Wb, Hb, refk, conv="fft")
+        for got, name in zip(out[2:], names):                                                               # (2)
+            _close(got, refk[name], f"{name} long2048 {algo}", tn[name])
+        ref0 = orc.lmufft_backward(g["x"], g["w_u"], g["b_u"], g["W_h"], g["b_h"], g["H"], ghb, None, h_mask=h_mask,
+                                   u_mask=refk["u"] > 0, conv="fft")
+        for got, name in zip(out[2:], names):                                                               # (3)
+            _close(got, ref0[name], f"{name} long2048 {algo} vs un-rounded", tn[name])
+        hflip = h_mask != (z0 > 0)                                                                          # (4)
+        uflip = (refk["u"] > 0) != (a0 > 0)
+        assert hflip.mean() < 0.02 and uflip.mean() < 0.05, (algo, float(hflip.mean()), float(uflip.mean()))
+        assert np.all(np.abs(z0[hflip]) <= 4e-2 * term_h[hflip]) and np.all(np.abs(a0[uflip]) <= 4e-2 * term_a[uflip])
+        later = np.flip(np.maximum.accumulate(np.flip(hflip.any(axis=-1), axis=1), axis=1), axis=1)      # (5)
+        same = ~uflip & ~later
+        assert same.sum() >= 20, int(same.sum())
+        gx_ref = g["gx"].astype(np.float64)
+        err = np.abs(out[2] - gx_ref)[same]
+        bound = (2e-2 * (np.abs(gx_ref) + 2 * tn["gx"]))[same]
+        print(f"{algo}: {int(same.sum())} frames with the reference's patterns; worst err / bound {float((err / bound).max()):.2f}; "
+              f"hidden flips {float(hflip.mean()):.4f}, encoder flips {float(uflip.mean()):.4f}")
+        assert np.all(err <= bound), (algo, float((err / bound).max()))
