@@ -144,6 +144,8 @@ def _load():
     lib.lmufft_layernorm_dropout_bwd.restype = ci
     lib.lmufft_layernorm_dropout_bwd.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, vp, f32, i64, i32, f32, u32, u32, vp, vp,
                                                  vp, vp, vp, sz, vp]
+    lib.lmufft_backward_needs_gm_bf16.restype = ci
+    lib.lmufft_backward_needs_gm_bf16.argtypes = [sp, ci, ci]
     lib.lmufft_dropout_epoch.restype = ci
     lib.lmufft_dropout_epoch.argtypes = [vp]
     lib.lmufft_linear_wprep_bf16.restype = ci
@@ -229,6 +231,7 @@ EXPORTS = (
     "lmufft_wprep_bf16",
     "lmufft_forward_bf16",
     "lmufft_forward_ln_bf16",
+    "lmufft_backward_needs_gm_bf16",
     "lmufft_backward_bf16",
     "lmufft_backward_data_bf16",
     "lmufft_backward_weights_bf16",

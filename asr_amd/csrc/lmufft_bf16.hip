@@ -32,7 +32,7 @@ static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) 
 
 #ifdef LMUFFT_STAMPS
 // Debug build only (-DLMUFFT_STAMPS=<kernel id>: 1 weight gradient, 2 forward convolution,
-// 3 adjoint convolution, 4 projection):
+// 3 adjoint convolution, 4 projection, 5 encoder gradient from gz):
 // per-workgroup timestamps (100 MHz wall clock in slots 0..3, shader-clock sums in slots 4..7),
 // read back through lmufft_debug_stamps().
 __device__ long long g_stamps[8 * 4096];
@@ -513,6 +513,302 @@ __global__ __launch_bounds__(kThreads) void k_relu_bwd_bf16(const bf16_t* __rest
     }
   }
 }
+
+// ---------------------------------------------------------------------------
+// Encoder gradient straight from the masked upstream gradient ("Q route", T <= kGuQMaxT).
+// The reference's backward goes gz -> gm = gz W_h[:, :M] -> gu = adjoint convolution of gm with H
+// (autograd of src/lmu.py:303-316).  Both steps are linear, so they compose:
+//   gu[b][s] = sum_{t >= s} sum_n gz[b][t][n] Q[n][t - s],   Q[n][tau] = sum_k W_h[n][k] H[k][tau],
+// one GEMM of gz against the constant Q^T [T][Hd] followed by sums along the diagonals t - tau = s --
+// gm is never formed, written or read back (two kernels and ~65 MB of HBM traffic per layer at
+// batch 64 x 400 frames become one kernel reading gz).  Q is rounded to bf16 once per step, as W_h and H are
+// on the two-step route, where gm is rounded besides.
+//
+// k_relu_bwd_q_bf16: the gz pass; its first workgroups make Q^T on the matrix cores from the bf16 copies of
+// H^T (hprep) and W_h (wprep) -- 30 MFLOP that would otherwise be a launch of their own.
+// ---------------------------------------------------------------------------
+constexpr int kGuQMaxT = 512;
+using QPrepTile = TileB<64, 64, 64, 2, 2>;
+struct QPrep {
+  const bf16_t *HbT, *Wb;
+  bf16_t* QT;
+  int rowsQ, rowsHT, Hd, M, ldHT, ldW, ldQ;
+};
+
+__global__ __launch_bounds__(kThreads) void k_relu_bwd_q_bf16(const bf16_t* __restrict__ h,
+                                                              const bf16_t* __restrict__ gh,
+                                                              const bf16_t* __restrict__ gh_n,
+                                                              bf16_t* __restrict__ gz, int rows, int T, int Hd, QPrep q,
+                                                              int qblocks) {
+  __shared__ __attribute__((aligned(16))) bf16_t qsmem[2 * 64 * (64 + 8)];
+  if ((int)blockIdx.x < qblocks) {
+    using TL = QPrepTile;
+    const int tiles_n = (q.Hd + TL::BN - 1) / TL::BN;
+    const int tau0 = ((int)blockIdx.x / tiles_n) * TL::BM, n0 = ((int)blockIdx.x % tiles_n) * TL::BN;
+    auto la = plain_load_b([=](int r, int k) -> bf16x8 {
+      const int tau = tau0 + r;
+      return bload8<true>(q.HbT, (long)tau * q.ldHT + k, k, q.ldHT, tau < q.rowsHT);
+    });
+    auto lb = plain_load_b([=](int r, int k) -> bf16x8 {
+      const int n = n0 + r;
+      return bload8<true>(q.Wb, (long)n * q.ldW + k, k, q.M, n < q.Hd);
+    });
+    typedef LdsOperandKC<TL::BM, TL::BK, decltype(la)> OpA;
+    typedef LdsOperandKC<TL::BN, TL::BK, decltype(lb)> OpB;
+    static_assert(OpA::ELEMS + OpB::ELEMS == 2 * 64 * (64 + 8), "LDS carve");
+    OpA oa(qsmem, la);
+    OpB ob(qsmem + OpA::ELEMS, lb);
+    WavePos<TL> w;
+    f32x16 acc[TL::TM][TL::TN];
+    tileb_zero<TL>(acc);
+    gemm_loop_kc<TL>(oa, ob, acc, 0, q.M, w);
+    tileb_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
+      const int tau = tau0 + mm, n = n0 + nn;
+      if (tau < q.rowsQ && n < q.ldQ) q.QT[(long)tau * q.ldQ + n] = (bf16_t)(n < q.Hd ? v : 0.f);
+    });
+    return;
+  }
+  const unsigned CH = (unsigned)Hd / 8;  // 16-byte chunks per row
+  const long total = (long)rows * CH;
+  const long nb = (long)gridDim.x - qblocks;
+  for (long i = ((long)blockIdx.x - qblocks) * kThreads + threadIdx.x; i < total; i += nb * kThreads) {
+    const unsigned row = (unsigned)(i / CH), c = (unsigned)(i - (long)row * CH);
+    const long off = (long)row * Hd + c * 8;
+    const bf16x8 hv = *reinterpret_cast<const bf16x8*>(h + off);
+    bf16x8 g = gh ? *reinterpret_cast<const bf16x8*>(gh + off) : bzero8();
+    if (gh_n) {
+      const unsigned b = row / (unsigned)T;
+      if (row - b * (unsigned)T == (unsigned)(T - 1)) {
+        const bf16x8 gl = *reinterpret_cast<const bf16x8*>(gh_n + (long)b * Hd + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = (bf16_t)((float)g[j] + (float)gl[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = (float)hv[j] > 0.f ? g[j] : (bf16_t)0.f;
+    *reinterpret_cast<bf16x8*>(gz + off) = g;
+  }
+}
+
+// k_gu_q_bf16: workgroup = (utterance b, tile of 128 frames t -- right-aligned, so that the short tile is the
+// first one --, chunk c of 256 lags); P[i][tau] = sum_n gz[b][t0 + i][n] Q^T[tau][n] for the chunk's lags below
+// t0 + 128, then sums along the diagonals i - tau = s - t0.  A GEMM tile of 128 x 256 on eight waves (a wave owns 32
+// frames x 128 lags: four 32 x 32 accumulators), K = Hd in k-tiles of 32 through a three-stage LDS-DMA ring with
+// counted waits; column tiles past the causal limit are skipped.  74 KB of LDS: two workgroups share a CU, so the
+// 6 B (tile, chunk) pairs of batch 64 x 400 frames are all resident at once (with one 147 KB workgroup per CU and a
+// six-stage ring the long pairs ran no faster -- the kernel is bound by what the chip's CUs ingest together, about
+// 7.5 TB/s of L2 and HBM reads through the LDS-DMA path -- and the short pairs waited for a second round).
+// The diagonal sums happen in registers (sixteen lane rotations per 32 x 32 tile, see below); the waves' 63 sums
+// per tile meet in a small LDS array and are added in a fixed order into gu_part[slot][b][s], slot = the
+// (tile, chunk) pair's number inside the utterance; the input-gradient GEMM adds the slots.
+using GuQTile = TileB<128, 256, 32, 4, 2>;
+constexpr int kGuQStages = 3;
+
+constexpr int kGuQMaxSlots = 32;
+struct GuQPlan {  // the (tile, chunk) pairs of an utterance, longest first
+  int nslot;
+  unsigned char tile[kGuQMaxSlots], chunk[kGuQMaxSlots];
+};
+static GuQPlan guq_plan(int T) {
+  const int BM = GuQTile::BM, BN = GuQTile::BN, pad = (BM - T % BM) % BM;
+  GuQPlan p;
+  p.nslot = 0;
+  int work[kGuQMaxSlots];
+  for (int j = 0; j * BM - pad < T; ++j) {
+    const int t0 = j * BM - pad, tend = t0 + BM;
+    for (int c = 0; c * BN < tend && p.nslot < kGuQMaxSlots; ++c) {
+      int tiles = 0;  // 32 x 32 tiles with a causal pair
+      for (int rm = 0; rm < BM / 32; ++rm) {
+        const int lags = std::min(std::min(BN, tend - c * BN), t0 + 32 * rm + 32 - c * BN);
+        tiles += lags > 0 ? (lags + 31) / 32 : 0;
+      }
+      int k = p.nslot++;
+      while (k > 0 && work[k - 1] < tiles) {  // insertion sort, descending
+        work[k] = work[k - 1];
+        p.tile[k] = p.tile[k - 1];
+        p.chunk[k] = p.chunk[k - 1];
+        --k;
+      }
+      work[k] = tiles;
+      p.tile[k] = (unsigned char)j;
+      p.chunk[k] = (unsigned char)c;
+    }
+  }
+  return p;
+}
+
+__global__ __launch_bounds__(GuQTile::THREADS)
+void k_gu_q_bf16(const bf16_t* __restrict__ gz, const bf16_t* __restrict__ QT, float* __restrict__ part, int B, int T,
+                 int Hd, int ldQ, int rowsQ, GuQPlan plan) {
+  using TL = GuQTile;
+  constexpr int NS = kGuQStages;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // the grid runs slot after slot, longest first: the short ones start on the CUs whose first workgroup has finished
+  const int slot = (int)blockIdx.x / B, b = (int)blockIdx.x % B;
+  const int j = plan.tile[slot], c = plan.chunk[slot];
+  const int t0 = j * TL::BM - (TL::BM - T % TL::BM) % TL::BM;  // < 0 for a partial first tile
+  const int tend = t0 + TL::BM;                    // <= T
+  const int lag0 = c * TL::BN;                     // first lag of the chunk
+  const int nlag = min(TL::BN, tend - lag0);       // lags of the chunk that have a causal pair (> 0 by construction)
+  const bf16_t* gzb = gz + (long)b * T * Hd;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+
+  // LDS-DMA staging, k-tiles of 32: a piece = one wave-instruction = 16 rows x 64 bytes; row r's 16-byte chunk d sits
+  // at position d ^ ((r >> 2) & 3) (conflict-free ds_read_b128 fragments), applied on the source side.  Wave w
+  // stages the frames' piece w and the lags' pieces w and w + 8.  A piece with no needed row in it is never issued
+  // (its LDS rows keep whatever they held); inside an issued piece rows outside the operand re-read its nearest
+  // valid row.  Neither touches the result: a frame t < 0 or a lag beyond the causal limit only meets diagonals
+  // s = t - lag < 0, which nobody reads, and a diagonal is needed as a whole or not at all.
+  constexpr int kStageA = TL::BM * 64, kStageB = TL::BN * 64, kStage = kStageA + kStageB;
+  static_assert(TL::NW == 8 && TL::BM == 128 && TL::BN == 256 && TL::BK == 32, "piece assignment");
+  const bf16_t* src[3];
+  bool live[3];
+  {
+    const int rr = lane >> 2, pos = lane & 3;
+    int row = 16 * wave + rr;                       // frames
+    live[0] = t0 + 16 * wave + 15 >= 0;
+    src[0] = gzb + (long)max(t0 + row, 0) * Hd + 8 * (pos ^ ((row >> 2) & 3));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                   // lags
+      row = 16 * (wave + 8 * i) + rr;
+      live[1 + i] = 16 * (wave + 8 * i) < nlag;
+      src[1 + i] = QT + (long)(lag0 + min(row, nlag - 1)) * ldQ + 8 * (pos ^ ((row >> 2) & 3));
+    }
+  }
+  const int npiece = __builtin_amdgcn_readfirstlane((live[0] ? 1 : 0) + (live[1] ? 1 : 0) + (live[2] ? 1 : 0));
+  auto issue = [&](int stage, int k0) {
+    const int kk = k0 < Hd ? k0 : 0;                // k-tiles past the end re-read the first one (nobody reads them)
+    unsigned char* base = smem_raw + stage * kStage;
+    if (live[0])
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[0] + kk),
+                                       (__attribute__((address_space(3))) void*)(base + wave * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      if (live[1 + i])
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[1 + i] + kk),
+                                         (__attribute__((address_space(3))) void*)(base + kStageA + (wave + 8 * i) * 1024),
+                                         16, 0, 0);
+  };
+  auto wait_tile = [&]() {  // all but the newest NS - 2 k-tiles of this wave's pieces have landed
+    switch (npiece) {
+      case 0: break;
+      case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * (NS - 2)) : "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NS - 2)) : "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (NS - 2)) : "memory"); break;
+    }
+  };
+  auto frag = [&](int stage, int off, int row, int kl, int hh) -> bf16x8 {
+    const int d = (kl >> 3) + hh;
+    return *reinterpret_cast<const bf16x8*>(smem_raw + stage * kStage + off + row * 64 + ((d ^ ((row >> 2) & 3)) << 4));
+  };
+
+  WavePos<TL> w;
+  LMUFFT_STAMP(5, 0);
+  const int rmw = wave / TL::WGN, cw = wave % TL::WGN;  // this wave's row tile and column half
+  // column tiles of this wave that hold a causal pair: lag0 + WN cw + 32 tn <= t0 + 32 rmw + 31
+  int ntn = (min(nlag, t0 + 32 * rmw + 32 - lag0) - TL::WN * cw + 31) / 32;
+  ntn = __builtin_amdgcn_readfirstlane(ntn < 0 ? 0 : (ntn > TL::TN ? TL::TN : ntn));
+  f32x16 acc[TL::TN];
+#pragma unroll
+  for (int tn = 0; tn < TL::TN; ++tn)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[tn][i] = 0.f;
+
+  {  // K loop: NS - 1 k-tiles in flight, counted waits, raw barriers
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st) issue(st, st * TL::BK);
+    int stage = 0, pf = NS - 1;
+    for (int k0 = 0; k0 < Hd; k0 += TL::BK) {
+      wait_tile();
+      __builtin_amdgcn_s_barrier();
+      issue(pf, k0 + (NS - 1) * TL::BK);
+#pragma unroll
+      for (int kl = 0; kl < TL::BK; kl += 16) {
+        const bf16x8 af = frag(stage, 0, w.wm0 + w.r, kl, w.hh);
+#pragma unroll
+        for (int tn = 0; tn < TL::TN; ++tn)
+          if (tn < ntn) {
+            const bf16x8 bfr = frag(stage, kStageA, w.wn0 + tn * 32 + w.r, kl, w.hh);
+            acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[tn], 0, 0, 0);
+          }
+      }
+      stage = stage + 1 == NS ? 0 : stage + 1;
+      pf = pf + 1 == NS ? 0 : pf + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing k-tiles
+    __syncthreads();                                  // the stages are free
+  }
+  LMUFFT_STAMP(5, 1);
+
+  // Diagonal sums of a 32 x 32 product, in registers.  Accumulator register i of lane (r, hh) is the element
+  // (row rho = (i & 3) + 8 (i >> 2) + 4 hh, lag r); fetched from lane (r' + rho) mod 32 of the same half it lands,
+  // in lane r', on the diagonal delta = row - lag = -r' (no wrap) or 32 - r' (wrap): sixteen lane rotations and two
+  // running sums per lane replace an LDS image of the tile and a pass over it.
+  float* wsum = reinterpret_cast<float*>(smem_raw);  // [row tile][column tile][half hh][64]: sums of delta = idx - 31
+  {
+    int rot[16];
+    unsigned wrapmask = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int v = w.r + (i & 3) + 8 * (i >> 2) + 4 * w.hh;
+      rot[i] = ((lane & 32) | (v & 31)) << 2;
+      wrapmask |= (v >= 32 ? 1u : 0u) << i;
+    }
+    float pv[TL::TN][16];
+#pragma unroll
+    for (int tn = 0; tn < TL::TN; ++tn)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float a = acc[tn][i];  // (a bit_cast applied to the vector element itself read element 0 sixteen times)
+        pv[tn][i] = __int_as_float(__builtin_amdgcn_ds_bpermute(rot[i], __float_as_int(a)));
+      }
+#pragma unroll
+    for (int tn = 0; tn < TL::TN; ++tn) {
+      float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const bool wrap = (wrapmask >> i) & 1u;
+        d1 += wrap ? 0.f : pv[tn][i];
+        d2 += wrap ? pv[tn][i] : 0.f;
+      }
+      // delta = -r (d1) and 32 - r (d2; r = 0: none) of this half's rows; the two halves are added by the readers
+      float* dst = wsum + ((rmw * (TL::WGN * TL::TN) + cw * TL::TN + tn) * 2 + w.hh) * 64;
+      dst[31 - w.r] = d1;
+      dst[63 - w.r] = d2;
+    }
+  }
+  __syncthreads();
+  LMUFFT_STAMP(5, 2);
+  // frame s collects, from every row tile rm, the (at most two) column tiles whose diagonal delta = s - t0 - 32 rm
+  // + lag0 + 32 tn lies in [-31, 31]; fixed order
+  float* out = part + ((long)slot * B + b) * T;
+  for (int s = threadIdx.x; s < T; s += TL::THREADS) {
+    float sum = 0.f;
+    if (s < tend) {
+#pragma unroll
+      for (int rm = 0; rm < TL::WGM; ++rm) {
+        // rows 32 rm + rho, lags lag0 + 32 tn + r: s = t0 + row - lag, so delta = rho - r = 32 tn - x with
+        const int x = 32 * rm + t0 - s - lag0;
+        const int tlo = x >> 5;                         // the tile with delta in [-31, 0] (floor)
+        const int dlo = 32 * tlo - x;
+        constexpr int CT = TL::BN / 32;  // column tiles of the workgroup
+        if (tlo >= 0 && tlo < CT) {
+          const float* p = wsum + (rm * CT + tlo) * 128 + dlo + 31;
+          sum += p[0] + p[64];
+        }
+        if (tlo + 1 >= 0 && tlo + 1 < CT && dlo <= -1) {
+          const float* p = wsum + (rm * CT + tlo + 1) * 128 + dlo + 63;
+          sum += p[0] + p[64];
+        }
+      }
+    }
+    out[s] = sum;
+  }
+  LMUFFT_STAMP(5, 3);
+  LMUFFT_STAMP_ADD(5, 4, slot - g_stamps[stamp_block() * 8 + 4]);
+}
+
 
 // ---------------------------------------------------------------------------
 // out[row][j] = sum_n gz[row][n] W_h[n][j_begin + j]  (+ ga[row] w_u[j])
@@ -1198,8 +1494,13 @@ static WprepLayout wprep_layout(const lmufft_shape& s) {
 struct BwdPlanB {
   int S, rps, ntt, cb2_P;
   long slab_floats;
-  size_t off_gz, off_wslab, off_gupart, off_ga, off_scan, scan_bytes, total;
+  size_t off_gz, off_wslab, off_gupart, off_ga, off_scan, scan_bytes, off_q, total;
+  int q_rows, q_ld, q_slots;  // Q route: rows and row stride of Q^T, (frame tile, lag chunk) pairs per utterance
 };
+// The Q route (k_gu_q_bf16) takes sequences of up to kGuQMaxT frames with 16-byte friendly sizes.
+static bool q_route_shape_ok(const lmufft_shape& s) {
+  return s.T <= kGuQMaxT && s.M % 8 == 0 && s.Hd % GuQTile::BK == 0 && s.Hd / 8 <= kThreads;  // whole k-tiles
+}
 // slab of the weight-gradient kernel: gW_h | RB copies of gb_h | RU copies of gw_u | gb_u
 static SlabOutputs wgrad_outputs(const lmufft_shape& s, float* gW_h, float* gb_h, float* gw_u, float* gb_u) {
   using TL = WgradTileB;
@@ -1233,13 +1534,19 @@ static BwdPlanB plan_backward_b(const lmufft_shape& s) {
     const int tiles = cdivb(s.T, kCb2St) * cdivb(s.B, kCb2Bt);
     p.cb2_P = std::max(1, std::min(std::min(32, s.T), (768 + tiles - 1) / tiles));
   }
+  p.q_slots = guq_plan(s.T).nslot;
+  p.q_rows = cdivb(s.T, 64) * 64;
+  p.q_ld = up8(s.Hd);
   p.off_gupart = off;
-  off += align256b(sizeof(float) * std::max((size_t)s.B * p.ntt * s.T, (size_t)p.cb2_P * s.B * s.T));
+  off += align256b(sizeof(float) * std::max(std::max((size_t)s.B * p.ntt * s.T, (size_t)p.cb2_P * s.B * s.T),
+                                            (size_t)p.q_slots * s.B * s.T));
   p.off_ga = off;
   off += align256b(sizeof(float) * (size_t)rows);
   p.off_scan = off;  // scratch of the state-space route (slabs of its adjoint GEMM)
   p.scan_bytes = scan_workspace_bytes(s.B, s.T, s.M);
   off += align256b(p.scan_bytes);
+  p.off_q = off;
+  off += align256b(sizeof(bf16_t) * (size_t)p.q_rows * p.q_ld);
   p.total = off;
   return p;
 }
@@ -1539,7 +1846,7 @@ static int backward_bf16_parts(int parts, const lmufft_shape* s, const void* x_,
                                size_t workspace_bytes, void* stream) {
   if (int rc = check_shape_b(s)) return rc;
   if (!x_ || !m_) return set_error("backward: NULL pointer");
-  if ((parts & 1) && (!w_u || !wprep || !hprep || !u || !h_ || !gm_)) return set_error("backward: NULL pointer");
+  if ((parts & 1) && (!w_u || !wprep || !hprep || !u || !h_)) return set_error("backward: NULL pointer");
   if ((parts & 2) && (!gw_u || !gb_u || !gW_h || !gb_h)) return set_error("backward: NULL pointer");
   bool scan = false;
   if (parts & 1)
@@ -1570,9 +1877,26 @@ static int backward_bf16_parts(int parts, const lmufft_shape* s, const void* x_,
   bf16_t* gz = (bf16_t*)(ws + p.off_gz);
   const bool vec_h = (s->Hd % 8 == 0) && (s->Hd / 8 <= kThreads) && al16(h) && (!gh || al16(gh)) &&
                      (!gh_n || al16(gh_n));
+  // gm == NULL selects the Q route: the encoder gradient straight from gz, gm is never formed
+  const bool qroute = (parts & 1) && !gm && !scan && q_route_shape_ok(*s) && vec_h;
+  if ((parts & 1) && !gm && !qroute)
+    return set_error("backward: gm == NULL needs the Q route (no state-space route, T <= %d, memory size a multiple of 8, "
+                     "hidden size a multiple of 32, 16-byte aligned h / gh); pass a gm buffer", kGuQMaxT);
 
   if (parts & 1) {
-  {  // gz = relu'(h) * (gh + gh_n)
+  if (qroute) {  // gz = relu'(h) * (gh + gh_n), and Q^T = H^T W_h[:, :M]^T on the pass's first workgroups
+    const QPrep q{HbT, (const bf16_t*)((const char*)wprep + wl.off_Wb), (bf16_t*)(ws + p.off_q), p.q_rows, hl.ldHb,
+                  s->Hd, s->M, hl.ldHT, wl.ldW, p.q_ld};
+    const int qblocks = (p.q_rows / QPrepTile::BM) * cdivb(s->Hd, QPrepTile::BN);
+    const long work = rows * (s->Hd / 8);
+    const dim3 grid(qblocks + (int)std::min<long>((work + kThreads - 1) / kThreads, 8192));
+    {
+      PROFB("k_relu_bwd_bf16");
+      hipLaunchKernelGGL(k_relu_bwd_q_bf16, grid, dim3(kThreads), 0, st, h, gh, gh_n, gz, (int)rows, s->T, s->Hd, q,
+                         qblocks);
+    }
+    LAUNCH_CHECKB("k_relu_bwd_q_bf16");
+  } else {  // gz = relu'(h) * (gh + gh_n)
     const long work = vec_h ? rows * (s->Hd / 8) : rows * s->Hd;
     const dim3 grid(std::min<long>((work + kThreads - 1) / kThreads, 8192));
     {
@@ -1619,17 +1943,36 @@ static int backward_bf16_parts(int parts, const lmufft_shape* s, const void* x_,
     return 0;
   };
 
-  // gm = gz W_h[:, :M]
   const GaParts no_parts{nullptr, nullptr, nullptr, 0, 0};
-  if (int rc = dgrad(DgradMTileB{}, DgradMTileB{}, "k_dgrad_m_bf16", gm, 0, s->M, nullptr, nullptr, no_parts)) return rc;
   // the input-gradient GEMM can sum the adjoint convolution's partial slabs itself (and write ga)
   const bool dgrad_x_fast = gx && (s->Hd % 8 == 0) && (s->D % 8 == 0) && al16(gx);
   GaParts ga_parts = no_parts;
+  if (qroute) {  // gu slabs straight from gz
+    using TG = GuQTile;
+    const size_t lds = (size_t)kGuQStages * (TG::BM + TG::BN) * TG::BK * 2;
+    static_assert(kGuQStages * (TG::BM + TG::BN) * TG::BK * 2 >= TG::NW * TG::TN * 128 * 4, "the waves' diagonal sums fit");
+    if (hipFuncSetAttribute((const void*)k_gu_q_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return set_error("cannot reserve %zu bytes of LDS for k_gu_q_bf16", lds);
+    {
+      PROFB("k_gu_q_bf16");
+      hipLaunchKernelGGL(k_gu_q_bf16, dim3(s->B * p.q_slots), dim3(TG::THREADS), lds, st, (const bf16_t*)gz,
+                         (const bf16_t*)(ws + p.off_q), gupart, s->B, s->T, s->Hd, p.q_ld, p.q_rows, guq_plan(s->T));
+    }
+    LAUNCH_CHECKB("k_gu_q_bf16");
+    if (dgrad_x_fast && p.q_slots <= kGaMaxParts) {
+      ga_parts = GaParts{gupart, u, ga, rows, p.q_slots};
+    } else if (int rc = launch_sum_slabs_masked(gupart, u, ga, rows, p.q_slots, st)) {
+      return rc;
+    }
+  } else {
+  // gm = gz W_h[:, :M]
+  if (int rc = dgrad(DgradMTileB{}, DgradMTileB{}, "k_dgrad_m_bf16", gm, 0, s->M, nullptr, nullptr, no_parts)) return rc;
   // ga = (adjoint conv of gm) * (u > 0)
   if (scan) {
     if (int rc = scan_conv_backward(*s, gm, scanprep, u, ga, ws + p.off_scan, p.scan_bytes, st)) return rc;
   } else if (int rc = conv_backward_bf16_any(*s, gm, hl, HbT, p, gupart, u, ga, dgrad_x_fast, &ga_parts, st)) {
     return rc;
+  }
   }
   // gx = gz W_h[:, M:] + ga w_u
   if (gx) {
@@ -1664,6 +2007,12 @@ static int backward_bf16_parts(int parts, const lmufft_shape* s, const void* x_,
 }
 
 extern "C" {
+
+int lmufft_backward_needs_gm_bf16(const lmufft_shape* s, int conv_algo, int has_scanprep) {
+  if (!s) return 1;
+  const bool scan = conv_algo == LMUFFT_CONV_SCAN || (conv_algo == LMUFFT_CONV_AUTO && has_scanprep);
+  return (scan || !q_route_shape_ok(*s)) ? 1 : 0;
+}
 
 int lmufft_backward_bf16(const lmufft_shape* s, const void* x, const float* w_u, const void* wprep,
                          const void* hprep, const void* scanprep, const float* u, const void* m, const void* h,

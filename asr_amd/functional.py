@@ -11,6 +11,11 @@ import torch
 
 from . import _lib
 
+# True: the bf16 backward always forms the memory gradient gm = gz W_h[:, :M] and runs the adjoint convolution
+# on it (the reference's own order of operations); False: where the library can, it takes the encoder gradient
+# straight from gz (include/lmufft.h, lmufft_backward_needs_gm_bf16).  Tests compare the two.
+FORCE_MEMORY_GRADIENT = False
+
 _ALGOS = {"auto": _lib.CONV_AUTO, "toeplitz": _lib.CONV_TOEPLITZ, "fft": _lib.CONV_FFT, "scan": _lib.CONV_SCAN}
 _DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
 
@@ -263,8 +268,12 @@ class _LMUFFTFunction(torch.autograd.Function):
             gb_u = torch.empty((1,), dtype=torch.float32, device=dev)
             gW_h = torch.empty_like(W_h)
             gb_h = torch.empty((Hd,), dtype=torch.float32, device=dev)
-        gm = torch.empty_like(m)
         shp = _shape(B, T, D, M, Hd, ldH)
+        # the bf16 backward forms the memory gradient only on the routes that need it (long sequences, odd sizes)
+        gm = None
+        if dt == torch.float32 or FORCE_MEMORY_GRADIENT or _lib.lib.lmufft_backward_needs_gm_bf16(
+                ctypes.byref(shp), ctx.conv_algo, 0 if scanprep is None else 1):
+            gm = torch.empty_like(m)
         with torch.cuda.device(dev):
             ws = _workspace(_lib.lib.lmufft_backward_workspace_bytes(ctypes.byref(shp), _DTYPES[dt]), dev)
             if dt == torch.float32:

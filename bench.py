@@ -114,6 +114,8 @@ def kernel_work(name, B, T, D, M, Hd, s=4):
         "k_dgrad_x": (2.0 * rows * D * Hd, rows * (gz_in + D * s + 4) + Hd * D * s),
         "k_wgrad": (2.0 * rows * MD * Hd, rows * (gz_in + MD * s) + Hd * MD * 4),
         "k_relu_bwd": (2.0 * rows * Hd, rows * 3 * Hd * s),
+        # encoder gradient straight from gz: gz against Q^T [T][Hd], causal half of the lags; reads gz and Q^T once
+        "k_gu_q": (1.0 * rows * Hd * (T + 1), rows * Hd * s + T * Hd * 2 + rows * 4),
         "k_conv_fwd": (1.0 * B * T * (T + 1) * M, rows * M * s + rows * 4 + M * T * s),
         "k_conv_bwd": (1.0 * B * T * (T + 1) * M, rows * M * s + rows * 4 + M * T * s),
         # state-space route (bf16): two dense GEMMs of K = M + 128 against a constant matrix of (M + 128) x 128 M

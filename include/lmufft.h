@@ -224,6 +224,15 @@ int lmufft_conv_forward_scan_bf16(const lmufft_shape* s, const float* u, const v
 int lmufft_conv_backward_scan_bf16(const lmufft_shape* s, const void* gm, const void* scanprep, float* gu,
                                    void* workspace, size_t workspace_bytes, void* stream);
 
+/* gm: [B][T][M] bf16 scratch that receives the memory gradient gz W_h[:, :M], or NULL.  With gm == NULL the
+ * encoder gradient is taken straight from the masked upstream gradient: the two linear steps of autograd of
+ * src/lmu.py:303-316 (gm = gz W_h[:, :M], then the adjoint convolution with H) are composed into one GEMM against
+ * Q^T, Q[n][tau] = sum_k W_h[n][k] H[k][tau], built once per call, and gm is never formed.  That route takes
+ * sequences of up to 512 frames, a memory size that is a multiple of 8, a hidden size that is a multiple of 32 and
+ * 16-byte aligned h / gh, and is
+ * not used with the state-space convolution; lmufft_backward_needs_gm_bf16 tells (1: pass a gm buffer, 0: gm may
+ * be NULL) for a shape, conv_algo and whether scanprep is given. */
+int lmufft_backward_needs_gm_bf16(const lmufft_shape* s, int conv_algo, int has_scanprep);
 int lmufft_backward_bf16(const lmufft_shape* s, const void* x, const float* w_u,
                          const void* wprep, const void* hprep, const void* scanprep, const float* u,
                          const void* m, const void* h, const void* gh,
