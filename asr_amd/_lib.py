@@ -20,7 +20,7 @@ CONV_TOEPLITZ = 1
 CONV_FFT = 2
 CONV_SCAN = 3
 NOALLOC_SCRATCH_BYTES = 8 << 20
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 class Shape(ctypes.Structure):
@@ -104,7 +104,7 @@ def _load():
     lib.lmufft_wprep_bf16.restype = ci
     lib.lmufft_wprep_bf16.argtypes = [sp, vp, vp, vp]
     lib.lmufft_forward_bf16.restype = ci
-    lib.lmufft_forward_bf16.argtypes = [sp] + [vp] * 12 + [ci, vp, sz, vp]
+    lib.lmufft_forward_bf16.argtypes = [sp] + [vp] * 13 + [ci, vp, sz, vp]
     lib.lmufft_forward_ln_bf16.restype = ci
     lib.lmufft_forward_ln_bf16.argtypes = [sp] + [vp] * 14 + [ctypes.c_float, vp, ci, ci, vp, sz, vp]
     lib.lmufft_conv_forward_bf16.restype = ci
@@ -112,9 +112,9 @@ def _load():
     lib.lmufft_conv_backward_bf16.restype = ci
     lib.lmufft_conv_backward_bf16.argtypes = [sp, vp, vp, vp, vp, sz, vp]
     lib.lmufft_backward_bf16.restype = ci
-    lib.lmufft_backward_bf16.argtypes = [sp] + [vp] * 16 + [ci, vp, sz, vp]
+    lib.lmufft_backward_bf16.argtypes = [sp] + [vp] * 17 + [ci, vp, sz, vp]
     lib.lmufft_backward_data_bf16.restype = ci
-    lib.lmufft_backward_data_bf16.argtypes = [sp] + [vp] * 12 + [ci, vp, sz, vp]
+    lib.lmufft_backward_data_bf16.argtypes = [sp] + [vp] * 13 + [ci, vp, sz, vp]
     lib.lmufft_backward_weights_bf16.restype = ci
     lib.lmufft_backward_weights_bf16.argtypes = [sp] + [vp] * 6 + [vp, sz, vp]
     lib.lmufft_scan_chunk.restype = ctypes.c_int32

@@ -188,10 +188,11 @@ __device__ __forceinline__ void gemm_loop_glds_deep(const OA& a, const OB& b, f3
 //   col_limit % 8 == 0 and 16-byte aligned rows (the caller checks); out == NULL: only the LDS image.
 // `lds` needs BM * (BN + 8) * 2 bytes.  Returns with the tile still in LDS
 // (image [BM][BN + 8]) so that callers can copy rows out of it again.
-template <class T, class V>
+//   chunk(row, col, v) is called by the lane that stores the 8 elements v to out[row][col .. col + 8)
+template <class T, class V, class C>
 __device__ __forceinline__ void store_tile_bf16(const f32x16 (&acc)[T::TM][T::TN], const WavePos<T>& w,
                                                 bf16_t* lds, bf16_t* __restrict__ out, long ld, long row0,
-                                                int col0, long row_limit, int col_limit, V&& value) {
+                                                int col0, long row_limit, int col_limit, V&& value, C&& chunk) {
   constexpr int LDT = T::BN + 8;
   tile_epilogue_ix<T>(acc, w, [&](int tm, int tn, int i, int m, int n, float v) {
     lds[m * LDT + n] = (bf16_t)value(tm, tn, i, m, n, v);
@@ -202,9 +203,19 @@ __device__ __forceinline__ void store_tile_bf16(const f32x16 (&acc)[T::TM][T::TN
     const int m = idx / CH, c = idx % CH;
     const long row = row0 + m;
     const int col = col0 + c * 8;
-    if (out && row >= 0 && row < row_limit && col < col_limit)
-      *reinterpret_cast<bf16x8*>(out + row * ld + col) = *reinterpret_cast<const bf16x8*>(&lds[m * LDT + c * 8]);
+    if (out && row >= 0 && row < row_limit && col < col_limit) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(&lds[m * LDT + c * 8]);
+      *reinterpret_cast<bf16x8*>(out + row * ld + col) = v;
+      chunk(row, col, v);
+    }
   }
+}
+
+template <class T, class V>
+__device__ __forceinline__ void store_tile_bf16(const f32x16 (&acc)[T::TM][T::TN], const WavePos<T>& w,
+                                                bf16_t* lds, bf16_t* __restrict__ out, long ld, long row0,
+                                                int col0, long row_limit, int col_limit, V&& value) {
+  store_tile_bf16<T>(acc, w, lds, out, ld, row0, col0, row_limit, col_limit, value, [](long, int, const bf16x8&) {});
 }
 
 }  // namespace lmufft

@@ -362,7 +362,7 @@ constexpr int kProjStages = 2;
 __global__ __launch_bounds__(ProjGldsTile::THREADS) void k_proj_fwd_glds_bf16(
     const bf16_t* __restrict__ m, const bf16_t* __restrict__ x, const bf16_t* __restrict__ Wb,
     const float* __restrict__ bias, bf16_t* __restrict__ h, bf16_t* __restrict__ h_n, int rows, int T, int M, int D,
-    int Hd, int ldW, LnEpilogue ln) {
+    int Hd, int ldW, LnEpilogue ln, unsigned char* __restrict__ hmask) {
   using TL = ProjGldsTile;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int n0 = blockIdx.x * TL::BN;
@@ -402,8 +402,21 @@ __global__ __launch_bounds__(ProjGldsTile::THREADS) void k_proj_fwd_glds_bf16(
   float bcol[TL::TN];
   preload_cols<TL>(bcol, w, [&](int nn) { return load_or_zero(bias + n0 + nn, n0 + nn < Hd); });
   bf16_t* tile = reinterpret_cast<bf16_t*>(smem_raw);
-  store_tile_bf16<TL>(acc, w, tile, h, Hd, m0, n0, rows, Hd,
-                      [&](int, int tn, int, int, int, float v) { return fmaxf(v + bcol[tn], 0.f); });
+  // relu pattern for the backward, one bit per element: hmask[row][Hd / 8] bytes, bit j of byte c = h[row][8 c + j] > 0,
+  // written by the lane that stores those 8 elements (the backward then reads 1/16 of the bytes of h to mask the
+  // upstream gradient)
+  const int CHM = Hd / 8;
+  store_tile_bf16<TL>(
+      acc, w, tile, h, Hd, m0, n0, rows, Hd,
+      [&](int, int tn, int, int, int, float v) { return fmaxf(v + bcol[tn], 0.f); },
+      [&](long row, int col, const bf16x8& v) {
+        if (hmask) {
+          unsigned bits = 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bits |= ((float)v[j] > 0.f ? 1u : 0u) << j;
+          hmask[row * CHM + (col >> 3)] = (unsigned char)bits;
+        }
+      });
   LMUFFT_STAMP(4, 2);
   // h_n: the last frame of every utterance that ends inside this row tile (tile still in LDS)
   const long tile_end = min((long)rows, m0 + TL::BM);
@@ -536,6 +549,7 @@ struct QPrep {
 };
 
 __global__ __launch_bounds__(kThreads) void k_relu_bwd_q_bf16(const bf16_t* __restrict__ h,
+                                                              const unsigned char* __restrict__ hmask,
                                                               const bf16_t* __restrict__ gh,
                                                               const bf16_t* __restrict__ gh_n,
                                                               bf16_t* __restrict__ gz, int rows, int T, int Hd, QPrep q,
@@ -574,7 +588,15 @@ __global__ __launch_bounds__(kThreads) void k_relu_bwd_q_bf16(const bf16_t* __re
   for (long i = ((long)blockIdx.x - qblocks) * kThreads + threadIdx.x; i < total; i += nb * kThreads) {
     const unsigned row = (unsigned)(i / CH), c = (unsigned)(i - (long)row * CH);
     const long off = (long)row * Hd + c * 8;
-    const bf16x8 hv = *reinterpret_cast<const bf16x8*>(h + off);
+    unsigned keep;  // bit j: h[row][8 c + j] > 0 -- from the forward's bit mask when there is one (1/16 of the bytes)
+    if (hmask) {
+      keep = hmask[i];
+    } else {
+      const bf16x8 hv = *reinterpret_cast<const bf16x8*>(h + off);
+      keep = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) keep |= ((float)hv[j] > 0.f ? 1u : 0u) << j;
+    }
     bf16x8 g = gh ? *reinterpret_cast<const bf16x8*>(gh + off) : bzero8();
     if (gh_n) {
       const unsigned b = row / (unsigned)T;
@@ -585,7 +607,7 @@ __global__ __launch_bounds__(kThreads) void k_relu_bwd_q_bf16(const bf16_t* __re
       }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) g[j] = (float)hv[j] > 0.f ? g[j] : (bf16_t)0.f;
+    for (int j = 0; j < 8; ++j) g[j] = ((keep >> j) & 1u) ? g[j] : (bf16_t)0.f;
     *reinterpret_cast<bf16x8*>(gz + off) = g;
   }
 }
@@ -1675,10 +1697,21 @@ static int use_scan_route(int conv_algo, const void* scanprep, bool* scan) {
   return 0;
 }
 
+// hmask[row][c] bit j = h[row][8 c + j] > 0 from a finished h (shapes the LDS-DMA projection kernel does not take)
+__global__ __launch_bounds__(kThreads) void k_hmask_from_h(const bf16_t* __restrict__ h, unsigned char* __restrict__ hmask,
+                                                           long chunks) {
+  for (long i = blockIdx.x * (long)kThreads + threadIdx.x; i < chunks; i += (long)gridDim.x * kThreads) {
+    unsigned bits = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bits |= ((float)h[i * 8 + j] > 0.f ? 1u : 0u) << j;
+    hmask[i] = (unsigned char)bits;
+  }
+}
+
 static int forward_bf16_impl(const lmufft_shape* s, const void* x_, const float* w_u, const float* b_u, void* wprep,
                              const float* W_h, const float* b_h, const void* hprep, const void* scanprep, float* u,
-                             void* m_, void* h_, void* h_n_, int conv_algo, void* workspace, size_t workspace_bytes,
-                             void* stream, const LnEpilogue& ln) {
+                             void* m_, void* h_, void* h_n_, void* hmask, int conv_algo, void* workspace,
+                             size_t workspace_bytes, void* stream, const LnEpilogue& ln) {
   if (int rc = check_shape_b(s)) return rc;
   if (!x_ || !w_u || !b_u || !wprep || !b_h || !hprep || !u || !m_ || (!h_ && !ln.y) || !h_n_)
     return set_error("forward: NULL pointer");
@@ -1735,7 +1768,7 @@ static int forward_bf16_impl(const lmufft_shape* s, const void* x_, const float*
       {
         PROFB("k_proj_fwd_bf16");
         hipLaunchKernelGGL(k_proj_fwd_glds_bf16, grid, dim3(TG::THREADS), lds, st, m, x, Wb, b_h, h, h_n, (int)rows,
-                           s->T, s->M, s->D, s->Hd, ldW, ln);
+                           s->T, s->M, s->D, s->Hd, ldW, ln, (unsigned char*)hmask);
       }
     } else {
       const dim3 grid(cdivb(s->Hd, TL::BN), cdivb(rows, TL::BM));
@@ -1743,6 +1776,11 @@ static int forward_bf16_impl(const lmufft_shape* s, const void* x_, const float*
       PROFB("k_proj_fwd_bf16");
       hipLaunchKernelGGL(k_proj_fwd_bf16<false>, grid, dim3(kThreads), lds, st, m, x, Wb, b_h, h, h_n, (int)rows,
                          s->T, s->M, s->D, s->Hd, ldW);
+      if (hmask && s->Hd % 8 == 0) {
+        const long chunks = rows * (s->Hd / 8);
+        hipLaunchKernelGGL(k_hmask_from_h, dim3((int)std::min<long>((chunks + kThreads - 1) / kThreads, 4096)),
+                           dim3(kThreads), 0, st, (const bf16_t*)h, (unsigned char*)hmask, chunks);
+      }
     }
     LAUNCH_CHECKB("k_proj_fwd_bf16");
   }
@@ -1819,9 +1857,11 @@ extern "C" {
 
 int lmufft_forward_bf16(const lmufft_shape* s, const void* x, const float* w_u, const float* b_u, void* wprep,
                         const float* W_h, const float* b_h, const void* hprep, const void* scanprep, float* u, void* m,
-                        void* h, void* h_n, int conv_algo, void* workspace, size_t workspace_bytes, void* stream) {
+                        void* h, void* h_n, void* hmask, int conv_algo, void* workspace, size_t workspace_bytes,
+                        void* stream) {
   if (!h) return set_error("forward: NULL pointer");
-  return forward_bf16_impl(s, x, w_u, b_u, wprep, W_h, b_h, hprep, scanprep, u, m, h, h_n, conv_algo, workspace,
+  if (hmask && s && s->Hd % 8) return set_error("forward: hmask needs a hidden size that is a multiple of 8");
+  return forward_bf16_impl(s, x, w_u, b_u, wprep, W_h, b_h, hprep, scanprep, u, m, h, h_n, hmask, conv_algo, workspace,
                            workspace_bytes, stream, LnEpilogue{nullptr, nullptr, 0.f, nullptr, 0});
 }
 
@@ -1831,7 +1871,7 @@ int lmufft_forward_ln_bf16(const lmufft_shape* s, const void* x, const float* w_
                            int y_dtype, int conv_algo, void* workspace, size_t workspace_bytes, void* stream) {
   if (!gamma || !beta || !y) return set_error("forward with layer norm: NULL pointer");
   if (y_dtype != LMUFFT_F32 && y_dtype != LMUFFT_BF16) return set_error("forward with layer norm: unknown dtype");
-  return forward_bf16_impl(s, x, w_u, b_u, wprep, W_h, b_h, hprep, scanprep, u, m, h, h_n, conv_algo, workspace,
+  return forward_bf16_impl(s, x, w_u, b_u, wprep, W_h, b_h, hprep, scanprep, u, m, h, h_n, nullptr, conv_algo, workspace,
                            workspace_bytes, stream, LnEpilogue{gamma, beta, eps, y, y_dtype == LMUFFT_BF16});
 }
 
@@ -1841,7 +1881,8 @@ int lmufft_forward_ln_bf16(const lmufft_shape* s, const void* x, const float* w_
 // the workspace's gz and ga, 3 = both
 static int backward_bf16_parts(int parts, const lmufft_shape* s, const void* x_, const float* w_u, const void* wprep,
                                const void* hprep, const void* scanprep, const float* u, const void* m_,
-                               const void* h_, const void* gh_, const void* gh_n_, void* gx_, float* gw_u,
+                               const void* h_, const void* hmask, const void* gh_, const void* gh_n_, void* gx_,
+                               float* gw_u,
                                float* gb_u, float* gW_h, float* gb_h, void* gm_, int conv_algo, void* workspace,
                                size_t workspace_bytes, void* stream) {
   if (int rc = check_shape_b(s)) return rc;
@@ -1892,7 +1933,8 @@ static int backward_bf16_parts(int parts, const lmufft_shape* s, const void* x_,
     const dim3 grid(qblocks + (int)std::min<long>((work + kThreads - 1) / kThreads, 8192));
     {
       PROFB("k_relu_bwd_bf16");
-      hipLaunchKernelGGL(k_relu_bwd_q_bf16, grid, dim3(kThreads), 0, st, h, gh, gh_n, gz, (int)rows, s->T, s->Hd, q,
+      hipLaunchKernelGGL(k_relu_bwd_q_bf16, grid, dim3(kThreads), 0, st, h, (const unsigned char*)hmask, gh, gh_n, gz,
+                         (int)rows, s->T, s->Hd, q,
                          qblocks);
     }
     LAUNCH_CHECKB("k_relu_bwd_q_bf16");
@@ -2016,23 +2058,24 @@ int lmufft_backward_needs_gm_bf16(const lmufft_shape* s, int conv_algo, int has_
 
 int lmufft_backward_bf16(const lmufft_shape* s, const void* x, const float* w_u, const void* wprep,
                          const void* hprep, const void* scanprep, const float* u, const void* m, const void* h,
-                         const void* gh, const void* gh_n, void* gx, float* gw_u, float* gb_u, float* gW_h,
-                         float* gb_h, void* gm, int conv_algo, void* workspace, size_t workspace_bytes, void* stream) {
-  return backward_bf16_parts(3, s, x, w_u, wprep, hprep, scanprep, u, m, h, gh, gh_n, gx, gw_u, gb_u, gW_h, gb_h, gm,
+                         const void* hmask, const void* gh, const void* gh_n, void* gx, float* gw_u, float* gb_u,
+                         float* gW_h, float* gb_h, void* gm, int conv_algo, void* workspace, size_t workspace_bytes,
+                         void* stream) {
+  return backward_bf16_parts(3, s, x, w_u, wprep, hprep, scanprep, u, m, h, hmask, gh, gh_n, gx, gw_u, gb_u, gW_h, gb_h, gm,
                              conv_algo, workspace, workspace_bytes, stream);
 }
 
 int lmufft_backward_data_bf16(const lmufft_shape* s, const void* x, const float* w_u, const void* wprep,
                               const void* hprep, const void* scanprep, const float* u, const void* m, const void* h,
-                              const void* gh, const void* gh_n, void* gx, void* gm, int conv_algo, void* workspace,
-                              size_t workspace_bytes, void* stream) {
-  return backward_bf16_parts(1, s, x, w_u, wprep, hprep, scanprep, u, m, h, gh, gh_n, gx, nullptr, nullptr, nullptr,
+                              const void* hmask, const void* gh, const void* gh_n, void* gx, void* gm, int conv_algo,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  return backward_bf16_parts(1, s, x, w_u, wprep, hprep, scanprep, u, m, h, hmask, gh, gh_n, gx, nullptr, nullptr, nullptr,
                              nullptr, gm, conv_algo, workspace, workspace_bytes, stream);
 }
 
 int lmufft_backward_weights_bf16(const lmufft_shape* s, const void* x, const void* m, float* gw_u, float* gb_u,
                                  float* gW_h, float* gb_h, void* workspace, size_t workspace_bytes, void* stream) {
-  return backward_bf16_parts(2, s, x, nullptr, nullptr, nullptr, nullptr, nullptr, m, nullptr, nullptr, nullptr,
+  return backward_bf16_parts(2, s, x, nullptr, nullptr, nullptr, nullptr, nullptr, m, nullptr, nullptr, nullptr, nullptr,
                              nullptr, gw_u, gb_u, gW_h, gb_h, nullptr, LMUFFT_CONV_AUTO, workspace, workspace_bytes,
                              stream);
 }

@@ -15,6 +15,9 @@ from . import _lib
 # on it (the reference's own order of operations); False: where the library can, it takes the encoder gradient
 # straight from gz (include/lmufft.h, lmufft_backward_needs_gm_bf16).  Tests compare the two.
 FORCE_MEMORY_GRADIENT = False
+# bf16: the forward also writes h's relu pattern as one bit per element and the backward masks the upstream
+# gradient with it instead of reading h back (tests switch it off to compare the two)
+USE_RELU_MASK = True
 
 _ALGOS = {"auto": _lib.CONV_AUTO, "toeplitz": _lib.CONV_TOEPLITZ, "fft": _lib.CONV_FFT, "scan": _lib.CONV_SCAN}
 _DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
@@ -208,6 +211,7 @@ class _LMUFFTFunction(torch.autograd.Function):
         h = torch.empty((B, T, Hd), dtype=dt, device=dev)
         h_n = torch.empty((B, Hd), dtype=dt, device=dev)
         shp = _shape(B, T, D, M, Hd, ldH)
+        hmask = None
         with torch.cuda.device(dev):
             ws = _workspace(_lib.lib.lmufft_forward_workspace_bytes(ctypes.byref(shp), _DTYPES[dt]), dev)
             if dt == torch.float32:
@@ -223,14 +227,17 @@ class _LMUFFTFunction(torch.autograd.Function):
                 # bf16 copies of W_h (both orientations), made by the forward's first launch and reused
                 # by the backward
                 wprep = _workspace(_lib.lib.lmufft_wprep_bytes(ctypes.byref(shp)), dev)
+                # the relu pattern of h as a bit mask: the backward reads it instead of h (1/16 of the bytes)
+                if USE_RELU_MASK and Hd % 8 == 0 and any(ctx.needs_input_grad[:5]):
+                    hmask = torch.empty((B * T, Hd // 8), dtype=torch.uint8, device=dev)
                 rc = _lib.lib.lmufft_forward_bf16(
                     ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(b_u), _ptr(wprep), _ptr(W_h), _ptr(b_h), _ptr(hprep),
-                    _ptr(scanprep), _ptr(u), _ptr(m), _ptr(h), _ptr(h_n), conv_algo, _ptr(ws), ws.numel(),
+                    _ptr(scanprep), _ptr(u), _ptr(m), _ptr(h), _ptr(h_n), _ptr(hmask), conv_algo, _ptr(ws), ws.numel(),
                     _stream(dev))
                 what = "lmufft_forward_bf16"
         _lib.check(rc, what)
         ctx.save_for_backward(x, w_u, W_h, H, u, m, h, hprep, wprep if dt != torch.float32 else None,
-                              fftprep if dt == torch.float32 else None, scanprep if dt != torch.float32 else None)
+                              fftprep if dt == torch.float32 else None, scanprep if dt != torch.float32 else None, hmask)
         ctx.conv_algo = conv_algo
         ctx.async_wgrad = bool(async_wgrad)
         ctx.grad_sink = grad_sink
@@ -240,7 +247,7 @@ class _LMUFFTFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gh, gh_n):
-        x, w_u, W_h, H, u, m, h, hprep, wprep, fftprep, scanprep = ctx.saved_tensors
+        x, w_u, W_h, H, u, m, h, hprep, wprep, fftprep, scanprep, hmask = ctx.saved_tensors
         B, T, D, M, Hd, ldH = ctx.shape
         dev = x.device
         dt = x.dtype
@@ -289,7 +296,7 @@ class _LMUFFTFunction(torch.autograd.Function):
                 # gradients handed back to autograd are accumulated on this stream at once.
                 rc = _lib.lib.lmufft_backward_data_bf16(
                     ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(wprep), _ptr(hprep), _ptr(scanprep), _ptr(u), _ptr(m),
-                    _ptr(h), _ptr(gh), _ptr(gh_n), _ptr(gx), _ptr(gm), ctx.conv_algo, _ptr(ws), ws.numel(),
+                    _ptr(h), _ptr(hmask), _ptr(gh), _ptr(gh_n), _ptr(gx), _ptr(gm), ctx.conv_algo, _ptr(ws), ws.numel(),
                     _stream(dev))
                 _lib.check(rc, "lmufft_backward_data_bf16")
                 side = _wgrad_stream(dev)
@@ -306,8 +313,8 @@ class _LMUFFTFunction(torch.autograd.Function):
             else:
                 rc = _lib.lib.lmufft_backward_bf16(
                     ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(wprep), _ptr(hprep), _ptr(scanprep), _ptr(u), _ptr(m),
-                    _ptr(h), _ptr(gh), _ptr(gh_n), _ptr(gx), _ptr(gw_u), _ptr(gb_u), _ptr(gW_h), _ptr(gb_h), _ptr(gm),
-                    ctx.conv_algo, _ptr(ws), ws.numel(), _stream(dev))
+                    _ptr(h), _ptr(hmask), _ptr(gh), _ptr(gh_n), _ptr(gx), _ptr(gw_u), _ptr(gb_u), _ptr(gW_h), _ptr(gb_h),
+                    _ptr(gm), ctx.conv_algo, _ptr(ws), ws.numel(), _stream(dev))
                 what = "lmufft_backward_bf16"
         _lib.check(rc, what)
         if direct:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMUFFT_ABI_VERSION 18
+#define LMUFFT_ABI_VERSION 19
 
 /* element types of the activations (x, h, gh, gx, m) */
 #define LMUFFT_F32 0
@@ -171,10 +171,12 @@ int lmufft_wprep_bf16(const lmufft_shape* s, const float* W_h, void* wprep, void
 /* scanprep: NULL, or the operands of the state-space convolution route (below).  conv_algo AUTO takes
  * that route whenever scanprep is given and the Toeplitz kernels otherwise; SCAN requires it.  The
  * workspace (lmufft_forward_workspace_bytes / lmufft_backward_workspace_bytes) is only read on that route. */
+/* hmask: NULL, or [B*T][Hd/8] bytes (Hd a multiple of 8) that receive the relu pattern of h, bit j of byte
+ * (row, c) = h[row][8 c + j] > 0.  Handed to the backward it replaces the read of h there (1/16 of the bytes). */
 int lmufft_forward_bf16(const lmufft_shape* s, const void* x, const float* w_u,
                         const float* b_u, void* wprep, const float* W_h, const float* b_h,
                         const void* hprep, const void* scanprep, float* u, void* m, void* h,
-                        void* h_n, int conv_algo, void* workspace, size_t workspace_bytes,
+                        void* h_n, void* hmask, int conv_algo, void* workspace, size_t workspace_bytes,
                         void* stream);
 
 /* The bf16 forward followed by the layer norm the encoder applies to the layer's output
@@ -233,9 +235,10 @@ int lmufft_conv_backward_scan_bf16(const lmufft_shape* s, const void* gm, const 
  * not used with the state-space convolution; lmufft_backward_needs_gm_bf16 tells (1: pass a gm buffer, 0: gm may
  * be NULL) for a shape, conv_algo and whether scanprep is given. */
 int lmufft_backward_needs_gm_bf16(const lmufft_shape* s, int conv_algo, int has_scanprep);
+/* hmask: NULL, or the relu pattern the forward wrote (see lmufft_forward_bf16); h must still be given. */
 int lmufft_backward_bf16(const lmufft_shape* s, const void* x, const float* w_u,
                          const void* wprep, const void* hprep, const void* scanprep, const float* u,
-                         const void* m, const void* h, const void* gh,
+                         const void* m, const void* h, const void* hmask, const void* gh,
                          const void* gh_n, void* gx, float* gw_u, float* gb_u,
                          float* gW_h, float* gb_h, void* gm, int conv_algo,
                          void* workspace, size_t workspace_bytes, void* stream);
@@ -251,8 +254,8 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x, const float* w_u,
  * lmufft_backward_bf16 is the two back to back on one stream. */
 int lmufft_backward_data_bf16(const lmufft_shape* s, const void* x, const float* w_u,
                               const void* wprep, const void* hprep, const void* scanprep,
-                              const float* u, const void* m, const void* h, const void* gh,
-                              const void* gh_n, void* gx, void* gm, int conv_algo, void* workspace,
+                              const float* u, const void* m, const void* h, const void* hmask,
+                              const void* gh, const void* gh_n, void* gx, void* gm, int conv_algo, void* workspace,
                               size_t workspace_bytes, void* stream);
 int lmufft_backward_weights_bf16(const lmufft_shape* s, const void* x, const void* m, float* gw_u,
                                  float* gb_u, float* gW_h, float* gb_h, void* workspace,

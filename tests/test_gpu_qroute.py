@@ -76,6 +76,43 @@ def test_null_memory_gradient_is_refused_where_the_composed_route_does_not_apply
     f32 = torch.float32
     rc = _lib.lib.lmufft_backward_bf16(
         ctypes.byref(shp), p(z(B, T, D)), p(z(1, D, dt=f32)), p(wprep), p(hprep), None, p(z(B, T, dt=f32)), p(z(B, T, M)),
-        p(z(B, T, Hd)), p(z(B, T, Hd)), None, p(z(B, T, D)), p(z(1, D, dt=f32)), p(z(1, dt=f32)), p(z(Hd, M + D, dt=f32)),
+        p(z(B, T, Hd)), None, p(z(B, T, Hd)), None, p(z(B, T, D)), p(z(1, D, dt=f32)), p(z(1, dt=f32)), p(z(Hd, M + D, dt=f32)),
         p(z(Hd, dt=f32)), None, _lib.CONV_AUTO, p(ws), ws.numel(), None)
     assert rc != 0 and b"gm" in _lib.lib.lmufft_last_error()
+
+
+@pytest.mark.parametrize("B,T,D,M,Hd", [(64, 400, 384, 192, 384), (3, 129, 80, 64, 128), (2, 77, 64, 12, 136)])
+def test_relu_bit_mask_is_the_pattern_of_h_and_changes_nothing(B, T, D, M, Hd):
+    """The forward's bit mask (bit j of byte (row, c) = h[row][8 c + j] > 0) against h itself -- written by the
+    projection's epilogue on the first two shapes and by the separate pass on the third (M % 8 != 0) -- and a
+    backward that masks with it against one that reads h: bit-equal gradients."""
+    from asr_amd import LMUFFT, _lib, functional
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(T)
+    layer = LMUFFT(D, Hd, M, T, 100.0)
+    torch.nn.init.xavier_uniform_(layer.W_u.weight)
+    torch.nn.init.xavier_uniform_(layer.W_h.weight)
+    layer = layer.to(dev)
+    g = torch.Generator(device=dev).manual_seed(9)
+    x0 = torch.randn(B, T, D, device=dev, generator=g).bfloat16()
+    gh = torch.randn(B, T, Hd, device=dev, generator=g).bfloat16()
+    gh_n = torch.randn(B, Hd, device=dev, generator=g).bfloat16()
+    out = {}
+    for use in (True, False):
+        functional.USE_RELU_MASK = use
+        try:
+            layer.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_(True)
+            h, h_n = layer(x)
+            if use:
+                mask = h.grad_fn.saved_tensors[-1] if hasattr(h.grad_fn, "saved_tensors") else None
+                assert mask is not None and mask.dtype == torch.uint8 and mask.shape == (B * T, Hd // 8)
+                want = np.packbits((h.detach().float() > 0).cpu().numpy().reshape(B * T, Hd), axis=1, bitorder="little")
+                assert np.array_equal(mask.cpu().numpy(), want)
+            torch.autograd.backward([h, h_n], [gh, gh_n])
+            out[use] = [x.grad] + [p.grad.clone() for p in layer.parameters()]
+        finally:
+            functional.USE_RELU_MASK = True
+    for a, b in zip(out[True], out[False]):
+        assert torch.equal(a, b)
