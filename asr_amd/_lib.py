@@ -20,7 +20,7 @@ CONV_TOEPLITZ = 1
 CONV_FFT = 2
 CONV_SCAN = 3
 NOALLOC_SCRATCH_BYTES = 8 << 20
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 
 class Shape(ctypes.Structure):
@@ -33,6 +33,19 @@ class Shape(ctypes.Structure):
         ("M", ctypes.c_int32),
         ("Hd", ctypes.c_int32),
         ("ldH", ctypes.c_int32),
+    ]
+
+
+class LrSchedule(ctypes.Structure):
+    """Mirror of `lmufft_lr_schedule` (include/lmufft.h)."""
+
+    _fields_ = [
+        ("lr0", ctypes.c_double),
+        ("max_lr", ctypes.c_double),
+        ("decay_rate", ctypes.c_double),
+        ("warmup_steps", ctypes.c_int32),
+        ("decay_steps", ctypes.c_int32),
+        ("scheduled", ctypes.c_int32),
     ]
 
 
@@ -167,6 +180,9 @@ def _load():
     lib.lmufft_adamw_step_f32.restype = ci
     lib.lmufft_adamw_step_f32.argtypes = [vp, vp, vp, vp, ctypes.c_int64] + [ctypes.c_float] * 5 + [
         ctypes.c_int32, vp, ctypes.c_float, vp]
+    lib.lmufft_adamw_step_clock_f32.restype = ci
+    lib.lmufft_adamw_step_clock_f32.argtypes = [vp, vp, vp, vp, ctypes.c_int64, vp, ctypes.POINTER(LrSchedule)] + [
+        ctypes.c_float] * 4 + [vp, ctypes.c_float, vp]
     lib.lmufft_profile_enable.restype = ci
     lib.lmufft_profile_enable.argtypes = [ci]
     lib.lmufft_profile_reset.restype = None
@@ -225,6 +241,7 @@ EXPORTS = (
     "lmufft_grad_norm_workspace_bytes",
     "lmufft_grad_norm2_f32",
     "lmufft_adamw_step_f32",
+    "lmufft_adamw_step_clock_f32",
     "lmufft_hprep_bytes",
     "lmufft_hprep_bf16",
     "lmufft_wprep_bytes",

@@ -116,6 +116,78 @@ __global__ __launch_bounds__(kOptThreads) void k_adamw(float* __restrict__ p, co
   }
 }
 
+// ---- the same step with its clock in device memory -----------------------------------------------------------------
+// A step replayed from a HIP graph cannot take the learning rate and the step count as launch arguments: they
+// are frozen at capture.  Here both live in a small device array the kernels advance themselves:
+//   clock[0]  scheduler steps taken        clock[1]  optimizer steps taken (a NaN norm does not count, as in the
+//   clock[2..5]  this step's {lr, 1 - b1^t, sqrt(1 - b2^t), clip coefficient or NaN = skip}, floats     reference)
+// k_opt_clock (one thread, double arithmetic like the host's) runs between the norm and the update.
+// The learning rate of optimizer step k is what the scheduler set after step k - 1 (the loop calls
+// optimizer.step() and then lr_scheduler.step(), src/training/distributed.py:229-234; the scheduler's formula:
+// src/training/utils.py:246-263): the constructor's rate for the first step, then
+//   s <= warmup: max_lr * s / warmup        else  max_lr * decay_rate ** ((s - warmup) // decay_steps),  s = k - 1.
+struct LrSchedule {
+  double lr0, max_lr, decay_rate;
+  int warmup_steps, decay_steps, scheduled;
+};
+
+__global__ void k_opt_clock(int* __restrict__ clock, LrSchedule sc, float beta1, float beta2, float max_norm,
+                            const float* __restrict__ norm2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float* f = reinterpret_cast<float*>(clock);
+  const int s = clock[0];
+  double lr = sc.lr0;
+  if (sc.scheduled && s > 0) {
+    if (s <= sc.warmup_steps)
+      lr = sc.max_lr * ((double)s / (double)sc.warmup_steps);
+    else
+      lr = sc.max_lr * pow(sc.decay_rate, (double)((s - sc.warmup_steps) / max(sc.decay_steps, 1)));
+  }
+  clock[0] = s + 1;
+  float coef = 1.f;
+  if (norm2) {
+    const float norm = sqrtf(norm2[0]);
+    coef = norm != norm ? norm : fminf(1.f, max_norm / (norm + 1e-6f));
+  }
+  int t = clock[1];
+  if (coef == coef) clock[1] = ++t;
+  f[2] = (float)lr;
+  f[3] = (float)(1.0 - pow((double)beta1, (double)t));
+  f[4] = (float)sqrt(1.0 - pow((double)beta2, (double)t));
+  f[5] = coef;
+}
+
+__global__ __launch_bounds__(kOptThreads) void k_adamw_clock(float* __restrict__ p, const float* __restrict__ g,
+                                                             float* __restrict__ m, float* __restrict__ v, long n,
+                                                             AdamW h, const int* __restrict__ clock) {
+  const float* f = reinterpret_cast<const float*>(clock);
+  const float coef = f[5];
+  if (coef != coef) return;  // NaN gradients: the step is skipped (uniform over the grid)
+  h.lr = f[2];
+  h.bc1 = f[3];
+  h.bc2_sqrt = f[4];
+  const long n4 = n >> 2;
+  float4* p4 = reinterpret_cast<float4*>(p);
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  float4* m4 = reinterpret_cast<float4*>(m);
+  float4* v4 = reinterpret_cast<float4*>(v);
+  for (long i = blockIdx.x * (long)kOptThreads + threadIdx.x; i < n4; i += (long)gridDim.x * kOptThreads) {
+    float4 pp = p4[i], mm = m4[i], vv = v4[i];
+    const float4 gg = g4[i];
+    adamw1(pp.x, gg.x, mm.x, vv.x, h, coef);
+    adamw1(pp.y, gg.y, mm.y, vv.y, h, coef);
+    adamw1(pp.z, gg.z, mm.z, vv.z, h, coef);
+    adamw1(pp.w, gg.w, mm.w, vv.w, h, coef);
+    p4[i] = pp;
+    m4[i] = mm;
+    v4[i] = vv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long i = (n4 << 2) + threadIdx.x;
+    adamw1(p[i], g[i], m[i], v[i], h, coef);
+  }
+}
+
 static inline bool al16p(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 static inline int opt_blocks(long n) {
   const long b = ((n >> 2) + kOptThreads - 1) / kOptThreads;
@@ -177,6 +249,39 @@ int lmufft_adamw_step_f32(float* params, const float* grads, float* exp_avg, flo
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error("launch of k_adamw failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
+int lmufft_adamw_step_clock_f32(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                int32_t* clock, const lmufft_lr_schedule* schedule, float beta1, float beta2, float eps,
+                                float weight_decay, const float* norm2, float max_norm, void* stream) {
+  if (n <= 0) return set_error("adamw: n = %lld", (long long)n);
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !clock || !schedule) return set_error("adamw: NULL pointer");
+  if (!(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f)) return set_error("adamw: betas must lie in [0, 1)");
+  if (norm2 && !(max_norm > 0.f)) return set_error("adamw: max_norm must be positive when a norm is given");
+  if (schedule->scheduled && (schedule->warmup_steps < 0 || schedule->decay_steps <= 0))
+    return set_error("adamw: schedule needs warmup_steps >= 0 and decay_steps > 0");
+  if (!al16p(params) || !al16p(grads) || !al16p(exp_avg) || !al16p(exp_avg_sq))
+    return set_error("adamw: the arenas must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  LrSchedule sc{schedule->lr0,          schedule->max_lr,      schedule->decay_rate,
+                schedule->warmup_steps, schedule->decay_steps, schedule->scheduled};
+  AdamW h;
+  h.lr = 0.f;
+  h.beta1 = beta1;
+  h.beta2 = beta2;
+  h.eps = eps;
+  h.wd = weight_decay;
+  h.bc1 = h.bc2_sqrt = 1.f;
+  h.max_norm = max_norm;
+  {
+    ProfScope ps("k_adamw", st);
+    hipLaunchKernelGGL(k_opt_clock, dim3(1), dim3(64), 0, st, clock, sc, beta1, beta2, max_norm, norm2);
+    hipLaunchKernelGGL(k_adamw_clock, dim3(opt_blocks(n)), dim3(kOptThreads), 0, st, params, grads, exp_avg, exp_avg_sq,
+                       (long)n, h, (const int*)clock);
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error("launch of k_adamw_clock failed: %s", hipGetErrorString(e));
   return 0;
 }
 

@@ -39,6 +39,9 @@ class LearningRateScheduler:
         self.decay_steps = decay_steps
         self.decay_rate = decay_rate
         self.step_count = 0
+        # an optimizer that keeps its clock on the device evaluates this rule there (FlatAdamW(device_clock=True))
+        if getattr(optimizer, "device_clock", False):
+            optimizer._attach_schedule(self)
 
     def step(self) -> float:
         self.step_count += 1
@@ -61,10 +64,19 @@ class FlatAdamW:
     the device -- unlike the reference, which then does not call optimizer.step(), the step counter
     still advances, since nothing is read back to the host.
     `param_groups[0]["lr"]` is read at every step, so LearningRateScheduler drives it unchanged.
+
+    `device_clock=True`: the step count and the learning rate live in device memory and the kernels advance
+    them themselves (lmufft_adamw_step_clock_f32), so that step() can be captured into a HIP graph and replayed:
+    launch arguments are frozen at capture, these are not.  A LearningRateScheduler built on such an optimizer
+    hands its rule to the device; its own step() then only keeps the host's copy of the count and the rate (for
+    logging) in step, and `param_groups[0]["lr"]` is no longer read.  An update skipped for a NaN norm does not
+    advance the optimizer's step count, as in the reference; `steps` on the host is then an upper bound and
+    `device_steps()` reads the true value back.
     """
 
     def __init__(self, params: Optional[Iterable[torch.nn.Parameter]] = None, lr: float = 1e-3, betas=(0.9, 0.999),
-                 eps: float = 1e-8, weight_decay: float = 1e-2, max_grad_norm: Optional[float] = None, buckets=None):
+                 eps: float = 1e-8, weight_decay: float = 1e-2, max_grad_norm: Optional[float] = None, buckets=None,
+                 device_clock: bool = False):
         if buckets is not None:
             if buckets.arena is None:
                 raise RuntimeError("FlatAdamW: the buckets do not share one arena (mixed dtypes or devices)")
@@ -110,6 +122,26 @@ class FlatAdamW:
         self.param_groups = [{"params": plist, "lr": lr, "betas": tuple(betas), "eps": eps,
                               "weight_decay": weight_decay}]
         self.steps = 0
+        self.device_clock = bool(device_clock)
+        self._clock = torch.zeros(8, dtype=torch.int32, device=dev) if device_clock else None
+        self._schedule = _lib.LrSchedule(float(lr), float(lr), 1.0, 0, 1, 0)
+
+    def _attach_schedule(self, sched) -> None:
+        if self.steps:
+            raise RuntimeError("FlatAdamW: attach the scheduler before the first step (the device clock has started)")
+        self._schedule = _lib.LrSchedule(float(self.param_groups[0]["lr"]), float(sched.max_lr), float(sched.decay_rate),
+                                         int(sched.warmup_steps), int(sched.decay_steps), 1)
+
+    def device_steps(self):
+        """(scheduler steps, optimizer steps) as the device counts them; synchronises."""
+        if self._clock is None:
+            return self.steps, self.steps
+        c = self._clock[:2].tolist()
+        return int(c[0]), int(c[1])
+
+    def device_lr(self) -> float:
+        """The learning rate the last device-clocked step used; synchronises."""
+        return float(self._clock[2:3].view(torch.float32).item())
 
     # -- the step -----------------------------------------------------------------------------
     def _stream(self):
@@ -133,12 +165,19 @@ class FlatAdamW:
                 rc = _lib.lib.lmufft_grad_norm2_f32(_ptr(self.grads), self.grads.numel(), _ptr(self._norm2),
                                                     _ptr(self._ws), self._ws.numel(), self._stream())
                 _lib.check(rc, "lmufft_grad_norm2_f32")
-            rc = _lib.lib.lmufft_adamw_step_f32(_ptr(self.flat), _ptr(self.grads), _ptr(self.exp_avg),
-                                                _ptr(self.exp_avg_sq), self.flat.numel(), float(g["lr"]),
-                                                float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
-                                                float(g["weight_decay"]), self.steps,
-                                                _ptr(self._norm2) if clip else None,
-                                                float(self.max_grad_norm) if clip else 0.0, self._stream())
+            if self.device_clock:
+                rc = _lib.lib.lmufft_adamw_step_clock_f32(
+                    _ptr(self.flat), _ptr(self.grads), _ptr(self.exp_avg), _ptr(self.exp_avg_sq), self.flat.numel(),
+                    _ptr(self._clock), ctypes.byref(self._schedule), float(g["betas"][0]), float(g["betas"][1]),
+                    float(g["eps"]), float(g["weight_decay"]), _ptr(self._norm2) if clip else None,
+                    float(self.max_grad_norm) if clip else 0.0, self._stream())
+            else:
+                rc = _lib.lib.lmufft_adamw_step_f32(_ptr(self.flat), _ptr(self.grads), _ptr(self.exp_avg),
+                                                    _ptr(self.exp_avg_sq), self.flat.numel(), float(g["lr"]),
+                                                    float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                                    float(g["weight_decay"]), self.steps,
+                                                    _ptr(self._norm2) if clip else None,
+                                                    float(self.max_grad_norm) if clip else 0.0, self._stream())
         _lib.check(rc, "lmufft_adamw_step_f32")
         # the kernel wrote through raw pointers: tell autograd (and caches keyed on `_version`) so
         torch._C._increment_version(self.params)
@@ -150,10 +189,11 @@ class FlatAdamW:
     # -- checkpoints: the layout torch.optim.AdamW writes (src/training/utils.py:328-334 stores it) --
     def state_dict(self) -> dict:
         state = {}
-        if self.steps:
+        steps = self.device_steps()[1] if self.device_clock else self.steps
+        if steps:
             for i, (p, off) in enumerate(zip(self.params, self._offsets)):
                 sl = slice(off, off + p.numel())
-                state[i] = {"step": torch.tensor(float(self.steps)),
+                state[i] = {"step": torch.tensor(float(steps)),
                             "exp_avg": self.exp_avg[sl].view_as(p).clone(),
                             "exp_avg_sq": self.exp_avg_sq[sl].view_as(p).clone()}
         g = self.param_groups[0]
@@ -185,3 +225,12 @@ class FlatAdamW:
             raise ValueError(f"FlatAdamW: parameters at different step counts {sorted(steps)}; one flat step "
                              "cannot continue them")
         self.steps = steps.pop() if steps else 0
+        if self._clock is not None:
+            # the scheduler's count is not part of AdamW's state: the loop restores it (set_scheduler_steps)
+            self._clock[1:2].fill_(self.steps)
+
+    def set_scheduler_steps(self, n: int) -> None:
+        """Device clock: continue the learning-rate rule from `n` scheduler steps (`LearningRateScheduler.step_count`,
+        src/training/utils.py:246-250), e.g. after a checkpoint restore."""
+        if self._clock is not None:
+            self._clock[0:1].fill_(int(n))

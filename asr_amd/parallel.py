@@ -116,6 +116,9 @@ class GradBuckets:
         # run the collectives even in a one-rank group (they change nothing there; used to exercise the
         # RCCL stream hand-over on a single GPU)
         self.exchange_single_rank = exchange_single_rank
+        # False: every step runs as on a single rank -- no collective is issued (used to time a step without its
+        # exchange beside the same step with it; the gradients are then NOT synchronised)
+        self.exchange_enabled = True
         self.buckets: List[torch.Tensor] = []
         self._params: List[List[torch.nn.Parameter]] = []
         self._views: List[List[torch.Tensor]] = []
@@ -195,7 +198,7 @@ class GradBuckets:
 
     # -- bookkeeping ------------------------------------------------------------------------
     def _distributed(self) -> bool:
-        if not (dist.is_available() and dist.is_initialized()):
+        if not self.exchange_enabled or not (dist.is_available() and dist.is_initialized()):
             return False
         return dist.get_world_size(self.group) > 1 or self.exchange_single_rank
 
@@ -396,7 +399,7 @@ class GradBuckets:
 
         return step
 
-    def capture_graph_exchange(self, fns: Sequence[Callable], overlap: bool = True):
+    def capture_graph_exchange(self, fns: Sequence[Callable], overlap: bool = True, after: Callable = None):
         """Capture the whole step -- the segments fns[0], fns[1], ... AND its all-reduces -- into ONE HIP graph;
         the returned step() is a single replay with no Python and no host-side launch in it.
 
@@ -407,6 +410,8 @@ class GradBuckets:
         the same collectives from the host between its segment graphs, which costs a short step more than the
         exchange can hide (three stacked layers, batch 64 x 400 frames, one rank with the RCCL path on: 0.392 ms
         without exchange, 0.474 ms with per-bucket host launches, 0.420 ms with one host launch per step).
+        `after`, if given, is captured behind the exchange -- the optimizer step of a whole training step (one whose
+        learning rate and step count live in device memory: FlatAdamW(device_clock=True)).
         Same preconditions as capture_pipeline.  Every rank must capture and replay the same sequence.
         Dropout inside the step: its seeds are frozen at capture; the graph's first node increments the device's
         dropout epoch counter, which the kernels add to the seeds when they run, so replays draw fresh masks."""
@@ -421,6 +426,8 @@ class GradBuckets:
                 for fn in fns:
                     fn()
                 self.finish()  # launches what is left and waits: the waits become the graph's joins
+                if after is not None:
+                    after()
         finally:
             self.overlap = saved
         self._graphs = [graph]

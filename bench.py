@@ -77,6 +77,9 @@ def parse_args():
     ap.add_argument("--async-wgrad", action="store_true",
                     help="run every layer's parameter gradients on a side stream, beside the backward of the layers below")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="one rank: skip the batch sweep (256 and 1024 utterances) and the whole-model sub-object that "
+                         "the default run appends to its line after the timed region")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying HIP graphs")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -302,7 +305,7 @@ def bench_conv(args, dev):
     }
 
 
-def bench_full_step(args, dev, rank, world):
+def bench_full_step(args, dev, rank, world, steps=None, warmup=None):
     """The reference's whole training step at its single-GPU configuration: mel-shaped input -> 3-layer encoder
     (attention, LMUFFT, layer norm, dropout 0.1) -> CTC head and loss -> backward -> clip 10 -> AdamW -> scheduler
     (configs/base_config.yaml:3-15, 29-36; src/training/distributed.py:139-234), bf16 autocast.  This package's
@@ -318,6 +321,8 @@ def bench_full_step(args, dev, rank, world):
     from asr_amd.parallel import GradBuckets
 
     B, T = args.batch, args.frames
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     torch.manual_seed(1234)
     model = LMUASRModel(80, args.hidden, args.memory, args.layers, args.theta, T, 34, num_attention_heads=6,
                         dropout=0.1).to(dev).train()
@@ -328,30 +333,37 @@ def bench_full_step(args, dev, rank, world):
     enc = model.encoder
     enc.bf16_stream = bool(args.bf16_stream)
     buckets = GradBuckets(model.bucket_groups(), bucket_mb=args.bucket_mb if args.bucket_mb is not None else 4.0,
-                          overlap=not args.no_overlap)
-    opt = FlatAdamW(buckets=buckets, lr=1.5e-3, betas=(0.9, 0.999), weight_decay=0.01, max_grad_norm=10.0)
+                          overlap=not args.no_overlap, exchange_single_rank=args.exchange_single_rank)
+    # the step count and the learning rate live in device memory, so that the whole step -- optimizer and
+    # scheduler included -- can be one HIP graph
+    opt = FlatAdamW(buckets=buckets, lr=1.5e-3, betas=(0.9, 0.999), weight_decay=0.01, max_grad_norm=10.0,
+                    device_clock=True)
     sched = LearningRateScheduler(opt, warmup_steps=1500, max_lr=1.5e-3)
     g = torch.Generator(device=dev).manual_seed(1234 + 2 + rank)
     spec = torch.randn(B, T, 80, device=dev, generator=g)
     in_len = torch.full((B,), T, dtype=torch.long, device=dev)
     tgt_len = torch.randint(20, 61, (B,), device=dev, generator=g)
     targets = torch.randint(0, 33, (B, 60), device=dev, generator=g)
-    # The data loader hands out the lengths on the host; torch's CTC loss wants them there (device tensors are
-    # read back, a synchronisation per step).  The total is known there too: the step makes no read-back.
-    in_len_host, tgt_len_host = in_len.cpu(), tgt_len.cpu()
-    total = int(tgt_len_host.sum())
+    # The lengths stay on the device (the CTC kernel reads them there): the step makes no host-to-device copy and
+    # no read-back.
+    in_len32, tgt_len32 = in_len.to(torch.int32), tgt_len.to(torch.int32)
     losses = []
+    out = {}
 
-    def step():
-        buckets.zero_grad()
+    def forward_backward():
         with torch.autocast("cuda", dtype=torch.bfloat16):
             lp = model.log_probs_for_training(spec, in_len)
-        loss = model.compute_loss(lp, targets, in_len_host, tgt_len_host, total)
+        loss = model.compute_loss(lp, targets, in_len32, tgt_len32)
         loss.backward()
+        out["loss"] = loss.detach()
+
+    def step_eager():
+        buckets.zero_grad()
+        forward_backward()
         buckets.finish()
         opt.step()
         sched.step()
-        return loss
+        return out["loss"]
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -359,25 +371,52 @@ def bench_full_step(args, dev, rank, world):
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        losses.append(step())
+    step = step_eager
+    launch = "eager launches"
+    for _ in range(max(3, warmup if args.no_graph else 3)):
+        losses.append(step_eager().clone())
+    if not args.no_graph:
+        # forward, loss, backward, gradient exchange, clipping, AdamW and the scheduler's rule as ONE HIP graph:
+        # a step is one replay, with no Python and no host-side launch in it
+        torch.cuda.synchronize(dev)
+        out.clear()
+        try:
+            replay = buckets.capture_graph_exchange([forward_backward], overlap=not args.no_overlap, after=opt.step)
+            launch = "one hip graph (forward, CTC loss, backward, exchange, clip, AdamW, scheduler)"
+
+            def step():
+                replay()
+                sched.step()  # host copy of the count, for logging; the device evaluates the rule itself
+                return out["loss"]
+        except Exception as e:
+            print(f"[bench] capturing the whole step failed ({type(e).__name__}: {e}); launching eagerly", file=sys.stderr)
+            torch.cuda.synchronize(dev)
+            buckets._replay = False
+            step = step_eager
+        for _ in range(warmup):
+            losses.append(step().clone())
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        losses.append(step())
+    for _ in range(steps):
+        step()
     sync()
     elapsed = time.perf_counter() - t0
+    losses.append(out["loss"].clone())
+    rank_ms = [elapsed / steps * 1e3] * 2
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed, -elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        rank_ms = [-float(tt[1]) / steps * 1e3, float(tt[0]) / steps * 1e3]
+        elapsed = float(tt[0])
     per_kernel = {}
-    psteps = min(args.steps, 5)
+    psteps = min(steps, 5)
+    buckets._replay = False
+    out.clear()  # no autograd graph of the captured step may stay alive into the eager steps (stream of its nodes)
     if rank == 0:
         _lib.profile_reset()
         _lib.profile_enable(True)
     for _ in range(psteps):
-        step()
+        step_eager()
     torch.cuda.synchronize(dev)
     if rank == 0:
         _lib.profile_enable(False)
@@ -386,7 +425,7 @@ def bench_full_step(args, dev, rank, world):
         from torch.profiler import ProfilerActivity, profile
         with profile(activities=[ProfilerActivity.CUDA]) as prof:
             for _ in range(psteps):
-                step()
+                step_eager()
             torch.cuda.synchronize(dev)
         rows = sorted(prof.key_averages(), key=lambda r: -r.self_device_time_total)
         tot = sum(r.self_device_time_total for r in rows)
@@ -419,12 +458,14 @@ def bench_full_step(args, dev, rank, world):
                                 "are priced at the 384 -> 384 layer")
     return {
         "metric": "full train step frames/sec (whole model, hot path swapped in)",
-        "value": world * B * T / (elapsed / args.steps), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "value": world * B * T / (elapsed / steps), "unit": "frames/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"3-layer LMU ASR model (80 -> {args.hidden}/{args.memory}, 6 heads, vocab 34, dropout 0.1, "
                                f"seq_len {T}), batch {B} per GPU, bf16 autocast: forward + CTC loss + backward + clip 10 + "
-                               "AdamW(1.5e-3, wd 0.01) + warm-up scheduler, eager launches",
+                               "AdamW(1.5e-3, wd 0.01) + warm-up scheduler",
+                   "launch": launch, "rank_ms_per_step_min_max": rank_ms,
+                   "optimizer_steps_on_device": list(opt.device_steps()), "learning_rate_on_device": opt.device_lr(),
                    "batch_per_gpu": B, "frames": T, "parallelism": f"dp{world}", "world_size": world,
                    "hip_kernels": "LMUFFT, attention, Linear (incl. vocabulary projection), layer norm + dropout (forward "
                                   "and backward), CTC loss + gradient, gradient norm + clip + AdamW",
@@ -459,53 +500,16 @@ def emit(obj) -> None:
         os.write(_RESULT_FD, line)
 
 
-def main():
-    args = parse_args()
-    world_env = os.environ.get("WORLD_SIZE")
-    if args.gpus > 1 and world_env is None:
-        raise SystemExit(spawn_ranks(args))
-    keep_stdout_for_the_result()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(world_env or "1")
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
-
+def bench_layer_stack(args, dev, rank, world, batch, steps, warmup, detail=True):
+    """Forward + backward of the stack of LMUFFT layers with its gradient exchange, at `batch` utterances per GPU.
+    Returns the result object on rank 0 (None elsewhere) and the first layer's H."""
     import torch
     import torch.distributed as dist
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the LMUFFT layer has no CPU path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if args.unit == "conv":
-        emit(bench_conv(args, dev))
-        return
-    if world == 1 and args.exchange_single_rank:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
-        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
-        if dist.get_world_size() != args.gpus or dist.get_backend() != "nccl":
-            raise SystemExit(f"process group has {dist.get_world_size()} ranks on {dist.get_backend()}, "
-                             f"expected {args.gpus} on nccl")
-
-    if args.workload == "c2_full":
-        out = bench_full_step(args, dev, rank, world)
-        if rank == 0:
-            emit(out)
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
 
     from asr_amd import LMUFFT, _lib
     from asr_amd.parallel import GradBuckets
 
-    B, T, D, M, Hd = args.batch, args.frames, args.hidden, args.memory, args.hidden
+    B, T, D, M, Hd = batch, args.frames, args.hidden, args.memory, args.hidden
     torch.manual_seed(1234)  # identical parameters on every rank
     layers = []
     for _ in range(args.layers):
@@ -564,7 +568,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for _ in range(max(1, args.warmup if args.no_graph else 3)):
+    for _ in range(max(1, warmup if args.no_graph else 3)):
         step_eager()
     if not args.no_graph:
         # the step replayed from HIP graphs: it is ~30 short kernels, and launching them one by one
@@ -593,23 +597,62 @@ def main():
             print(f"[bench] HIP graph capture failed ({type(e).__name__}: {e}); launching eagerly", file=sys.stderr)
             args.no_graph = True
             torch.cuda.synchronize(dev)
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             step()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     sync()
     elapsed = time.perf_counter() - t0
+    rank_ms = [elapsed / steps * 1e3] * 2
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed, -elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        rank_ms = [-float(tt[1]) / steps * 1e3, float(tt[0]) / steps * 1e3]
+        elapsed = float(tt[0])
+
+    # What the exchange costs the step where it cannot hide: the same step captured again WITHOUT its collectives
+    # (every rank on its own; the gradients are not synchronised in these untimed-for-the-metric steps), timed the
+    # same way.  exposed = step with exchange - slowest rank's step without.
+    exchange = None
+    if detail and buckets._distributed() and not args.no_graph:
+        buckets.exchange_enabled = False
+        try:
+            torch.cuda.synchronize(dev)
+            st.clear()
+            x.grad = None
+            solo = buckets.capture_graph_exchange(segments, overlap=overlap)
+            nsolo = max(10, min(steps, 100))
+            for _ in range(5):
+                solo()
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(nsolo):
+                solo()
+            torch.cuda.synchronize(dev)
+            mine = (time.perf_counter() - t1) / nsolo * 1e3
+            solo_ms = [mine, mine]
+            if world > 1:
+                tt = torch.tensor([mine, -mine], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                solo_ms = [-float(tt[1]), float(tt[0])]
+            exchange = {"ms_per_step_without_exchange_min_max_over_ranks": solo_ms,
+                        "exposed_exchange_ms": elapsed / steps * 1e3 - solo_ms[1], "steps": nsolo}
+        except Exception as e:
+            print(f"[bench] the step without exchange could not be captured ({type(e).__name__}: {e})", file=sys.stderr)
+            torch.cuda.synchronize(dev)
+        finally:
+            buckets.exchange_enabled = True
 
     # second, untimed pass with event brackets around every kernel launch
     # (every rank runs it -- the steps contain collectives -- but only rank 0 records events)
     per_kernel = {}
-    psteps = min(args.steps, 10)
+    psteps = min(steps, 10)
+    # no autograd graph of the captured steps may stay alive into the eager ones: its gradient-accumulation nodes
+    # belong to the capture's stream
+    st.clear()
+    x.grad = None
     if rank == 0:
         _lib.profile_reset()
         _lib.profile_enable(True)
@@ -624,8 +667,8 @@ def main():
         dist.barrier()
 
     if rank == 0:
-        ms_step = elapsed / args.steps * 1e3
-        value = world * B * T / (elapsed / args.steps)
+        ms_step = elapsed / steps * 1e3
+        value = world * B * T / (elapsed / steps)
         dom = max(per_kernel, key=lambda k: per_kernel[k]["total_ms_per_step"]) if per_kernel else None
         roofline = None
         if dom and kernel_work(dom, B, T, D, M, Hd, esize):
@@ -639,8 +682,8 @@ def main():
             "value": value,
             "unit": "frames/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
+            "steps": steps,
+            "warmup": warmup,
             "ms_per_step": ms_step,
             "higher_is_better": True,
             "scaling": "weak",
@@ -660,16 +703,88 @@ def main():
                 "bucket_mb": [round(b.numel() * 4 / (1 << 20), 3) for b in buckets.buckets],
                 "exchange": "per bucket, behind the remaining backward segments" if overlap else "one all-reduce after the backward",
                 "launch": "eager" if args.no_graph else (launch_mode or f"hip graph replay ({len(segments)} segments)"),
+                # wall clock of the timed steps on the fastest and the slowest rank (barriers on both sides)
+                "rank_ms_per_step_min_max": rank_ms,
+                "exchange_cost": exchange,
             },
             "roofline": roofline,
             "step_hbm": {"algorithmic_bytes_per_step": layer_bytes,
-                         "achieved_GBs_wall": layer_bytes / (elapsed / args.steps) / 1e9,
+                         "achieved_GBs_wall": layer_bytes / (elapsed / steps) / 1e9,
                          "achieved_GBs_kernels": layer_bytes / t_kern / 1e9 if t_kern else None,
-                         "frac_of_peak_wall": layer_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
+                         "frac_of_peak_wall": layer_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS},
             "kernels": per_kernel,
         }
+    H = layers[0].H
+    buckets.remove()
+    return (out if rank == 0 else None), H
+
+
+def main():
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        raise SystemExit(spawn_ranks(args))
+    keep_stdout_for_the_result()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(world_env or "1")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
+
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the LMUFFT layer has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if args.unit == "conv":
+        emit(bench_conv(args, dev))
+        return
+    if world == 1 and args.exchange_single_rank:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+        if dist.get_world_size() != args.gpus or dist.get_backend() != "nccl":
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks on {dist.get_backend()}, "
+                             f"expected {args.gpus} on nccl")
+
+    if args.workload == "c2_full":
+        out = bench_full_step(args, dev, rank, world)
+        if rank == 0:
+            emit(out)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    out, H = bench_layer_stack(args, dev, rank, world, args.batch, args.steps, args.warmup)
+    if rank == 0:
+        if world == 1 and not args.no_extras:
+            # The same step at larger batches (more workgroups per CU: kernel efficiency apart from the
+            # one-tile-per-CU fill regime of batch 64), and the whole model's train step; both short, after the
+            # timed region
+            sweep = []
+            for bsz in (256, 1024):
+                sub, _ = bench_layer_stack(args, dev, rank, world, bsz, 40, 5, detail=False)
+                sweep.append({"batch_per_gpu": bsz, "ms_per_step": sub["ms_per_step"], "value": sub["value"],
+                              "frac_of_peak_wall": sub["step_hbm"]["frac_of_peak_wall"],
+                              "kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in sub["kernels"].items()}})
+                del sub
+                torch.cuda.empty_cache()
+            out["batch_sweep"] = sweep
+            if args.workload == "c2_lmu" and args.dtype == "bf16":
+                full = bench_full_step(args, dev, rank, world, steps=60, warmup=10)
+                out["c2_full"] = {k: full[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup",
+                                                      "hip_kernel_ms_per_step", "loss_first_last")}
+                out["c2_full"]["launch"] = full["config"]["launch"]
+                out["c2_full"]["workload"] = full["config"]["workload"]
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args, layers[0].H, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(args, H, args.cpu_seconds)
         emit(out)
     if world > 1:
         dist.barrier()

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMUFFT_ABI_VERSION 19
+#define LMUFFT_ABI_VERSION 20
 
 /* element types of the activations (x, h, gh, gx, m) */
 #define LMUFFT_F32 0
@@ -445,6 +445,30 @@ int lmufft_adamw_step_f32(float* params, const float* grads, float* exp_avg, flo
                           int64_t n, float lr, float beta1, float beta2, float eps,
                           float weight_decay, int32_t step, const float* norm2, float max_norm,
                           void* stream);
+
+/* The same update with its clock in device memory, for steps replayed from a HIP graph (launch arguments
+ * are frozen at capture; the learning rate and the step count must not be).
+ *   clock: 8 int32 on the device, zeroed once by the caller and then owned by this call:
+ *     [0] scheduler steps taken, [1] optimizer steps taken (a step skipped for a NaN norm does not count, as
+ *     the reference does not call optimizer.step() then, src/training/distributed.py:222-231), [2..5] the
+ *     current step's learning rate, bias corrections and clip coefficient as floats (for monitoring).
+ *   schedule (host memory, read during the call): the warm-up / staircase-decay rule of
+ *     LearningRateScheduler.step, src/training/utils.py:246-263, evaluated on the device in double.  The rate
+ *     of optimizer step k is the one the scheduler set after step k - 1 -- the loop calls optimizer.step(),
+ *     then lr_scheduler.step() (src/training/distributed.py:229-234) -- i.e. lr0 for the first step.
+ *     scheduled == 0: lr0 at every step. */
+typedef struct lmufft_lr_schedule {
+  double lr0;           /* the optimizer's constructor rate */
+  double max_lr;
+  double decay_rate;
+  int32_t warmup_steps;
+  int32_t decay_steps;
+  int32_t scheduled;
+} lmufft_lr_schedule;
+int lmufft_adamw_step_clock_f32(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                                int64_t n, int32_t* clock, const lmufft_lr_schedule* schedule,
+                                float beta1, float beta2, float eps, float weight_decay,
+                                const float* norm2, float max_norm, void* stream);
 
 /* ------------------------------------------------------------------------
  * Masked self-attention core for inference.  Replaces the score / softmax /

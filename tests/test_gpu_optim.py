@@ -109,6 +109,65 @@ def test_nan_gradient_skips_update_and_state_dict_round_trips_through_torch():
         assert torch.allclose(p.detach(), q.detach(), rtol=2e-6, atol=2e-7)
 
 
+def test_device_clock_follows_the_reference_loop_and_replays_from_a_graph():
+    """FlatAdamW(device_clock=True): learning rate and step count live on the device (lmufft_adamw_step_clock_f32).
+    Against the float64 oracle run the way the reference's loop runs it (src/training/distributed.py:207-234:
+    optimizer.step() with the rate the scheduler set after the previous step, no optimizer.step() on a NaN norm,
+    lr_scheduler.step() every iteration); bit-equal to the host-clocked optimizer while no step is skipped; and the
+    same sequence again as replays of ONE captured step -- nothing of the clock is frozen in the graph."""
+    from asr_amd.optim import FlatAdamW, LearningRateScheduler
+
+    dev = _dev()
+    host, params = _make(SHAPES, 31, dev)
+    _, params_h = _make(SHAPES, 31, dev)
+    _, params_g = _make(SHAPES, 31, dev)
+    kw = dict(lr=1.5e-3, weight_decay=0.01, max_grad_norm=0.5)
+    opt = FlatAdamW(params, device_clock=True, **kw)
+    sch = LearningRateScheduler(opt, warmup_steps=3, max_lr=2e-3, decay_steps=2, decay_rate=0.9)
+    opt_h = FlatAdamW(params_h, **kw)
+    sch_h = LearningRateScheduler(opt_h, warmup_steps=3, max_lr=2e-3, decay_steps=2, decay_rate=0.9)
+    opt_g = FlatAdamW(params_g, device_clock=True, **kw)
+    LearningRateScheduler(opt_g, warmup_steps=3, max_lr=2e-3, decay_steps=2, decay_rate=0.9)
+    # the graph: one optimizer step on whatever the gradient arena holds
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        opt_g.step()
+    ref = [h.double().numpy().copy() for h in host]
+    m = [np.zeros_like(r) for r in ref]
+    v = [np.zeros_like(r) for r in ref]
+    g = torch.Generator().manual_seed(32)
+    lr, t_adam, steps, nan_at = 1.5e-3, 0, 9, 5
+    for it in range(1, steps + 1):
+        grads = [torch.randn(s, generator=g) * 2 for s in SHAPES]
+        if it == nan_at:
+            grads[1][7] = float("nan")
+        for o in (opt, opt_h, opt_g):
+            o.zero_grad()
+            for p, x in zip(o.params, grads):
+                p.grad.add_(x.to(dev))
+        opt.step()
+        opt_h.step()
+        graph.replay()
+        if it != nan_at:
+            t_adam += 1
+            oo.adamw_step(ref, [x.double().numpy() for x in grads], m, v, t_adam, lr, weight_decay=0.01, max_grad_norm=0.5)
+        assert opt.device_lr() == np.float32(lr) == opt_g.device_lr()
+        lr = sch.step()
+        assert lr == sch_h.step() == oo.scheduled_lr(it, 3, 2e-3, 2, 0.9)
+        if it < nan_at:  # the host clock counts the skipped step, so the two part ways there (by design)
+            for p, q in zip(params, params_h):
+                assert torch.equal(p.detach(), q.detach())
+        for p, q in zip(params, params_g):
+            assert torch.equal(p.detach(), q.detach())
+    assert opt.device_steps() == (steps, steps - 1) == opt_g.device_steps()
+    for p, r in zip(params, ref):
+        got = p.detach().cpu().double().numpy()
+        assert np.all(np.abs(got - r) <= 2e-6 * np.abs(r) + 2e-7 * steps), float(np.abs(got - r).max())
+    assert float(opt.state_dict()["state"][0]["step"]) == steps - 1
+
+
 def test_flat_adamw_on_the_bucket_arena_trains_a_layer():
     """FlatAdamW adopts the gradient arena of GradBuckets (the LMUFFT kernels write their parameter gradients
     straight into it): ten steps on a small layer lower the loss, and match torch.optim.AdamW on a twin layer
