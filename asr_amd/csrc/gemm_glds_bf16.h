@@ -185,14 +185,16 @@ __device__ __forceinline__ void gemm_loop_glds_deep(const OA& a, const OB& b, f3
 // sees 16-byte stores of whole row segments instead of 2-byte column stores.
 //   value(tm, tn, i, m, n, v)  -> float to store for tile-local (m, n)
 //   out[(row0 + m) * ld + col0 + n], 0 <= rows < row_limit (row0 may be negative), cols < col_limit,
-//   col_limit % 8 == 0 and 16-byte aligned rows (the caller checks); out == NULL: only the LDS image.
+//   col_limit % 8 == 0 and 16-byte aligned rows (the caller checks); out == NULL: only the LDS image;
+//   row_first: rows below it are not stored either.
 // `lds` needs BM * (BN + 8) * 2 bytes.  Returns with the tile still in LDS
 // (image [BM][BN + 8]) so that callers can copy rows out of it again.
 //   chunk(row, col, v) is called by the lane that stores the 8 elements v to out[row][col .. col + 8)
 template <class T, class V, class C>
 __device__ __forceinline__ void store_tile_bf16(const f32x16 (&acc)[T::TM][T::TN], const WavePos<T>& w,
                                                 bf16_t* lds, bf16_t* __restrict__ out, long ld, long row0,
-                                                int col0, long row_limit, int col_limit, V&& value, C&& chunk) {
+                                                int col0, long row_limit, int col_limit, V&& value, C&& chunk,
+                                                long row_first = 0) {
   constexpr int LDT = T::BN + 8;
   tile_epilogue_ix<T>(acc, w, [&](int tm, int tn, int i, int m, int n, float v) {
     lds[m * LDT + n] = (bf16_t)value(tm, tn, i, m, n, v);
@@ -203,7 +205,7 @@ __device__ __forceinline__ void store_tile_bf16(const f32x16 (&acc)[T::TM][T::TN
     const int m = idx / CH, c = idx % CH;
     const long row = row0 + m;
     const int col = col0 + c * 8;
-    if (out && row >= 0 && row < row_limit && col < col_limit) {
+    if (out && row >= row_first && row < row_limit && col < col_limit) {
       const bf16x8 v = *reinterpret_cast<const bf16x8*>(&lds[m * LDT + c * 8]);
       *reinterpret_cast<bf16x8*>(out + row * ld + col) = v;
       chunk(row, col, v);

@@ -357,6 +357,100 @@ struct LnEpilogue {  // y == NULL: none
   void* y;
   int y_bf16;
 };
+// Epilogue of the projection: h = relu(acc + b_h) through LDS as whole row segments, the relu bit mask, h_n and the
+// optional layer norm.  Tile row 0 is global row m0 (= utterance * T + frame; may lie before the rows the workgroup
+// owns); rows in [row_begin, row_end) are stored.  The loop has ended with a barrier: all of LDS is free.
+template <class TL>
+__device__ __forceinline__ void proj_epilogue(const f32x16 (&acc)[TL::TM][TL::TN], const WavePos<TL>& w,
+                                              unsigned char* smem_raw, const float* __restrict__ bias,
+                                              bf16_t* __restrict__ h, bf16_t* __restrict__ h_n,
+                                              unsigned char* __restrict__ hmask, const LnEpilogue& ln, long m0,
+                                              long row_begin, long row_end, int T, int Hd, int n0) {
+  float bcol[TL::TN];
+  preload_cols<TL>(bcol, w, [&](int nn) { return load_or_zero(bias + n0 + nn, n0 + nn < Hd); });
+  bf16_t* tile = reinterpret_cast<bf16_t*>(smem_raw);
+  // relu pattern for the backward, one bit per element: hmask[row][Hd / 8] bytes, bit j of byte c = h[row][8 c + j] > 0,
+  // written by the lane that stores those 8 elements (the backward then reads 1/16 of the bytes of h to mask the
+  // upstream gradient)
+  const int CHM = Hd / 8;
+  store_tile_bf16<TL>(
+      acc, w, tile, h, Hd, m0, n0, row_end, Hd,
+      [&](int, int tn, int, int, int, float v) { return fmaxf(v + bcol[tn], 0.f); },
+      [&](long row, int col, const bf16x8& v) {
+        if (hmask) {
+          unsigned bits = 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bits |= ((float)v[j] > 0.f ? 1u : 0u) << j;
+          hmask[row * CHM + (col >> 3)] = (unsigned char)bits;
+        }
+      },
+      row_begin);
+  // h_n: the last frame of every utterance that ends inside this row tile (tile still in LDS)
+  constexpr int LDT = TL::BN + 8;
+  for (long rl = (row_begin / T) * T + T - 1; rl < row_end; rl += T) {
+    const int ml = (int)(rl - m0);
+    for (int c = threadIdx.x; c < TL::BN / 8; c += TL::THREADS) {
+      const int col = n0 + c * 8;
+      if (col < Hd)
+        *reinterpret_cast<bf16x8*>(h_n + (rl / T) * Hd + col) = *reinterpret_cast<const bf16x8*>(&tile[ml * LDT + c * 8]);
+    }
+  }
+  // Layer norm of the rows of h that follows the layer in the encoder (src/models/lmu_encoder.py:274),
+  // taken from the bf16 tile still in LDS -- the same bf16-rounded h a separate layer-norm kernel
+  // would read back from HBM; the tile spans the whole row (the host checks Hd <= BN).  Four lanes
+  // share a row: fp32 mean, centred second moment, two shuffles each.
+  if (ln.y) {
+    const int rl = threadIdx.x >> 2, q = threadIdx.x & 3;
+    static_assert(TL::THREADS == 4 * TL::BM, "four lanes per tile row");
+    const long row = m0 + rl;
+    const int chunks = Hd / 8;
+    float s = 0.f;
+    for (int c = q; c < chunks; c += 4) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(&tile[rl * LDT + c * 8]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (float)v[j];
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    const float mean = s / (float)Hd;
+    float ss = 0.f;
+    for (int c = q; c < chunks; c += 4) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(&tile[rl * LDT + c * 8]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = (float)v[j] - mean;
+        ss += d * d;
+      }
+    }
+    ss += __shfl_xor(ss, 1);
+    ss += __shfl_xor(ss, 2);
+    const float rstd = rsqrtf(ss / (float)Hd + ln.eps);
+    if (row >= row_begin && row < row_end) {
+      for (int c = q; c < chunks; c += 4) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(&tile[rl * LDT + c * 8]);
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(ln.gamma + c * 8);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(ln.gamma + c * 8 + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(ln.beta + c * 8);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(ln.beta + c * 8 + 4);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          o[j] = ((float)v[j] - mean) * rstd * (j < 4 ? g0[j] : g1[j - 4]) + (j < 4 ? b0[j] : b1[j - 4]);
+        if (ln.y_bf16) {
+          bf16x8 ob;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ob[j] = (bf16_t)o[j];
+          *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(ln.y) + row * Hd + c * 8) = ob;
+        } else {
+          float* yp = reinterpret_cast<float*>(ln.y) + row * Hd + c * 8;
+          *reinterpret_cast<f32x4*>(yp) = f32x4{o[0], o[1], o[2], o[3]};
+          *reinterpret_cast<f32x4*>(yp + 4) = f32x4{o[4], o[5], o[6], o[7]};
+        }
+      }
+    }
+  }
+}
+
 constexpr int kProjStages = 2;
 
 __global__ __launch_bounds__(ProjGldsTile::THREADS) void k_proj_fwd_glds_bf16(
@@ -399,90 +493,217 @@ __global__ __launch_bounds__(ProjGldsTile::THREADS) void k_proj_fwd_glds_bf16(
   gemm_loop_glds<TL>(oa, ob, acc, 0, K, w);
   LMUFFT_STAMP(4, 1);
 
-  float bcol[TL::TN];
-  preload_cols<TL>(bcol, w, [&](int nn) { return load_or_zero(bias + n0 + nn, n0 + nn < Hd); });
-  bf16_t* tile = reinterpret_cast<bf16_t*>(smem_raw);
-  // relu pattern for the backward, one bit per element: hmask[row][Hd / 8] bytes, bit j of byte c = h[row][8 c + j] > 0,
-  // written by the lane that stores those 8 elements (the backward then reads 1/16 of the bytes of h to mask the
-  // upstream gradient)
-  const int CHM = Hd / 8;
-  store_tile_bf16<TL>(
-      acc, w, tile, h, Hd, m0, n0, rows, Hd,
-      [&](int, int tn, int, int, int, float v) { return fmaxf(v + bcol[tn], 0.f); },
-      [&](long row, int col, const bf16x8& v) {
-        if (hmask) {
-          unsigned bits = 0;
+  proj_epilogue<TL>(acc, w, smem_raw, bias, h, h_n, hmask, ln, m0, m0, min((long)rows, m0 + TL::BM), T, Hd, n0);
+}
+
+// ---------------------------------------------------------------------------
+// Convolution and projection in ONE kernel: the m tile of a workgroup's frames is formed in LDS by the
+// Toeplitz GEMM and the projection reads it from there as the first k-tiles of its A operand.  m is
+// still written (the backward reads it) but never read back, and one launch with its ramp-up and tail
+// is gone: at batch 64 x 400 frames the two kernels took 12 + 25 us, this one 2x us.
+//
+// Workgroup = (utterance b, frame tile j): the ntile = ceil(T / 128) tiles of an utterance have
+// FT = ceil(T / ntile) frames each (T = 400: four tiles of 100 -- 256 workgroups at batch 64, one per
+// CU); the MFMA tile is the 128 frames ENDING at the tile's last frame, t0 = tend - 128, so rows before
+// the tile's first frame are computed and dropped.  512 threads.
+//   conv phase   128 frames x 192 memory columns, K = the tend lags that have a causal pair; A is the
+//                Toeplitz operand of k_conv_fwd_bf16 (shifted copies of u in LDS), B = Hb rows by LDS-DMA
+//                through a four-stage ring with counted waits (three k-tiles in flight; six stages were no
+//                faster: with every CU in this phase at once the chip's LDS-DMA ingest is the limit);
+//   hand-over    the accumulators go to LDS as bf16 in the layout of the projection's A stages
+//                ([128 rows][64 k], 16-byte chunks swizzled) -- three k-tiles -- and from there to HBM;
+//   projection   128 x 384, K = M + D in k-tiles of 64: W_h rows by LDS-DMA (two stages); A k-tiles below
+//                M are the m tiles, the others are x rows DMA'd into the same three-slot ring (slot
+//                kt % 3: its previous tenant was consumed two barriers earlier);
+//   epilogue     that of k_proj_fwd_glds_bf16.
+// Same k order and MFMA grouping as the two separate kernels: m and h come out bit-identical.
+// Needs M % 64 == 0, M <= 192, Hd <= 384, T <= 512, D % 8 == 0, Hd % 8 == 0, 16-byte aligned tensors.
+// ---------------------------------------------------------------------------
+using FusedConvTile = TileB<128, 192, 64, 4, 2>;
+constexpr int kFusedHbStages = 4;
+constexpr int kFusedMaxT = 512;
+constexpr int kFusedLdsRing = 2 * ProjGldsTile::BN * kGldsRowBytes;                  // behind the two W stages
+constexpr int kFusedLdsU = kFusedLdsRing + 3 * ProjGldsTile::BM * kGldsRowBytes;     // behind the A ring
+constexpr int kFusedLdsTotal = kFusedLdsU + 16384;
+static_assert(kFusedHbStages * FusedConvTile::BN * kGldsRowBytes <= kFusedLdsRing, "the Hb ring lives in the W stages");
+static_assert(kFusedLdsTotal <= 160 * 1024, "one workgroup's LDS");
+static_assert(kFusedLdsTotal >= ProjGldsTile::BM * (ProjGldsTile::BN + 8) * 2, "epilogue tile fits");
+static_assert((kFusedMaxT / 8 + 16) * 128 + kFusedMaxT * 4 <= 16384, "u copies fit");
+
+__global__ __launch_bounds__(ProjGldsTile::THREADS) void k_conv_proj_fwd_bf16(
+    const float* __restrict__ u, const bf16_t* __restrict__ Hb, int ldHb, const bf16_t* __restrict__ x,
+    const bf16_t* __restrict__ Wb, const float* __restrict__ bias, bf16_t* __restrict__ m, bf16_t* __restrict__ h,
+    bf16_t* __restrict__ h_n, unsigned char* __restrict__ hmask, int T, int M, int D, int Hd, int ldW, int ntile,
+    int FT, LnEpilogue ln) {
+  using TC = FusedConvTile;
+  using TP = ProjGldsTile;
+  static_assert(TC::THREADS == TP::THREADS && TC::BM == TP::BM, "one workgroup shape");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // the longest tiles of an utterance first
+  const int b = (int)blockIdx.x / ntile, j = ntile - 1 - (int)blockIdx.x % ntile;
+  const int tstart = j * FT, tend = min(T, tstart + FT), t0 = tend - TC::BM;
+  const int kend = tend;  // lags 0 .. tend - 1
+  const int kend_pad = cdiv_dev(kend, TC::BK) * TC::BK;
+
+  LMUFFT_STAMP(6, 0);
+  // ---- conv phase ----
+  typedef GldsOperand<TC::BN, TC::NW, false, TC::BK> OpH;
+  OpH oh(
+      smem_raw,
+      [&](int r, const bf16_t*& q0, const bf16_t*&) {
+        if (r >= M) return false;
+        q0 = Hb + (long)r * ldHb;
+        return true;
+      },
+      ldHb, ldHb);
+  constexpr int NSH = kFusedHbStages;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) bits |= ((float)v[j] > 0.f ? 1u : 0u) << j;
-          hmask[row * CHM + (col >> 3)] = (unsigned char)bits;
-        }
-      });
-  LMUFFT_STAMP(4, 2);
-  // h_n: the last frame of every utterance that ends inside this row tile (tile still in LDS)
-  const long tile_end = min((long)rows, m0 + TL::BM);
-  constexpr int LDT = TL::BN + 8;
-  for (long rl = (m0 / T) * T + T - 1; rl < tile_end; rl += T) {
-    const int ml = (int)(rl - m0);
-    for (int c = threadIdx.x; c < TL::BN / 8; c += TL::THREADS) {
-      const int col = n0 + c * 8;
-      if (col < Hd)
-        *reinterpret_cast<bf16x8*>(h_n + (rl / T) * Hd + col) = *reinterpret_cast<const bf16x8*>(&tile[ml * LDT + c * 8]);
+  for (int st = 0; st < NSH - 1; ++st) oh.issue(st, st * TC::BK);
+
+  // time-reversed u around the tile, eight shifted copies (see k_conv_fwd_bf16).  (The barriers here also wait
+  // for the Hb tiles just issued -- the compiler orders LDS writes behind outstanding LDS-DMA; giving this work
+  // to four waves that issue no DMA, or loading u first, measured slower.)
+  bf16_t* U8 = reinterpret_cast<bf16_t*>(smem_raw + kFusedLdsU);
+  const int nchunks = (kend_pad / 8 + TC::BM / 8) * 8;
+  float* uf = reinterpret_cast<float*>(U8 + nchunks * 8);
+  const float* ub = u + (long)b * T;
+  const int smax = t0 + TC::BM - 1;
+  for (int sidx = threadIdx.x; sidx < kend; sidx += TC::THREADS) uf[sidx] = ub[sidx];
+  __syncthreads();
+  for (int ch = threadIdx.x; ch < nchunks; ch += TC::THREADS) {
+    const int Q = ch >> 3, c = ch & 7;
+    bf16x8 v;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      const int pp = 8 * Q + jj - c;
+      const int sidx = smax - pp;
+      v[jj] = (bf16_t)((pp >= 0 && sidx >= 0 && sidx < kend) ? uf[sidx] : 0.f);
     }
+    *reinterpret_cast<bf16x8*>(&U8[ch * 8]) = v;
   }
-  // Layer norm of the rows of h that follows the layer in the encoder (src/models/lmu_encoder.py:274),
-  // taken from the bf16 tile still in LDS -- the same bf16-rounded h a separate layer-norm kernel
-  // would read back from HBM; the tile spans the whole row (the host checks Hd <= BN).  Four lanes
-  // share a row: fp32 mean, centred second moment, two shuffles each.
-  if (ln.y) {
-    const int rl = threadIdx.x >> 2, q = threadIdx.x & 3;
-    static_assert(TL::THREADS == 4 * TL::BM, "four lanes per tile row");
-    const long row = m0 + rl;
-    const int chunks = Hd / 8;
-    float s = 0.f;
-    for (int c = q; c < chunks; c += 4) {
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(&tile[rl * LDT + c * 8]);
+  __syncthreads();
+  LMUFFT_STAMP(6, 1);
+
+  // the projection's operands (address arithmetic done while the first Hb tiles fly)
+  const int K = M + D;
+  const long grow0 = (long)b * T + t0;  // global row of tile row 0
+  typedef GldsOperand<TP::BM, TP::NW, false, TP::BK> OpX;
+  typedef GldsOperand<TP::BN, TP::NW, false, TP::BK> OpW;
+  OpX ox(
+      smem_raw + kFusedLdsRing,
+      [&](int r, const bf16_t*& q0, const bf16_t*&) {
+        const int t = t0 + r;
+        if (t < tstart || t >= tend) return false;
+        q0 = x + (grow0 + r) * D - M;  // element k of the A row, M <= k < M + D
+        return true;
+      },
+      K, K);
+  OpW ow(
+      smem_raw,
+      [&](int r, const bf16_t*& q0, const bf16_t*&) {
+        if (r >= Hd) return false;
+        q0 = Wb + (long)r * ldW;
+        return true;
+      },
+      ldW, ldW);
+  {
+    ToeplitzOperand<TC> oa{U8};
+    WavePos<TC> w;
+    f32x16 acc[TC::TN];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s += (float)v[j];
+    for (int tn = 0; tn < TC::TN; ++tn)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[tn][i] = 0.f;
+    static_assert(TC::TM == 1, "one row tile per wave");
+    constexpr int KEEP = OpH::NI * (NSH - 2);
+    int stage = 0, pf = NSH - 1;
+    for (int k0 = 0; k0 < kend; k0 += TC::BK) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
+      __builtin_amdgcn_s_barrier();
+      oh.issue(pf, k0 + (NSH - 1) * TC::BK);
+#pragma unroll
+      for (int kl = 0; kl < TC::BK; kl += 16) {
+        const bf16x8 af = oa.frag(w.wm0 + w.r, k0, kl, w.hh);
+#pragma unroll
+        for (int tn = 0; tn < TC::TN; ++tn) {
+          const bf16x8 bfr = oh.frag(stage, w.wn0 + tn * 32 + w.r, kl, w.hh);
+          acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[tn], 0, 0, 0);
+        }
+      }
+      stage = stage + 1 == NSH ? 0 : stage + 1;
+      pf = pf + 1 == NSH ? 0 : pf + 1;
     }
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    const float mean = s / (float)Hd;
-    float ss = 0.f;
-    for (int c = q; c < chunks; c += 4) {
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(&tile[rl * LDT + c * 8]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing k-tiles
+    __syncthreads();                                  // the Hb ring is free: the W stages take its place
+    LMUFFT_STAMP(6, 2);
+
+    // ---- hand-over: the m tile as the projection's first A k-tiles ----
+    unsigned char* ring = smem_raw + kFusedLdsRing;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float d = (float)v[j] - mean;
-        ss += d * d;
+    for (int tn = 0; tn < TC::TN; ++tn)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = w.wm0 + (i & 3) + 8 * (i >> 2) + 4 * w.hh;
+        const int n = w.wn0 + tn * 32 + w.r;
+        if (n < M)
+          *reinterpret_cast<bf16_t*>(ring + (n >> 6) * (TP::BM * kGldsRowBytes) + row * kGldsRowBytes +
+                                     ((((n & 63) >> 3) ^ ((row >> 1) & 7)) << 4) + (n & 7) * 2) = (bf16_t)acc[tn][i];
+      }
+  }
+
+  // ---- projection ----
+  ow.issue(0, 0);  // behind the ring writes: in front of them the compiler would make the writes wait for it
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // the m tile is in the ring
+  LMUFFT_STAMP(6, 3);
+  WavePos<TP> w;
+  f32x16 acc[TP::TM][TP::TN];
+  tileb_zero<TP>(acc);
+  const int KM = M / TP::BK, KT = cdiv_dev(K, TP::BK);
+  int wst = 0, slot = 0, nslot = 1;  // ring slot of k-tile kt and of kt + 1
+  for (int kt = 0; kt < KT; ++kt, wst ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < KT) {
+      ow.issue(wst ^ 1, (kt + 1) * TP::BK);
+      if (kt + 1 >= KM) ox.issue(nslot, (kt + 1) * TP::BK);
+    }
+    if (kt == 0) {
+      // m to HBM as whole 16-byte row segments, from the ring (its m tiles stay until the x tiles replace them, from
+      // iteration 2 on).  Here, behind the loads of k-tile 1, the stores complete under that round trip; in front
+      // of the loop the first vmcnt(0) would wait for them.
+      const unsigned char* ring = smem_raw + kFusedLdsRing;
+      const int CM = M / 8;
+      bf16_t* mb = m + (long)b * T * M;
+      for (int idx = threadIdx.x; idx < TP::BM * CM; idx += TP::THREADS) {
+        const int row = idx / CM, c = idx - row * CM;
+        const int t = t0 + row;
+        if (t >= tstart && t < tend)
+          *reinterpret_cast<bf16x8*>(mb + (long)t * M + c * 8) = *reinterpret_cast<const bf16x8*>(
+              ring + (c >> 3) * (TP::BM * kGldsRowBytes) + row * kGldsRowBytes + (((c & 7) ^ ((row >> 1) & 7)) << 4));
       }
     }
-    ss += __shfl_xor(ss, 1);
-    ss += __shfl_xor(ss, 2);
-    const float rstd = rsqrtf(ss / (float)Hd + ln.eps);
-    if (row < rows) {
-      for (int c = q; c < chunks; c += 4) {
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(&tile[rl * LDT + c * 8]);
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(ln.gamma + c * 8);
-        const f32x4 g1 = *reinterpret_cast<const f32x4*>(ln.gamma + c * 8 + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(ln.beta + c * 8);
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(ln.beta + c * 8 + 4);
-        float o[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          o[j] = ((float)v[j] - mean) * rstd * (j < 4 ? g0[j] : g1[j - 4]) + (j < 4 ? b0[j] : b1[j - 4]);
-        if (ln.y_bf16) {
-          bf16x8 ob;
+    for (int kl = 0; kl < TP::BK; kl += 16) {
+      bf16x8 af[TP::TM], bfr[TP::TN];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) ob[j] = (bf16_t)o[j];
-          *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(ln.y) + row * Hd + c * 8) = ob;
-        } else {
-          float* yp = reinterpret_cast<float*>(ln.y) + row * Hd + c * 8;
-          *reinterpret_cast<f32x4*>(yp) = f32x4{o[0], o[1], o[2], o[3]};
-          *reinterpret_cast<f32x4*>(yp + 4) = f32x4{o[4], o[5], o[6], o[7]};
-        }
-      }
+      for (int tm = 0; tm < TP::TM; ++tm) af[tm] = ox.frag(slot, w.wm0 + tm * 32 + w.r, kl, w.hh);
+#pragma unroll
+      for (int tn = 0; tn < TP::TN; ++tn) bfr[tn] = ow.frag(wst, w.wn0 + tn * 32 + w.r, kl, w.hh);
+#pragma unroll
+      for (int tm = 0; tm < TP::TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TP::TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bfr[tn], acc[tm][tn], 0, 0, 0);
     }
+    slot = nslot;
+    nslot = nslot == 2 ? 0 : nslot + 1;
   }
+  __syncthreads();
+  LMUFFT_STAMP(6, 5);
+  proj_epilogue<TP>(acc, w, smem_raw, bias, h, h_n, hmask, ln, grow0, (long)b * T + tstart, (long)b * T + tend, T, Hd, 0);
+  LMUFFT_STAMP(6, 6);
+  LMUFFT_STAMP_ADD(6, 4, j - g_stamps[stamp_block() * 8 + 4]);
 }
 
 // ---------------------------------------------------------------------------
@@ -1708,6 +1929,18 @@ __global__ __launch_bounds__(kThreads) void k_hmask_from_h(const bf16_t* __restr
   }
 }
 
+// CUs of the current device (cached per device)
+static int compute_units() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (!cached[dev]) {
+    int n = 0;
+    cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+  }
+  return cached[dev];
+}
+
 static int forward_bf16_impl(const lmufft_shape* s, const void* x_, const float* w_u, const float* b_u, void* wprep,
                              const float* W_h, const float* b_h, const void* hprep, const void* scanprep, float* u,
                              void* m_, void* h_, void* h_n_, void* hmask, int conv_algo, void* workspace,
@@ -1744,6 +1977,34 @@ static int forward_bf16_impl(const lmufft_shape* s, const void* x_, const float*
                          prep_blocks);
   }
   LAUNCH_CHECKB("k_encode_fwd_bf16");
+  const bool vec = (s->M % 8 == 0) && (s->D % 8 == 0) && (s->Hd % 8 == 0) && al16(m) && al16(x) && al16(h) &&
+                   al16(h_n);  // (a NULL h counts as aligned)
+  if (ln.y && !(vec && s->Hd <= ProjGldsTile::BN && al16(ln.y) && al16(ln.gamma) && al16(ln.beta)))
+    return set_error("forward with layer norm: needs hidden_size <= %d, memory / input / hidden sizes that are "
+                     "multiples of 8 and 16-byte aligned tensors; use lmufft_add_layernorm after the layer",
+                     ProjGldsTile::BN);
+  // AUTO: convolution and projection as one kernel where its tile shapes fit (TOEPLITZ asks for the separate
+  // kernels; both give the same bits)
+  // -- and where its workgroups (one per CU: 160 KB of LDS) run in about one round: the phases of a workgroup
+  // do not overlap with anybody else's, so over several rounds the separate kernels, whose convolution runs at
+  // full occupancy, are faster (batch 64 x 400 frames: 32 us against 12 + 25; batch 256: 115 against 23 + 84)
+  const int fused_ntile = cdivb(s->T, ProjGldsTile::BM);
+  if (!scan && conv_algo == LMUFFT_CONV_AUTO && vec && s->M % 64 == 0 && s->M <= FusedConvTile::BN &&
+      s->Hd <= ProjGldsTile::BN && s->T <= kFusedMaxT && al16(Hb) && hl.ldHb % 8 == 0 &&
+      (long)s->B * fused_ntile <= 3L * compute_units() / 2) {
+    const int ntile = fused_ntile, FT = cdivb(s->T, ntile);
+    if (hipFuncSetAttribute((const void*)k_conv_proj_fwd_bf16, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kFusedLdsTotal) != hipSuccess)
+      return set_error("cannot reserve %d bytes of LDS for k_conv_proj_fwd_bf16", kFusedLdsTotal);
+    {
+      PROFB("k_conv_proj_fwd_bf16");
+      hipLaunchKernelGGL(k_conv_proj_fwd_bf16, dim3(s->B * ntile), dim3(ProjGldsTile::THREADS), kFusedLdsTotal, st, u, Hb,
+                         hl.ldHb, x, Wb, b_h, m, h, h_n, (unsigned char*)hmask, s->T, s->M, s->D, s->Hd, ldW, ntile, FT,
+                         ln);
+    }
+    LAUNCH_CHECKB("k_conv_proj_fwd_bf16");
+    return 0;
+  }
   if (scan) {
     if (int rc = scan_conv_forward(*s, u, scanprep, m, workspace, workspace_bytes, st)) return rc;
   } else if (int rc = conv_forward_bf16_any(*s, u, Hb, hl.ldHb, m, st)) {
@@ -1751,12 +2012,6 @@ static int forward_bf16_impl(const lmufft_shape* s, const void* x_, const float*
   }
   {
     using TL = ProjTileB;
-    const bool vec = (s->M % 8 == 0) && (s->D % 8 == 0) && (s->Hd % 8 == 0) && al16(m) && al16(x) && al16(h) &&
-                     al16(h_n);  // (a NULL h counts as aligned)
-    if (ln.y && !(vec && s->Hd <= ProjGldsTile::BN && al16(ln.y) && al16(ln.gamma) && al16(ln.beta)))
-      return set_error("forward with layer norm: needs hidden_size <= %d, memory / input / hidden sizes that are "
-                       "multiples of 8 and 16-byte aligned tensors; use lmufft_add_layernorm after the layer",
-                       ProjGldsTile::BN);
     if (vec) {  // LDS-DMA staging
       using TG = ProjGldsTile;
       const dim3 grid(cdivb(s->Hd, TG::BN), cdivb(rows, TG::BM));

@@ -120,6 +120,9 @@ def kernel_work(name, B, T, D, M, Hd, s=4):
         # encoder gradient straight from gz: gz against Q^T [T][Hd], causal half of the lags; reads gz and Q^T once
         "k_gu_q": (1.0 * rows * Hd * (T + 1), rows * Hd * s + T * Hd * 2 + rows * 4),
         "k_conv_fwd": (1.0 * B * T * (T + 1) * M, rows * M * s + rows * 4 + M * T * s),
+        # convolution + projection in one kernel: u and x in, m and h (and the relu bit mask) out, H and W_h once
+        "k_conv_proj_fwd": (1.0 * B * T * (T + 1) * M + 2.0 * rows * MD * Hd,
+                            rows * (4 + M * s + D * s + Hd * s + Hd // 8) + M * T * s + Hd * MD * s),
         "k_conv_bwd": (1.0 * B * T * (T + 1) * M, rows * M * s + rows * 4 + M * T * s),
         # state-space route (bf16): two dense GEMMs of K = M + 128 against a constant matrix of (M + 128) x 128 M
         "k_scan_gemm_fwd": (2.0 * rows * M * (M + 128), rows * M * 2 + 128 * M * (M + 128) * 2),
