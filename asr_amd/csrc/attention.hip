@@ -18,6 +18,7 @@
 // Nothing goes through LDS between the two contractions.  K and V tiles are staged in LDS once
 // per workgroup (4 waves = 128 queries of one head), next tile prefetched into registers.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <math.h>
 #include <stdint.h>
 
@@ -831,24 +832,38 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 2 : 1) void k_attention_bwd_dq_
     }
     attn_bf16x8 dsf[2];
     const bool interior = all_q_valid && j0 + 32 <= len;  // wave-uniform: no mask tests on such tiles
+    // The sixteen elements of a lane, as straight-line code: the two wave-uniform switches (mask tests, dropout)
+    // are compile-time flags of this block, chosen once per tile -- tested per element they cut the block into
+    // some 150 basic blocks whose exp2 / hash chains ran one after the other.
+    auto elements = [&](auto interior_c, auto drop_c) __attribute__((always_inline)) {
+      constexpr bool INTERIOR = decltype(interior_c)::value, DROP = decltype(drop_c)::value;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int j = j0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-      float dw = dp[i];
-      if (dr.threshold) {  // registers i, i + 1 (i even) are the two keys of one hash
-        uint32_t x = 0;
-        if ((i & 1) == 0) x = xpair = hash_pair(hrow, (unsigned)j >> 1);
-        else x = xpair;
-        dw = ((i & 1) ? hash_keep_hi(dr, x) : hash_keep_lo(dr, x)) ? dw : 0.f;
+      for (int i = 0; i < 16; ++i) {
+        const int j = j0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        float dw = dp[i];
+        if (DROP) {  // registers i, i + 1 (i even) are the two keys of one hash
+          uint32_t x = 0;
+          if ((i & 1) == 0) x = xpair = hash_pair(hrow, (unsigned)j >> 1);
+          else x = xpair;
+          dw = ((i & 1) ? hash_keep_hi(dr, x) : hash_keep_lo(dr, x)) ? dw : 0.f;
+        }
+        float ds;
+        if (INTERIOR) {
+          ds = __builtin_amdgcn_exp2f(__builtin_fmaf(st[i], scale2, -m2)) * invl * (dw - Dk);
+        } else {
+          const bool inside = q_valid && j < len;
+          const float e = __builtin_amdgcn_exp2f(st[i] * scale2 - m2) * invl * (dw - Dk);
+          ds = inside ? e : 0.f;
+        }
+        dsf[i >> 3][i & 7] = (attn_bf16)ds;
       }
-      float ds;
-      if (interior) {
-        ds = __builtin_amdgcn_exp2f(__builtin_fmaf(st[i], scale2, -m2)) * invl * (dw - Dk);
-      } else {
-        const bool inside = q_valid && j < len;
-        ds = inside ? __builtin_amdgcn_exp2f(st[i] * scale2 - m2) * invl * (dw - Dk) : 0.f;
-      }
-      dsf[i >> 3][i & 7] = (attn_bf16)ds;
+    };
+    if (interior) {
+      if (dr.threshold) elements(std::true_type{}, std::true_type{});
+      else elements(std::true_type{}, std::false_type{});
+    } else {
+      if (dr.threshold) elements(std::false_type{}, std::true_type{});
+      else elements(std::false_type{}, std::false_type{});
     }
     // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
 #pragma unroll
@@ -904,7 +919,6 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 2 : 1) void k_attention_bwd_dkv
   const long bh = (long)b * H + h;
   const int kj = blockIdx.x * (32 * NW) + wave * 32 + r;
   const bool k_valid = kj < len;
-  const bool all_k_valid = __all(k_valid);
   const bool wave_live = blockIdx.x * (32 * NW) + wave * 32 < T;  // wave-uniform
   const int kc = min(kj, T - 1);
 
@@ -1005,31 +1019,33 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 2 : 1) void k_attention_bwd_dkv
         xq[i + 1] = odd ? mine : other;
       }
     }
-    const bool interior = all_k_valid && i0 + 32 <= len;  // wave-uniform: no mask tests on such tiles
+    // Straight-line code for the sixteen elements: dropout on or off is a compile-time flag of the block, chosen
+    // once per tile (see k_attention_bwd_dq_bf16); the mask tests are two compares and selects on values for every
+    // tile -- a second pair of specialised blocks for interior tiles cost more in registers (spills) than the
+    // tests cost in instructions.
+    auto elements = [&](auto drop_c) __attribute__((always_inline)) {
+      constexpr bool DROP = decltype(drop_c)::value;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      // registers 4g .. 4g + 3 are four consecutive query rows: their statistics come as three 16-byte reads
-      const int row0 = 8 * g + 4 * hh;
-      const attn_f4 m4 = *reinterpret_cast<const attn_f4*>(&Ms[row0]);
-      const attn_f4 l4 = *reinterpret_cast<const attn_f4*>(&Ls[row0]);
-      const attn_f4 d4 = *reinterpret_cast<const attn_f4*>(&Ds[row0]);
+      for (int g = 0; g < 4; ++g) {
+        // registers 4g .. 4g + 3 are four consecutive query rows: their statistics come as three 16-byte reads
+        const int row0 = 8 * g + 4 * hh;
+        const attn_f4 m4 = *reinterpret_cast<const attn_f4*>(&Ms[row0]);
+        const attn_f4 l4 = *reinterpret_cast<const attn_f4*>(&Ls[row0]);
+        const attn_f4 d4 = *reinterpret_cast<const attn_f4*>(&Ds[row0]);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int i = 4 * g + e;
-        const bool keep = dr.threshold ? ((kj & 1) ? hash_keep_hi(dr, xq[i]) : hash_keep_lo(dr, xq[i])) : true;
-        float pv;
-        bool inside = true;
-        if (interior) {
-          pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[i], scale2, -m4[e])) * l4[e];
-        } else {
-          inside = i0 + row0 + e < len && k_valid;
-          pv = __builtin_amdgcn_exp2f((inside ? st[i] * scale2 : kMasked2) - m4[e]) * l4[e];
+        for (int e = 0; e < 4; ++e) {
+          const int i = 4 * g + e;
+          const bool keep = DROP ? ((kj & 1) ? hash_keep_hi(dr, xq[i]) : hash_keep_lo(dr, xq[i])) : true;
+          const bool inside = i0 + row0 + e < len && k_valid;
+          const float pv = __builtin_amdgcn_exp2f((inside ? st[i] * scale2 : kMasked2) - m4[e]) * l4[e];
+          const float dw = keep ? dp[i] : 0.f;
+          wf[i >> 3][i & 7] = (attn_bf16)(keep ? pv : 0.f);
+          dsf[i >> 3][i & 7] = (attn_bf16)(inside ? pv * (dw - d4[e]) : 0.f);
         }
-        const float dw = keep ? dp[i] : 0.f;
-        wf[i >> 3][i & 7] = (attn_bf16)(keep ? pv : 0.f);
-        dsf[i >> 3][i & 7] = (attn_bf16)(inside ? pv * (dw - d4[e]) : 0.f);
       }
-    }
+    };
+    if (dr.threshold) elements(std::true_type{});
+    else elements(std::false_type{});
     // dV^T[d][key] += dO^T[d][query] W[query][key];  dK^T[d][key] += Q^T[d][query] dS[query][key]
 #pragma unroll
     for (int half = 0; half < 2; ++half)
