@@ -218,7 +218,7 @@ struct FftLds {
   static constexpr int TW = 0;
   static constexpr int WORK = TW + 2 * N;
   static constexpr int TILE = WORK + kFftWaves * 2 * PADN;
-  static size_t bytes(int T) { return sizeof(float) * ((size_t)TILE + (size_t)T * kTileLd); }
+  static size_t bytes(int T, int pairs = kFftPairs) { return sizeof(float) * ((size_t)TILE + (size_t)T * (2 * pairs + 1)); }
   static size_t bytes_single() { return sizeof(float) * (size_t)(2 * N + 4 * PADN); }  // one-wave kernels
 };
 
@@ -278,24 +278,44 @@ __global__ __launch_bounds__(64) void k_fft_u(const float* __restrict__ u, const
 // ---------------------------------------------------------------------------
 // forward: m[b][t][k0 .. k0+31] for one batch item and 16 channel pairs
 // ---------------------------------------------------------------------------
-template <int N>
-__global__ __launch_bounds__(kFftThreads) void k_conv_fwd_fft(const float2* __restrict__ U,
+// PAIRS channel pairs per workgroup (16: 128-byte rows of m; 24: three transforms per wave, which at batch 64 and
+// 96 pairs is one workgroup per CU with every SIMD at six transforms -- 16 gave 1.5 rounds of workgroups, i.e. eight
+// transforms on the busiest SIMDs).  FUSE_U: the workgroup's first wave takes the spectrum of u[b] itself (the
+// workgroups of a batch item each do, writing the same numbers to the same place) instead of a launch of 64
+// one-wave workgroups before this one.
+template <int N, int PAIRS, bool FUSE_U>
+__global__ __launch_bounds__(kFftThreads) void k_conv_fwd_fft(const float* __restrict__ u, float2* __restrict__ U,
                                                               const float2* __restrict__ G,
                                                               const float2* __restrict__ table,
                                                               float* __restrict__ m, int T, int M, int npairs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using L = FftLds<N>;
+  constexpr int COLS = 2 * PAIRS, LD = COLS + 1;
   float2* tw = reinterpret_cast<float2*>(lds + L::TW);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float2* buf = reinterpret_cast<float2*>(lds + L::WORK) + (size_t)wave * L::PADN;
   float* tile = lds + L::TILE;
-  const int b = blockIdx.y, p0 = blockIdx.x * kFftPairs;
-  const float2* Ub = U + (long)b * N;
+  const int b = blockIdx.y, p0 = blockIdx.x * PAIRS;
+  float2* Ub = U + (long)b * N;
 
   load_twiddles<N>(tw, table);
   __syncthreads();
+  if (FUSE_U) {
+    if (wave == 0) {
+      const float* ub = u + (long)b * T;
+      wave_fft<N, false>(
+          tw, buf,
+          [&](int i, int) {  // clamped address + select: the sixteen loads of a lane stay in flight together
+            const float v = ub[min(i, T - 1)];
+            return make_float2(i < T ? v : 0.f, 0.f);
+          },
+          [&](int i, float2 v, int) { Ub[i] = v; });
+      __threadfence_block();
+    }
+    __syncthreads();
+  }
   // ifft(U * G_p) -> columns 2*pl, 2*pl+1 of the tile; the waves take the pairs in turn
-  for (int pl = wave; pl < kFftPairs; pl += kFftWaves) {
+  for (int pl = wave; pl < PAIRS; pl += kFftWaves) {
     const int p = p0 + pl;
     if (p >= npairs) break;
     const float2* Gp = G + (long)p * N;
@@ -308,18 +328,18 @@ __global__ __launch_bounds__(kFftThreads) void k_conv_fwd_fft(const float2* __re
         tw, buf, [&](int i, int) { return buf[fpad(i)]; },
         [&](int i, float2 v, int) {
           if (i < T) {
-            tile[i * kTileLd + 2 * pl] = v.x;
-            tile[i * kTileLd + 2 * pl + 1] = v.y;
+            tile[i * LD + 2 * pl] = v.x;
+            tile[i * LD + 2 * pl + 1] = v.y;
           }
         });
   }
   __syncthreads();
-  // tile -> m[b][t][k0 + c], 128-byte row segments
+  // tile -> m[b][t][k0 + c], whole row segments
   const int k0 = 2 * p0;
   float* mb = m + (long)b * T * M;
-  for (int idx = threadIdx.x; idx < T * kFftCols; idx += kFftThreads) {
-    const int t = idx / kFftCols, c = idx % kFftCols;
-    if (k0 + c < M) mb[(long)t * M + k0 + c] = tile[t * kTileLd + c];
+  for (int idx = threadIdx.x; idx < T * COLS; idx += kFftThreads) {
+    const int t = idx / COLS, c = idx % COLS;
+    if (k0 + c < M) mb[(long)t * M + k0 + c] = tile[t * LD + c];
   }
 }
 
@@ -327,7 +347,7 @@ __global__ __launch_bounds__(kFftThreads) void k_conv_fwd_fft(const float2* __re
 // adjoint, first kernel: spectrum of the contribution of the 32 channels k0 .. k0+31 of one
 // batch item, Sp[(kgroup * B + b)][f] = sum_pairs fft(gm_2p + i gm_2p+1)[f] * Gr_p[f]
 // ---------------------------------------------------------------------------
-template <int N>
+template <int N, int PAIRS>
 __global__ __launch_bounds__(kFftThreads) void k_conv_bwd_fft(const float* __restrict__ gm,
                                                               const float2* __restrict__ Gr,
                                                               const float2* __restrict__ table,
@@ -339,13 +359,14 @@ __global__ __launch_bounds__(kFftThreads) void k_conv_bwd_fft(const float* __res
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float2* buf = reinterpret_cast<float2*>(lds + L::WORK) + (size_t)wave * L::PADN;
   float* tile = lds + L::TILE;
-  const int b = blockIdx.y, p0 = blockIdx.x * kFftPairs, k0 = 2 * p0;
+  constexpr int COLS = 2 * PAIRS, LD = COLS + 1;
+  const int b = blockIdx.y, p0 = blockIdx.x * PAIRS, k0 = 2 * p0;
   const float* gmb = gm + (long)b * T * M;
 
   load_twiddles<N>(tw, table);
-  for (int idx = threadIdx.x; idx < T * kFftCols; idx += kFftThreads) {
-    const int t = idx / kFftCols, c = idx % kFftCols;
-    tile[t * kTileLd + c] = (k0 + c < M) ? gmb[(long)t * M + k0 + c] : 0.f;
+  for (int idx = threadIdx.x; idx < T * COLS; idx += kFftThreads) {
+    const int t = idx / COLS, c = idx % COLS;
+    tile[t * LD + c] = (k0 + c < M) ? gmb[(long)t * M + k0 + c] : 0.f;
   }
   __syncthreads();
 
@@ -357,14 +378,14 @@ __global__ __launch_bounds__(kFftThreads) void k_conv_bwd_fft(const float* __res
 #pragma unroll
   for (int i = 0; i < PER; ++i) acc[i] = make_float2(0.f, 0.f);
 
-  for (int pl = wave; pl < kFftPairs; pl += kFftWaves) {
+  for (int pl = wave; pl < PAIRS; pl += kFftWaves) {
     const int p = p0 + pl;
     if (p >= npairs) break;
     const float2* Gp = Gr + (long)p * N;
     wave_fft<N, false>(
         tw, buf,
         [&](int i, int) {  // clamped address + select keeps the reads of a lane in flight together
-          const float* t2 = tile + min(i, T - 1) * kTileLd + 2 * pl;
+          const float* t2 = tile + min(i, T - 1) * LD + 2 * pl;
           const float re = t2[0], im = t2[1];
           return make_float2(i < T ? re : 0.f, i < T ? im : 0.f);
         },
@@ -783,7 +804,22 @@ int fft_prepare(const lmufft_shape& s, const float* H, void* prep, hipStream_t s
   return 0;
 }
 
-int fft_conv_groups(int M) { return cdivf((M + 1) / 2, kFftPairs); }
+int fft_conv_groups(int M) { return cdivf((M + 1) / 2, kFftPairs); }  // the most any route uses (workspace sizing)
+
+// Channel pairs per workgroup of the one-transform kernels: 24 where that takes fewer (rounds of workgroups) x
+// (transforms per wave) than 16 and its [T][49] tile fits the LDS.
+static int fft_cus() {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  return (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+}
+template <int N>
+static int fft_one_pairs(int npairs, int B, int T) {
+  if (FftLds<N>::bytes(T, 24) > 160 * 1024) return 16;
+  const int cus = fft_cus();
+  const long c24 = (long)cdivf((long)cdivf(npairs, 24) * B, cus) * 3, c16 = (long)cdivf((long)cdivf(npairs, 16) * B, cus) * 2;
+  return c24 < c16 ? 24 : 16;
+}
 
 // scratch of the FFT route: spectra of u (forward) or per-group partial spectra (adjoint)
 size_t fft_conv_workspace_bytes(const lmufft_shape& s) {
@@ -824,17 +860,19 @@ int fft_conv_forward(const lmufft_shape& s, const float* u, const void* prep, fl
   }
   const float2* table = (const float2*)prep + (size_t)2 * npairs * N;
   FFT_DISPATCH(N, {
-    const size_t lds1 = FftLds<NN>::bytes_single();
-    if (int rc = reserve_lds(k_fft_u<NN>, lds1, "k_fft_u")) return rc;
-    {
-      ProfScope ps("k_fft_u", st);
-      hipLaunchKernelGGL(k_fft_u<NN>, dim3(s.B), dim3(64), lds1, st, u, table, U, s.T);
-    }
-    const size_t lds = FftLds<NN>::bytes(s.T);
-    if (int rc = reserve_lds(k_conv_fwd_fft<NN>, lds, "k_conv_fwd_fft")) return rc;
+    const int P = fft_one_pairs<NN>(npairs, s.B, s.T);
+    const size_t lds = FftLds<NN>::bytes(s.T, P);
+    const dim3 grid(cdivf(npairs, P), s.B);
     ProfScope ps("k_conv_fwd_fft", st);
-    hipLaunchKernelGGL(k_conv_fwd_fft<NN>, dim3(cdivf(npairs, kFftPairs), s.B), dim3(kFftThreads), lds, st,
-                       (const float2*)U, (const float2*)prep, table, m, s.T, s.M, npairs);
+    if (P == 24) {
+      if (int rc = reserve_lds(k_conv_fwd_fft<NN, 24, true>, lds, "k_conv_fwd_fft")) return rc;
+      hipLaunchKernelGGL((k_conv_fwd_fft<NN, 24, true>), grid, dim3(kFftThreads), lds, st, u, U, (const float2*)prep,
+                         table, m, s.T, s.M, npairs);
+    } else {
+      if (int rc = reserve_lds(k_conv_fwd_fft<NN, 16, true>, lds, "k_conv_fwd_fft")) return rc;
+      hipLaunchKernelGGL((k_conv_fwd_fft<NN, 16, true>), grid, dim3(kFftThreads), lds, st, u, U, (const float2*)prep,
+                         table, m, s.T, s.M, npairs);
+    }
   });
   FFT_LAUNCH_CHECK("k_conv_fwd_fft");
   return 0;
@@ -875,18 +913,26 @@ int fft_conv_backward(const lmufft_shape& s, const float* gm, const void* prep, 
   const float2* Gr = (const float2*)prep + (size_t)npairs * N;
   const float2* table = (const float2*)prep + (size_t)2 * npairs * N;
   FFT_DISPATCH(N, {
-    const size_t lds = FftLds<NN>::bytes(s.T);
-    if (int rc = reserve_lds(k_conv_bwd_fft<NN>, lds, "k_conv_bwd_fft")) return rc;
+    const int P = fft_one_pairs<NN>(npairs, s.B, s.T);
+    const int ngroups = cdivf(npairs, P);
+    const size_t lds = FftLds<NN>::bytes(s.T, P);
     {
       ProfScope ps("k_conv_bwd_fft", st);
-      hipLaunchKernelGGL(k_conv_bwd_fft<NN>, dim3(groups, s.B), dim3(kFftThreads), lds, st, gm, Gr, table, Sp, s.B,
-                         s.T, s.M, npairs);
+      if (P == 24) {
+        if (int rc = reserve_lds(k_conv_bwd_fft<NN, 24>, lds, "k_conv_bwd_fft")) return rc;
+        hipLaunchKernelGGL((k_conv_bwd_fft<NN, 24>), dim3(ngroups, s.B), dim3(kFftThreads), lds, st, gm, Gr, table, Sp,
+                           s.B, s.T, s.M, npairs);
+      } else {
+        if (int rc = reserve_lds(k_conv_bwd_fft<NN, 16>, lds, "k_conv_bwd_fft")) return rc;
+        hipLaunchKernelGGL((k_conv_bwd_fft<NN, 16>), dim3(ngroups, s.B), dim3(kFftThreads), lds, st, gm, Gr, table, Sp,
+                           s.B, s.T, s.M, npairs);
+      }
     }
     const size_t lds1 = FftLds<NN>::bytes_single();
     if (int rc = reserve_lds(k_fft_gu<NN>, lds1, "k_fft_gu")) return rc;
     ProfScope ps("k_fft_gu", st);
     hipLaunchKernelGGL(k_fft_gu<NN>, dim3(s.B), dim3(64), lds1, st, (const float2*)Sp, table, u, gu, s.B, s.T,
-                       groups);
+                       ngroups);
   });
   FFT_LAUNCH_CHECK("k_conv_bwd_fft");
   return 0;

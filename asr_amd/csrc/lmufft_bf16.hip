@@ -1776,6 +1776,11 @@ static BwdPlanB plan_backward_b(const lmufft_shape& s) {
   {  // second form of the adjoint convolution: P frame ranges per s tile
     const int tiles = cdivb(s.T, kCb2St) * cdivb(s.B, kCb2Bt);
     p.cb2_P = std::max(1, std::min(std::min(32, s.T), (768 + tiles - 1) / tiles));
+    // ... and enough of them that a range's window of H^T (its frames + 63 rows of M + 8 bf16) fits the LDS beside the
+    // kernel's 32 KB of partial sums: large batches of long sequences would otherwise ask for one or two ranges
+    const long row_bytes = (long)(cdivb(s.M, 16) * 16 + 8) * sizeof(bf16_t);
+    const long fit = (160L * 1024 - (long)sizeof(float) * 4 * kCb2Bt * kCb2St) / row_bytes - (kCb2St - 1);
+    if (fit >= 1) p.cb2_P = std::max(p.cb2_P, cdivb(s.T, fit));
   }
   p.q_slots = guq_plan(s.T).nslot;
   p.q_rows = cdivb(s.T, 64) * 64;

@@ -82,3 +82,25 @@ def test_conv_bf16_impulse_and_determinism():
     a = causal_conv_adjoint_bf16(gm, Ht)
     b = causal_conv_adjoint_bf16(gm, Ht)
     assert torch.equal(a, b)
+
+
+def test_conv_bf16_adjoint_large_batch_of_long_sequences():
+    """Many utterances of a long sequence: the adjoint kernel's frame ranges must stay short enough for their
+    window of H^T to fit the LDS however few ranges the grid would need to fill the chip (batch 256 x 3000 frames
+    used to be refused).  The result per utterance does not depend on the batch it is computed in beyond the
+    summation order of the ranges: compared with the same utterances run eight at a time."""
+    from asr_amd.functional import causal_conv_adjoint_bf16, prepare_impulse_bf16
+
+    dev = torch.device("cuda:0")
+    B, T, M = 256, 3000, 192
+    rng = np.random.default_rng(7)
+    H = torch.from_numpy(_rand_H(rng, M, T)).to(dev)
+    hprep = prepare_impulse_bf16(H)
+    g = torch.Generator(device=dev).manual_seed(11)
+    gm = torch.randn(B, T, M, device=dev, generator=g).bfloat16()
+    gu = causal_conv_adjoint_bf16(gm, H, hprep=hprep)
+    assert gu.shape == (B, T) and torch.isfinite(gu).all()
+    for b0 in (0, 120, 248):
+        part = causal_conv_adjoint_bf16(gm[b0:b0 + 8].contiguous(), H, hprep=hprep)
+        scale = float(part.abs().max())
+        assert float((gu[b0:b0 + 8] - part).abs().max()) <= 2e-5 * scale

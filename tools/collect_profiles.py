@@ -30,6 +30,8 @@ def main():
     cp("stats_f32/f32_kernel_stats.csv", "f32_kernel_stats.csv")
     cp("stats_c2_full/c2_kernel_stats.csv", "c2_full_kernel_stats.csv")
     cp("stats_c4_scan/c4_kernel_stats.csv", "c4_bf16_scan_kernel_stats.csv")
+    cp("stats_conv_bf16/conv_kernel_stats.csv", "conv_bf16_b64_t400_kernel_stats.csv")
+    cp("stats_conv_f32/conv_kernel_stats.csv", "conv_f32_b64_t400_kernel_stats.csv")
     # one file per conv-only line
     p = os.path.join(SRC, "bench_conv.jsonl")
     if os.path.exists(p):
@@ -56,6 +58,11 @@ def main():
     args = [sys.executable, os.path.join(ROOT, "tools", "make_traffic.py")]
     for dt in ("bf16", "f32"):
         args += [os.path.join(SRC, f"pmc_{dt}"), dt]
+    subprocess.run(args, check=False)
+    # the conv-only unit's kernels (both routes of each dtype), per launch, in a file of their own
+    args = [sys.executable, os.path.join(ROOT, "tools", "make_traffic.py"), "--out", os.path.join(dst, "conv_unit_traffic.json")]
+    for dt in ("bf16", "f32"):
+        args += [os.path.join(SRC, f"pmc_conv_{dt}"), dt]
     subprocess.run(args, check=False)
 
 

@@ -3,7 +3,7 @@
 Per kernel (bench.py's names) and per launch: HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
 FETCH_SIZE and WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts wide coalesced reads at
 half their bytes (128-byte requests tallied as 64), hence the factor 2.  Each counter comes from
-its own run.  usage: make_traffic.py <dir with *_counter_collection.csv> <dtype tag> [more dirs/tags]"""
+its own run.  usage: make_traffic.py [--out file.json] <dir with *_counter_collection.csv> <dtype tag> [more dirs/tags]"""
 import collections
 import csv
 import glob
@@ -20,7 +20,8 @@ def classify(name, seq):
     if "k_dgrad" in n:  # fp32: one kernel, launched for gm then for gx
         seq["dgrad"] += 1
         return "k_dgrad_m" if seq["dgrad"] % 2 == 1 else "k_dgrad_x"
-    table = [("k_proj_fwd_glds_bf16", "k_proj_fwd_bf16"), ("k_proj_fwd_bf16", "k_proj_fwd_bf16"),
+    table = [("k_conv_proj_fwd_bf16", "k_conv_proj_fwd_bf16"), ("k_gu_q_bf16", "k_gu_q_bf16"),
+             ("k_relu_bwd_q_bf16", "k_relu_bwd_bf16"), ("k_proj_fwd_glds_bf16", "k_proj_fwd_bf16"), ("k_proj_fwd_bf16", "k_proj_fwd_bf16"),
              ("k_conv_bwd2_bf16", "k_conv_bwd_bf16"), ("k_conv_bwd_bf16", "k_conv_bwd_bf16"),
              ("k_conv_fwd_bf16", "k_conv_fwd_bf16"), ("k_wgrad_bf16", "k_wgrad_bf16"),
              ("k_relu_bwd_bf16", "k_relu_bwd_bf16"), ("k_encode_fwd_bf16", "k_encode_fwd_bf16"),
@@ -54,6 +55,10 @@ out = {}
 meta = {"formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch; one rocprofv3 --pmc run per counter",
         "kernels": {}}
 args = sys.argv[1:]
+out_path = os.path.join(os.path.dirname(__file__), "..", "profiles", "traffic.json")
+if args and args[0] == "--out":
+    out_path = args[1]
+    args = args[2:]
 for d, tag in zip(args[0::2], args[1::2]):
     for k, c in collect(d).items():
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
@@ -65,7 +70,7 @@ for d, tag in zip(args[0::2], args[1::2]):
             meta["kernels"][k] = {"run": tag, "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
                                   "launches": len(c["FETCH_SIZE"])}
 out["_meta"] = meta
-json.dump(out, open(os.path.join(os.path.dirname(__file__), "..", "profiles", "traffic.json"), "w"), indent=1)
+json.dump(out, open(out_path, "w"), indent=1)
 for k, v in out.items():
     if k != "_meta":
         print(f"{k:24s} {v / 1e6:9.2f} MB/launch  {meta['kernels'][k]}")

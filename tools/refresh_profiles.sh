@@ -7,14 +7,21 @@ O=gpurun_out/refresh
 rm -rf $O && mkdir -p $O
 timeout -k 10 240 python3 bench.py > $O/bench_bf16.json 2> $O/bench_bf16.err
 timeout -k 10 240 python3 bench.py --dtype f32 > $O/bench_f32.json 2> $O/bench_f32.err
-timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_bf16 -o bf16 -- python3 bench.py --steps 30 > $O/stats_bf16.log 2>&1
-timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_f32 -o f32 -- python3 bench.py --dtype f32 --steps 30 > $O/stats_f32.log 2>&1
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_bf16 -o bf16 -- python3 bench.py --steps 30 --no-extras --no-cpu-baseline > $O/stats_bf16.log 2>&1
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_f32 -o f32 -- python3 bench.py --dtype f32 --steps 30 --no-extras --no-cpu-baseline > $O/stats_f32.log 2>&1
 for dt in bf16 f32; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout -s KILL 180 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$dt/$c -o p -- python3 bench.py --dtype $dt --steps 5 --warmup 1 --no-graph > $O/pmc_${dt}_$c.log 2>&1
+    timeout -s KILL 180 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$dt/$c -o p -- python3 bench.py --dtype $dt --steps 5 --warmup 1 --no-graph --no-extras --no-cpu-baseline > $O/pmc_${dt}_$c.log 2>&1
   done
 done
 export PYTHONPATH=$PWD
+# conv-only unit at batch 64 x 400 frames: kernel statistics and HBM traffic counters of every route
+for dt in bf16 f32; do
+  timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_conv_$dt -o conv -- python3 bench.py --unit conv --dtype $dt --batch 64 --frames 400 --steps 200 > $O/stats_conv_$dt.log 2>&1
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout -s KILL 180 rocprofv3 --pmc $c --output-format csv -d $O/pmc_conv_$dt/$c -o p -- python3 bench.py --unit conv --dtype $dt --batch 64 --frames 400 --steps 20 --warmup 2 > $O/pmc_conv_${dt}_$c.log 2>&1
+  done
+done
 for shape in "64 400" "16 400" "32 3000"; do
   set -- $shape
   for dt in bf16 f32; do
