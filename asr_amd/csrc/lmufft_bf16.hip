@@ -2057,7 +2057,27 @@ static int conv_backward_bf16_any(const lmufft_shape& sh, const bf16_t* gm, cons
   const long rows = (long)s->B * s->T;
   const bool dgrad_x_fast = defer;
   const int KS = cdivb(s->M, 16);
-  if (s->M % 8 == 0 && al16(gm) && (KS == 2 || KS == 4 || KS == 8 || KS == 12 || KS == 16)) {
+  if (s->T <= kGuQMaxT && s->M % GuQTile::BK == 0 && al16(gm) && al16(HbT) && hl.ldHT % 8 == 0 &&
+      p.q_slots <= kGuQMaxSlots) {
+    // Short sequences: the kernel that takes the encoder gradient straight from gz (k_gu_q_bf16) is this very
+    // product with (gz, Q^T, Hd) = (gm, H^T, M) -- 128 frames x 256 lags per workgroup by LDS-DMA, diagonal sums in
+    // registers, six partial slabs per utterance at 400 frames instead of twelve
+    using TG = GuQTile;
+    const size_t lds = (size_t)kGuQStages * (TG::BM + TG::BN) * TG::BK * 2;
+    if (hipFuncSetAttribute((const void*)k_gu_q_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return set_error("cannot reserve %zu bytes of LDS for k_gu_q_bf16", lds);
+    {
+      PROFB("k_conv_bwd_bf16");
+      hipLaunchKernelGGL(k_gu_q_bf16, dim3(s->B * p.q_slots), dim3(TG::THREADS), lds, st, gm, HbT, gupart, s->B, s->T,
+                         s->M, hl.ldHT, hl.ldHb, guq_plan(s->T));
+    }
+    LAUNCH_CHECKB("k_conv_bwd_bf16");
+    if (dgrad_x_fast && p.q_slots <= kGaMaxParts) {
+      *ga_parts = GaParts{gupart, u, ga, rows, p.q_slots};
+    } else {
+      if (int rc = launch_sum_slabs_masked(gupart, u, ga, rows, p.q_slots, st)) return rc;
+    }
+  } else if (s->M % 8 == 0 && al16(gm) && (KS == 2 || KS == 4 || KS == 8 || KS == 12 || KS == 16)) {
     const int P = p.cb2_P;
     const dim3 grid(P, cdivb(s->T, kCb2St), cdivb(s->B, kCb2Bt));
     const int Lp_max = cdivb(s->T, P);
