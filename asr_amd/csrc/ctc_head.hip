@@ -443,6 +443,21 @@ __device__ __forceinline__ double ctc_lane_above(double v) {
 // Every thread of the group makes Tb - 1 calls of ctc_sync.  Returns the buffer the last step wrote; E: the last
 // frame's cumulative shift.  When the recursion is one wave (NW = 1) the neighbours' values come by DPP lane shifts
 // and the LDS is not used at all.
+// exp(x) as a double for x <= 0 without the fp32 underflow at x < -87 (a log-probability of -100 is a tiny but
+// nonzero probability; as an exact 0 it would make every path through that frame impossible and the utterance's
+// loss infinite): x = e ln 2 + r with e an integer, exp(r) in fp32 (r within +-0.35: the accuracy of the fp32
+// form), times 2^e applied to the double's exponent.  Below -700 (and for -inf) the result is 0.  (The recursions
+// rescale every kCtcRescale-th frame, so the floor that matters is the product of that many frames: log-probabilities
+// down to about -170 per frame on a needed path stay representable.)
+__device__ __forceinline__ double ctc_exp(float x) {
+  const float xc = fmaxf(x, -700.f);
+  const float e = rintf(xc * 1.44269504f);
+  float r = __builtin_fmaf(e, -0.693359375f, xc);  // Cody-Waite: ln 2 = 0.693359375 - 2.12194440e-4
+  r = __builtin_fmaf(e, 2.12194440e-4f, r);
+  const double p = (double)__expf(r) * __hiloint2double((1023 + (int)e) << 20, 0);
+  return x < -700.f ? 0.0 : p;
+}
+
 template <int NW, bool FWD>
 __device__ __forceinline__ int ctc_sweep(const float* __restrict__ lpb, int V, int blank, int my_label, int l, int L, int Tb,
                                          bool skip, double* __restrict__ w, int* __restrict__ ex,
@@ -454,11 +469,11 @@ __device__ __forceinline__ int ctc_sweep(const float* __restrict__ lpb, int V, i
   {
     const float* row = lpb + (long)t0 * V;
     if (FWD) {
-      vb = l == 0 ? (double)__expf(row[blank]) : 0.0;
-      vl = (l == 0 && L > 0) ? (double)__expf(row[my_label]) : 0.0;
+      vb = l == 0 ? ctc_exp(row[blank]) : 0.0;
+      vl = (l == 0 && L > 0) ? ctc_exp(row[my_label]) : 0.0;
     } else {
-      vb = l == L ? (double)__expf(row[blank]) : 0.0;
-      vl = l == L - 1 ? (double)__expf(row[my_label]) : 0.0;
+      vb = l == L ? ctc_exp(row[blank]) : 0.0;
+      vl = l == L - 1 ? ctc_exp(row[my_label]) : 0.0;
     }
   }
   E = 0;
@@ -506,7 +521,7 @@ __device__ __forceinline__ int ctc_sweep(const float* __restrict__ lpb, int V, i
       const int k = k0 + i;
       if (k < Tb) {  // uniform over the workgroup
         const int t = FWD ? k : Tb - 1 - k;
-        double pb = (double)__expf(qb[i]), pl = (double)__expf(ql[i]);
+        double pb = ctc_exp(qb[i]), pl = ctc_exp(ql[i]);
         if (i % kCtcRescale == 0) {  // the shift found at the end of the last period
           if (NW > 1) {
 #pragma unroll
@@ -669,7 +684,22 @@ __global__ __launch_bounds__(64 * ctc_grad_waves(NW)) void k_ctc_grad(
       } else {
         const double* a = ws + ((long)b * T + t) * 2 * NT;
         const double* bt = ws + (((long)B + b) * T + t) * 2 * NT;
-        for (int s = lane; s < S; s += 64) xw[s] = a[s] * bt[s];  // (path mass through the state) x p_t(class), scaled
+        // (path mass through the state) x p_t(class), scaled.  alpha and beta may each lie hundreds of binary orders
+        // below the largest state of their frame, and a plain product of two such doubles underflows: the products
+        // are formed on the mantissas and scaled by their exponents RELATIVE to the frame's largest product, 2^pmax.
+        int pmax = 0;
+        for (int s = lane; s < S; s += 64) {
+          const int ea = ctc_exponent(a[s]), eb = ctc_exponent(bt[s]);
+          pmax = max(pmax, (ea > 0 && eb > 0) ? ea + eb : 0);
+        }
+        pmax = ctc_wave_max(pmax);  // biased twice: true exponent pmax - 2046; 0: every product is zero
+        for (int s = lane; s < S; s += 64) {
+          const double av = a[s], bv = bt[s];
+          const int ea = ctc_exponent(av), eb = ctc_exponent(bv), rel = ea + eb - pmax;  // <= 0
+          const double ma = __hiloint2double((__double2hiint(av) & 0x800FFFFF) | (1023 << 20), __double2loint(av));
+          const double mb = __hiloint2double((__double2hiint(bv) & 0x800FFFFF) | (1023 << 20), __double2loint(bv));
+          xw[s] = (ea > 0 && eb > 0 && rel > -1000) ? ma * mb * __hiloint2double((1023 + rel) << 20, 0) : 0.0;
+        }
         ctc_wave_sync();
         double sum = 0.0;
         for (int i = lane; i <= L; i += 64) sum += xw[2 * i];  // blank class: states 0, 2, .., 2L over the lanes
@@ -685,7 +715,7 @@ __global__ __launch_bounds__(64 * ctc_grad_waves(NW)) void k_ctc_grad(
         if (sum > 0.0) {
           const int e2 = ctc_exponent(sum) - 1022;  // sum = m 2^e2, m in [0.5, 1)
           const double m = __hiloint2double((__double2hiint(sum) & 0x800FFFFF) | (1022 << 20), __double2loint(sum));
-          const double arg = (double)(ex_alpha[t] + ex_beta[t] + e2) * 0.6931471805599453 + nll - (double)lpc;
+          const double arg = (double)(ex_alpha[t] + ex_beta[t] + e2 + pmax - 2046) * 0.6931471805599453 + nll - (double)lpc;
           occ = (float)m * __expf((float)arg);
         }
         g = w * (__expf(lpc) - occ);

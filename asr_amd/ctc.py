@@ -86,6 +86,14 @@ def pack_targets(targets: torch.Tensor, target_lengths: torch.Tensor, total: Opt
     B, L = targets.shape
     if target_lengths.numel() != B:
         raise RuntimeError(f"pack_targets: {target_lengths.numel()} lengths for {B} utterances")
+    if total is not None:
+        total = int(total)
+        if total < 0 or total > B * L:
+            raise RuntimeError(f"pack_targets: total = {total} labels cannot come from {B} utterances of at most {L}")
+        if not target_lengths.is_cuda:
+            have = int(target_lengths.clamp(min=0, max=L).sum())
+            if have != total:
+                raise RuntimeError(f"pack_targets: total = {total}, but the lengths (clamped to max_len = {L}) sum to {have}")
     t = targets.to(torch.int64)
     if t.stride(1) != 1:
         t = t.contiguous()
@@ -138,7 +146,13 @@ def ctc_loss(log_probs: torch.Tensor, targets: torch.Tensor, input_lengths: torc
     """Mean-reduced CTC loss of log_probs [batch, frames, vocab] (batch first, as the model produces them) against
     the padded labels targets [batch, max_len]: what nn.CTCLoss(blank, reduction='mean', zero_infinity) returns for
     log_probs.transpose(0, 1) in the reference (src/models/asr_model.py:105, 144-154), with autograd.  HIP kernel
-    k_ctc_loss (loss and gradient in one launch, no target packing, lengths stay on the device)."""
+    k_ctc_loss (loss and gradient in one launch, no target packing, lengths stay on the device).
+
+    Range: the recursions run in the linear domain on doubles, rescaled every fourth frame by the frame's largest
+    state.  Log-probabilities down to about -170 per frame are exact; states more than e^-700 below the largest state
+    of their frame are flushed to zero.  An utterance all of whose alignments run through such states -- e.g. L labels
+    whose log-probabilities average below -700 / L on the way while the blank stays near 1 -- gets an infinite term,
+    which zero_infinity zeroes, where torch's log-domain kernel returns a large finite loss."""
     if not log_probs.is_cuda:
         raise RuntimeError(f"ctc_loss: log_probs live on {log_probs.device}; this runs only as a HIP kernel on a GPU "
                            "(there is no CPU fallback)")

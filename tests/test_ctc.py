@@ -177,6 +177,43 @@ def test_ctc_loss_kernel_matches_oracle(B, T, V, Lmax):
 
 
 @pytest.mark.gpu
+def test_ctc_loss_kernel_keeps_tiny_probabilities():
+    """Log-probabilities far below fp32's exp range (-87) on every alignment's way: the label the utterance needs
+    has probability e^-100 .. e^-120 in every frame (the linear-domain recursion rescales every fourth frame by the
+    largest state, so what must fit a double is four such frames in a row and the spread of a frame's states).  The loss is large but finite and its gradient is useful (torch's
+    log-domain kernel agrees); computed with exp in fp32 the paths vanished, the term became infinite and
+    zero_infinity zeroed loss and gradient."""
+    from asr_amd.ctc import ctc_loss
+
+    dev = torch.device("cuda:0")
+    B, T, V, Lmax = 4, 40, 34, 6
+    lp, targets, il, tl = _ctc_case(5, B, T, V, Lmax, full_lengths=True)
+    il[:] = T
+    logits = torch.randn(B, T, V, generator=torch.Generator().manual_seed(6))
+    # utterance 0: one label repeated Lmax times needs Lmax label frames and Lmax - 1 blanks among 40 frames; with
+    # only 10 frames every frame is on some needed path, and in all of them the label and the blank are crushed
+    il[0] = 2 * Lmax - 1
+    targets[0, :] = 3
+    logits[0, :, 3] -= 120.0
+    logits[0, :, V - 1] -= 100.0
+    # utterance 1: every label crushed by -100 in every frame (its complete paths lie e^-600 below the all-blank
+    # prefix, which sets the scale of a frame's states: inside the e^-700 a double gives the linear-domain recursion)
+    for j in range(Lmax):
+        logits[1, :, int(targets[1, j])] -= 100.0
+    lp = logits.log_softmax(-1)
+    assert float(lp.min()) < -110
+    x = lp.to(dev).requires_grad_(True)
+    loss = ctc_loss(x, targets.to(dev), il.to(dev), tl.to(dev), V - 1, True)
+    loss.backward()
+    want, grad = co.ctc_loss_and_grad(lp.double().numpy(), targets.numpy(), il.numpy(), tl.numpy(), V - 1, True)
+    assert np.isfinite(want) and want > 80  # the crushed utterances dominate the mean
+    assert abs(float(loss.detach()) - want) <= 1e-5 * abs(want), (float(loss.detach()), want)
+    got = x.grad.cpu().double().numpy()
+    assert np.abs(got[:2]).max() > 0  # not zeroed
+    assert np.abs(got - grad).max() <= 1e-4 * np.abs(grad).max() + 1e-7
+
+
+@pytest.mark.gpu
 def test_ctc_loss_kernel_matches_torch_on_the_gpu_and_is_deterministic():
     from asr_amd.ctc import ctc_loss
 

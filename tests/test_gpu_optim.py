@@ -249,3 +249,17 @@ def test_packed_targets_feed_ctc_loss_like_the_reference_loop():
     ref = torch.nn.functional.ctc_loss(lp.cpu(), torch.from_numpy(oo.pack_targets(targets.numpy(), tl.numpy())), il, tl,
                                        blank=V - 1, zero_infinity=True)
     assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
+
+
+def test_pack_targets_refuses_a_total_that_cannot_be_right():
+    from asr_amd import pack_targets
+
+    dev = _dev()
+    targets = torch.arange(5 * 7, device=dev).reshape(5, 7) % 30
+    lengths = torch.tensor([7, 3, 0, 9, 2])  # 9 is clamped to max_len = 7 by the kernel
+    packed, offsets = pack_targets(targets, lengths, total=19)
+    assert packed.numel() == 19 and int(offsets[-1]) == 19
+    with pytest.raises(RuntimeError, match="sum to 19"):
+        pack_targets(targets, lengths, total=21)           # the unclamped sum: a stale total
+    with pytest.raises(RuntimeError, match="cannot come from"):
+        pack_targets(targets, lengths.to(dev), total=36)   # device lengths: only the bound is checked
