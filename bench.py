@@ -777,7 +777,8 @@ def main():
                 sub, _ = bench_layer_stack(args, dev, rank, world, bsz, 40, 5, detail=False)
                 sweep.append({"batch_per_gpu": bsz, "ms_per_step": sub["ms_per_step"], "value": sub["value"],
                               "frac_of_peak_wall": sub["step_hbm"]["frac_of_peak_wall"],
-                              "kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in sub["kernels"].items()}})
+                              "kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in sub["kernels"].items()
+                                                 if v["launches_per_step"] > 0}})
                 del sub
                 torch.cuda.empty_cache()
             out["batch_sweep"] = sweep
