@@ -135,6 +135,36 @@ def linear_weight_grad_bf16(x: torch.Tensor, dy: torch.Tensor, want_bias: bool =
     return dW, db
 
 
+# True: weight gradients that are written straight into a gradient bucket run on a side stream, beside the rest of
+# the backward (nothing downstream depends on them); asr_amd.parallel.GradBuckets joins the stream before it
+# exchanges or hands out gradients.  Off by default; the results are the same numbers either way.
+ASYNC_WEIGHT_GRAD = False
+
+
+def _weight_grad_into_slots(xb, dyb, has_bias, slot_w, slot_b):
+    """linear_weight_grad_bf16 into bucket slices -- on the side stream when ASYNC_WEIGHT_GRAD is on and every
+    output is a bucket slice (a gradient handed back to autograd could be accumulated on this stream at once)."""
+    from . import functional as F
+
+    if not (ASYNC_WEIGHT_GRAD and slot_w is not None and (slot_b is not None or not has_bias)):
+        if ASYNC_WEIGHT_GRAD:
+            # this gradient goes back to autograd, which may add it into `.grad` -- a bucket slice that a gradient
+            # of the same step may still be writing on the side stream -- on this stream at once
+            F.join_async_weight_grads(xb.device)
+        return linear_weight_grad_bf16(xb, dyb, has_bias, slot_w, slot_b)
+
+    dev = xb.device
+    side = F._wgrad_stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        dW, db = linear_weight_grad_bf16(xb, dyb, has_bias, slot_w, slot_b)
+        done = torch.cuda.Event()
+        done.record(side)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    F._ASYNC_WGRAD.setdefault(key, []).append((done, (xb, dyb, dW, db)))
+    return dW, db
+
+
 def linear_weight_prep(weights, biases):
     """(W16 [N_pad, K], W16^T [K, N_pad], bias as autocast sees it [N_pad] fp32 or None) for the concatenation of the
     given fp32 weights [N_i, K] (and biases, all or none): one kernel launch per weight instead of cast, transpose
@@ -202,7 +232,7 @@ class _LinearTrain(torch.autograd.Function):
             weight, bias = ctx.params
             slot_w = None if ctx.pad else grad_slot(weight)
             slot_b = grad_slot(bias) if ctx.has_bias and not ctx.pad else None
-            dW, db = linear_weight_grad_bf16(xb, dyb, ctx.has_bias, slot_w, slot_b)
+            dW, db = _weight_grad_into_slots(xb, dyb, ctx.has_bias, slot_w, slot_b)
             if slot_w is not None:
                 dW = adopt(dW)
             if slot_b is not None:
@@ -240,7 +270,7 @@ class _FusedLinearTrain(torch.autograd.Function):
             dx = linear_bf16(dyb, w16t).to(ctx.x_dtype)
         fw = fused_slot(weights)
         fb = fused_slot(biases)
-        dW, db = linear_weight_grad_bf16(xb, dyb, True, None if fw is None else fw[0], None if fb is None else fb[0])
+        dW, db = _weight_grad_into_slots(xb, dyb, True, None if fw is None else fw[0], None if fb is None else fb[0])
         rows = [w.shape[0] for w in weights]
         gw = [adopt(s) for s in fw[1]] if fw is not None else list(torch.split(dW, rows))
         gb = [adopt(s) for s in fb[1]] if fb is not None else list(torch.split(db, rows))

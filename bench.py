@@ -335,6 +335,11 @@ def bench_full_step(args, dev, rank, world, steps=None, warmup=None):
             torch.nn.init.zeros_(mod.bias)
     enc = model.encoder
     enc.bf16_stream = bool(args.bf16_stream)
+    if args.async_wgrad:  # weight gradients of the Linear and LMUFFT layers on a side stream (a branch of the graph)
+        import asr_amd.linear as _lin
+        _lin.ASYNC_WEIGHT_GRAD = True
+        for l in enc.lmu_layers:
+            l.async_weight_grad = True
     buckets = GradBuckets(model.bucket_groups(), bucket_mb=args.bucket_mb if args.bucket_mb is not None else 4.0,
                           overlap=not args.no_overlap, exchange_single_rank=args.exchange_single_rank)
     # the step count and the learning rate live in device memory, so that the whole step -- optimizer and

@@ -219,13 +219,17 @@ def test_training_linear_matches_oracle(rows, K, N, with_bias):
 
 
 @pytest.mark.gpu
-def test_training_linear_writes_into_gradient_buckets():
+@pytest.mark.parametrize("side_stream", [False, True])
+def test_training_linear_writes_into_gradient_buckets(side_stream, monkeypatch):
     """Parameters of a GradBuckets: the weight-gradient kernel writes into the bucket, `.grad` IS the bucket's slice
     (no clearing between steps, no accumulation kernel), a second use in the same step adds; the padded
-    vocabulary width takes the copy route and lands in the bucket as well."""
+    vocabulary width takes the copy route and lands in the bucket as well.  With ASYNC_WEIGHT_GRAD the bucket-bound
+    gradients run on the side stream (joined by finish(), and before a second use's gradient is accumulated)."""
+    import asr_amd.linear as lin
     from asr_amd.linear import linear_train
     from asr_amd.parallel import GradBuckets
 
+    monkeypatch.setattr(lin, "ASYNC_WEIGHT_GRAD", side_stream)
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     a, head = torch.nn.Linear(64, 48).to(dev), torch.nn.Linear(48, 34).to(dev)
