@@ -1697,6 +1697,327 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_bf16(const bf16_t* __restric
   LMUFFT_STAMP(1, 3);
 }
 
+// ---------------------------------------------------------------------------
+// The same product and the same slabs on eight waves (used when every row is 16-byte friendly).
+// k_wgrad_bf16 runs one wave per SIMD -- its two operand stages fill the LDS a workgroup can have, and a second
+// workgroup per CU would double the slabs -- so nobody covers a wave's LDS and memory latency.  Here a workgroup is
+// two groups of four waves; a group has the tile and wave layout of k_wgrad_bf16 (a wave owns 64 x 96), its own two
+// LDS stages of 32 rows, its own two register sets, and takes every other 32-row k-tile of the workgroup's row range
+// into accumulators of its own.  The fragment reads per MFMA are those of the four-wave kernel (eight waves on ONE
+// staged tile would read four fragments for three MFMAs instead of five for six, and the transposing reads are the
+// limit); the second wave on a SIMD comes from the k split instead.  After the loop the second group's sums pass
+// through LDS and are added to the first group's, which writes the slab.
+// The small gradients are VALU sums over the fragments a wave holds anyway, again in turns of one k-step per wave:
+//   gb_h: the eight k values of an A fragment lane;  gw_u: the eight k values of a B fragment lane times ga[k]
+// (five registers instead of the 80 accumulator registers of the MFMA form, which would not leave two waves a SIMD's
+// register file; ga enters in fp32).
+// ---------------------------------------------------------------------------
+constexpr int kWgPairBK = 32;
+constexpr int kWgPairThreads = 512;
+using WgradPairTile = TileB<WgradTileB::BM, WgradTileB::BN, kWgPairBK, WgradTileB::WGM, WgradTileB::WGN>;
+constexpr int kWgPairLdA = WgradPairTile::BM + 32, kWgPairLdB = WgradPairTile::BN + 32;
+constexpr int kWgPairStageElems = kWgPairBK * (kWgPairLdA + kWgPairLdB) + 2 * kWgPairBK;  // A | B | ga (BK floats)
+constexpr int kWgPairExFloats = WgradPairTile::TM * WgradPairTile::TN * 16 + WgradPairTile::TM + WgradPairTile::TN + 1;
+constexpr size_t kWgPairLds =
+    std::max(std::max(sizeof(bf16_t) * 4 * (size_t)kWgPairStageElems, sizeof(float) * 256 * (size_t)kWgPairExFloats),
+             sizeof(float) * (size_t)WgradPairTile::BM * (WgradPairTile::BN + 4));
+static_assert((kWgPairLdA * 2) % 256 == 64 && (kWgPairLdB * 2) % 256 == 192, "four k rows land on distinct bank quarters");
+static_assert(WgradTileB::BK == 2 * kWgPairBK, "a row range is a whole number of tile pairs");
+
+__global__ __launch_bounds__(kWgPairThreads) void k_wgrad_pair_bf16(const bf16_t* __restrict__ gz,
+                                                                    const bf16_t* __restrict__ m,
+                                                                    const bf16_t* __restrict__ x,
+                                                                    const float* __restrict__ ga,
+                                                                    float* __restrict__ slabs, int rows,
+                                                                    int rows_per_split, int M, int D, int Hd,
+                                                                    int tile_blocks) {
+  using TL = WgradPairTile;
+  constexpr int GT = 256;                                     // threads of a group
+  constexpr int NVA = TL::BM * TL::BK / 8 / GT, NVB = TL::BN * TL::BK / 8 / GT;  // staging vectors per thread
+  constexpr int KSN = TL::BK / 16;
+  constexpr int LDA = kWgPairLdA, LDB = kWgPairLdB;
+  constexpr int kElemsA = TL::BK * LDA;
+  static_assert(NVA * GT * 8 == TL::BM * TL::BK && NVB * GT * 8 == TL::BN * TL::BK, "whole vectors per thread");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+  const int MD = M + D;
+  const int grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+  const int tid = threadIdx.x & (GT - 1), lane = threadIdx.x & 63;
+  const int tiles_j = (MD + TL::BN - 1) / TL::BN, tiles_n = (Hd + TL::BM - 1) / TL::BM;
+  const int inner = tiles_j * tiles_n / tile_blocks;
+  XcdSlot slot = xcd_slot(inner);
+  slot.member += (slot.group % tile_blocks) * inner;
+  slot.group /= tile_blocks;
+  const int tile_j = slot.member % tiles_j, tile_n = slot.member / tiles_j;
+  const int j0 = tile_j * TL::BN;
+  const int n0 = tile_n * TL::BM;
+  const int kbeg = slot.group * rows_per_split;
+  if (kbeg >= rows) return;
+  const int kend = min(rows, kbeg + rows_per_split);
+  const long off_gbh = ((long)Hd * MD + 3) & ~3L, off_gwu = off_gbh + (long)tiles_j * TL::WGN * ((Hd + 3) & ~3),
+             off_gbu = off_gwu + (long)tiles_n * TL::WGM * ((D + 3) & ~3);
+  float* slab = slabs + slot.group * (off_gbu + 4);
+
+  WavePos<TL> w;  // position inside the group
+  {
+    const int gw = (tid >> 6);
+    w.wm0 = (gw / TL::WGN) * TL::WM;
+    w.wn0 = (gw % TL::WGN) * TL::WN;
+  }
+  f32x16 acc[TL::TM][TL::TN];
+  tileb_zero<TL>(acc);
+  float accb[TL::TM], accu[TL::TN];
+#pragma unroll
+  for (int t = 0; t < TL::TM; ++t) accb[t] = 0.f;
+#pragma unroll
+  for (int t = 0; t < TL::TN; ++t) accu[t] = 0.f;
+  // turns: the k-step with global number gk belongs to the wave with slot gk % RB (gb_h) / gk % RU (gw_u) among the
+  // waves that hold the same fragment; this group's tiles are the 32-row tiles 2 i + grp of the row range
+  const int RB = tiles_j * TL::WGN, RU = tiles_n * TL::WGM;
+  const int slot_b = tile_j * TL::WGN + w.wn0 / TL::WN, slot_u = tile_n * TL::WGM + w.wm0 / TL::WM;
+  int pos_b = (grp * KSN) % RB, pos_u = (grp * KSN) % RU;
+
+  bf16_t* const gsmem = smem + grp * 2 * kWgPairStageElems;
+  auto stage_A = [&](int st) { return gsmem + st * kWgPairStageElems; };
+  auto stage_B = [&](int st) { return gsmem + st * kWgPairStageElems + kElemsA; };
+  auto stage_ga = [&](int st) { return reinterpret_cast<float*>(gsmem + st * kWgPairStageElems + kElemsA + TL::BK * LDB); };
+  // fragment addressing of ds_read_b64_tr_b16: in each 16-lane group lane 4 q + p addresses k row q, elements
+  // 4 p .. 4 p + 3, and receives the four k values of column (lane & 15)
+  const int fq = (lane & 15) >> 2, fp = lane & 3, fg1 = (lane >> 4) & 1;
+  const int foffA = (8 * w.hh + fq) * LDA + 16 * fg1 + 4 * fp, foffB = (8 * w.hh + fq) * LDB + 16 * fg1 + 4 * fp;
+  auto frag = [&](const bf16_t* a0, int ld) -> bf16x8 {
+    typedef bf16x4 __attribute__((address_space(3))) * lds_ptr;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(a0));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(a0 + 4 * ld));
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j] = lo[j];
+      v[4 + j] = hi[j];
+    }
+    return v;
+  };
+
+  // staging: running pointers, rows at or beyond kend come from the zero line (see k_wgrad_bf16)
+  bf16x8 ra[2][NVA], rb[2][NVB];
+  float ga_reg[2] = {0.f, 0.f}, gbu = 0.f;
+  const bf16_t* const zero_line = reinterpret_cast<const bf16_t*>(kZeroBytes);
+  const bf16_t* pa[NVA];
+  const bf16_t* pb[NVB];
+  int inc_b[NVB];
+  unsigned col_ok = 0;  // bit i: A vector i inside Hd; bit 8 + i: B vector i inside M + D
+  const int kg = kbeg + grp * TL::BK;  // the group's first tile; its tile i starts at kg + 2 BK i
+#pragma unroll
+  for (int i = 0; i < NVA; ++i) {
+    const int idx = tid + i * GT;
+    const int c = n0 + (idx % (TL::BM / 8)) * 8, kr = idx / (TL::BM / 8);
+    pa[i] = gz + (long)(kg + kr) * Hd + c;
+    col_ok |= (c < Hd ? 1u : 0u) << i;
+  }
+#pragma unroll
+  for (int i = 0; i < NVB; ++i) {
+    const int idx = tid + i * GT;
+    const int j = j0 + (idx % (TL::BN / 8)) * 8, kr = idx / (TL::BN / 8);
+    pb[i] = j < M ? m + (long)(kg + kr) * M + j : x + (long)(kg + kr) * D + (j - M);
+    inc_b[i] = 2 * TL::BK * (j < M ? M : D);
+    col_ok |= (j < MD ? 1u : 0u) << (8 + i);
+  }
+  auto fetch = [&](auto set_c, int k0) __attribute__((always_inline)) {
+    constexpr int set = decltype(set_c)::value;
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) {
+      const int kr = (tid + i * GT) / (TL::BM / 8);
+      const bf16_t* p = (((col_ok >> i) & 1u) && k0 + kr < kend) ? pa[i] : zero_line;
+      ra[set][i] = *reinterpret_cast<const bf16x8*>(p);
+      pa[i] += (long)2 * TL::BK * Hd;
+    }
+#pragma unroll
+    for (int i = 0; i < NVB; ++i) {
+      const int kr = (tid + i * GT) / (TL::BN / 8);
+      const bf16_t* p = (((col_ok >> (8 + i)) & 1u) && k0 + kr < kend) ? pb[i] : zero_line;
+      rb[set][i] = *reinterpret_cast<const bf16x8*>(p);
+      pb[i] += inc_b[i];
+    }
+    if (tid < TL::BK) ga_reg[set] = (ga && k0 + tid < kend) ? ga[k0 + tid] : 0.f;
+  };
+  // the part of a tile's LDS stores that is issued during k-step ks (ks < 0: all of them)
+  auto store_part = [&](auto set_c, int st, int ks) __attribute__((always_inline)) {
+    constexpr int set = decltype(set_c)::value;
+    bf16_t* sa = stage_A(st);
+    bf16_t* sb = stage_B(st);
+#pragma unroll
+    for (int i = 0; i < NVA; ++i)
+      if (ks < 0 || i % KSN == ks) {
+        const int idx = tid + i * GT;
+        *reinterpret_cast<bf16x8*>(&sa[(idx / (TL::BM / 8)) * LDA + (idx % (TL::BM / 8)) * 8]) = ra[set][i];
+      }
+#pragma unroll
+    for (int i = 0; i < NVB; ++i)
+      if (ks < 0 || i % KSN == ks) {
+        const int idx = tid + i * GT;
+        *reinterpret_cast<bf16x8*>(&sb[(idx / (TL::BN / 8)) * LDB + (idx % (TL::BN / 8)) * 8]) = rb[set][i];
+      }
+    if ((ks < 0 || ks == KSN - 1) && tid < TL::BK) {
+      stage_ga(st)[tid] = ga_reg[set];
+      gbu += ga_reg[set];
+    }
+  };
+  // round of the tile at k0, which sits in stage st; the group's next tile waits in register set `set_c`, and
+  // that set is refilled with the tile three ahead
+  auto round = [&](auto set_c, int k0, int st) __attribute__((always_inline)) {
+    const bf16_t* sA = stage_A(st) + foffA + w.wm0;
+    const bf16_t* sB = stage_B(st) + foffB + w.wn0;
+    const float* gaS = stage_ga(st);
+    bf16x8 fa[2][TL::TM], fb[2][TL::TN];
+    auto read_frags = [&](int buf, int kl) __attribute__((always_inline)) {
+#pragma unroll
+      for (int tm = 0; tm < TL::TM; ++tm) fa[buf][tm] = frag(sA + kl * LDA + tm * 32, LDA);
+#pragma unroll
+      for (int tn = 0; tn < TL::TN; ++tn) fb[buf][tn] = frag(sB + kl * LDB + tn * 32, LDB);
+    };
+    read_frags(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < KSN; ++ks) {
+      const int kl = ks * 16;
+      bf16x8(&af)[TL::TM] = fa[ks & 1];
+      bf16x8(&bfr)[TL::TN] = fb[ks & 1];
+      if (ks + 1 < KSN) read_frags((ks + 1) & 1, kl + 16);
+      store_part(set_c, st ^ 1, ks);  // that stage was last read before the previous barrier
+#pragma unroll
+      for (int tm = 0; tm < TL::TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TL::TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bfr[tn], acc[tm][tn], 0, 0, 0);
+      if (pos_b == slot_b) {  // wave-uniform
+#pragma unroll
+        for (int tm = 0; tm < TL::TM; ++tm) {
+          float sum = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sum += (float)af[tm][j];
+          accb[tm] += sum;
+        }
+      }
+      pos_b = pos_b + 1 == RB ? 0 : pos_b + 1;
+      if (pos_u == slot_u) {  // wave-uniform
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(&gaS[kl + 8 * w.hh]);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(&gaS[kl + 8 * w.hh + 4]);
+#pragma unroll
+        for (int tn = 0; tn < TL::TN; ++tn) {
+          float sum = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sum += (j < 4 ? g0[j] : g1[j - 4]) * (float)bfr[tn][j];
+          accu[tn] += sum;
+        }
+      }
+      pos_u = pos_u + 1 == RU ? 0 : pos_u + 1;
+    }
+#pragma unroll
+    for (int ks = 0; ks < KSN; ++ks) {  // the other group's tile
+      pos_b = pos_b + 1 == RB ? 0 : pos_b + 1;
+      pos_u = pos_u + 1 == RU ? 0 : pos_u + 1;
+    }
+    fetch(set_c, k0 + 3 * 2 * TL::BK);  // the set's registers are free once its tile has gone to LDS
+    __syncthreads();
+  };
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
+  const int ntile = (kend - kbeg + TL::BK - 1) / TL::BK;  // 32-row tiles of the range
+  const int nround = (ntile + 1) / 2;                     // both groups run every round (tiles past kend are zeros)
+  fetch(Set0{}, kg);
+  fetch(Set1{}, kg + 2 * TL::BK);
+  store_part(Set0{}, 0, -1);
+  fetch(Set0{}, kg + 4 * TL::BK);
+  __syncthreads();
+  {
+    int i = 0;
+    for (; i + 1 < nround; i += 2) {
+      round(Set1{}, kg + 2 * TL::BK * i, 0);
+      round(Set0{}, kg + 2 * TL::BK * (i + 1), 1);
+    }
+    if (i < nround) round(Set1{}, kg + 2 * TL::BK * i, 0);  // odd number of rounds
+  }
+
+  // the second group's sums -> LDS -> added to the first group's (the operand stages are free after the loop's last
+  // barrier); value v of thread tid sits at ex[v * 256 + tid]
+  float* ex = reinterpret_cast<float*>(smem_raw);
+  if (grp == 1) {
+#pragma unroll
+    for (int tm = 0; tm < TL::TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TL::TN; ++tn)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ex[((tm * TL::TN + tn) * 16 + i) * GT + tid] = acc[tm][tn][i];
+    constexpr int base = TL::TM * TL::TN * 16;
+#pragma unroll
+    for (int tm = 0; tm < TL::TM; ++tm) ex[(base + tm) * GT + tid] = accb[tm];
+#pragma unroll
+    for (int tn = 0; tn < TL::TN; ++tn) ex[(base + TL::TM + tn) * GT + tid] = accu[tn];
+    ex[(base + TL::TM + TL::TN) * GT + tid] = gbu;
+  }
+  __syncthreads();
+  if (grp == 0) {
+#pragma unroll
+    for (int tm = 0; tm < TL::TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TL::TN; ++tn)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[tm][tn][i] += ex[((tm * TL::TN + tn) * 16 + i) * GT + tid];
+    constexpr int base = TL::TM * TL::TN * 16;
+#pragma unroll
+    for (int tm = 0; tm < TL::TM; ++tm) accb[tm] += ex[(base + tm) * GT + tid];
+#pragma unroll
+    for (int tn = 0; tn < TL::TN; ++tn) accu[tn] += ex[(base + TL::TM + tn) * GT + tid];
+    gbu += ex[(base + TL::TM + TL::TN) * GT + tid];
+  }
+  __syncthreads();
+
+  // gW_h tile -> slab through LDS: 16-byte stores of whole row segments, by all eight waves
+  {
+    constexpr int LDT = TL::BN + 4;
+    float* tile = reinterpret_cast<float*>(smem_raw);
+    if (grp == 0) tileb_epilogue<TL>(acc, w, [&](int mm, int nn, float v) { tile[mm * LDT + nn] = v; });
+    __syncthreads();
+    const bool vec_out = (MD % 4 == 0);
+    for (int idx = threadIdx.x; idx < TL::BM * (TL::BN / 4); idx += kWgPairThreads) {
+      const int mm = idx / (TL::BN / 4), c = (idx % (TL::BN / 4)) * 4;
+      const int n = n0 + mm, j = j0 + c;
+      if (n >= Hd) continue;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&tile[mm * LDT + c]);
+      float* dst = slab + (long)n * MD + j;
+      if (vec_out && j + 3 < MD) {
+        *reinterpret_cast<f32x4*>(dst) = v;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (j + q < MD) dst[q] = v[q];
+      }
+    }
+  }
+  if (grp == 0) {
+    // a lane's sums cover the k values 8 hh .. 8 hh + 7 of every k-step: the two halves of the wave are added here
+    float* dstb = slab + off_gbh + (long)slot_b * ((Hd + 3) & ~3);
+#pragma unroll
+    for (int tm = 0; tm < TL::TM; ++tm) {
+      const float v = accb[tm] + __shfl_xor(accb[tm], 32);
+      const int n = n0 + w.wm0 + tm * 32 + w.r;
+      if (w.hh == 0 && n < Hd) dstb[n] = v;
+    }
+    float* dstu = slab + off_gwu + (long)slot_u * ((D + 3) & ~3);
+#pragma unroll
+    for (int tn = 0; tn < TL::TN; ++tn) {
+      const float v = accu[tn] + __shfl_xor(accu[tn], 32);
+      const int j = j0 + w.wn0 + tn * 32 + w.r;
+      if (w.hh == 0 && j >= M && j < MD) dstu[j - M] = v;
+    }
+    if (tile_n == 0 && tile_j == 0 && tid < 64) {  // gb_u = sum of ga over the row range
+      float v = gbu;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (tid == 0) slab[off_gbu] = v;
+    }
+  }
+}
+
 #ifdef LMUFFT_STAMPS
 extern "C" int lmufft_debug_stamps(long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(long long) * std::min(n, 8 * 4096));
@@ -2310,12 +2631,19 @@ static int backward_bf16_parts(int parts, const lmufft_shape* s, const void* x_,
     const dim3 grid(xcd_grid(p.S, cdivb(MD, TL::BN) * cdivb(s->Hd, TL::BM)));
     const size_t lds = std::max(2 * (sizeof(bf16_t) * (size_t)TL::BK * ((TL::BM + 32) + (TL::BN + 32)) + sizeof(float) * TL::BK),
                                 sizeof(float) * (size_t)TL::BM * (TL::BN + 4));
+    const bool pair = vec;  // eight waves, two k-interleaved groups
     if (hipFuncSetAttribute(vec ? (const void*)k_wgrad_bf16<true> : (const void*)k_wgrad_bf16<false>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return set_error("cannot reserve %zu bytes of LDS for k_wgrad_bf16", lds);
+    if (pair && hipFuncSetAttribute((const void*)k_wgrad_pair_bf16, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)kWgPairLds) != hipSuccess)
+      return set_error("cannot reserve %zu bytes of LDS for k_wgrad_pair_bf16", kWgPairLds);
     {
       PROFB("k_wgrad_bf16");
-      if (vec)
+      if (pair)
+        hipLaunchKernelGGL(k_wgrad_pair_bf16, grid, dim3(kWgPairThreads), kWgPairLds, st, (const bf16_t*)gz, m, x,
+                           (const float*)ga, wslab, (int)rows, p.rps, s->M, s->D, s->Hd, 1);
+      else if (vec)
         hipLaunchKernelGGL(k_wgrad_bf16<true>, grid, dim3(kThreads), lds, st, (const bf16_t*)gz, m, x,
                            (const float*)ga, wslab, (int)rows, p.rps, s->M, s->D, s->Hd);
       else
@@ -2408,14 +2736,14 @@ int lmufft_linear_wgrad_bf16(const void* x, const void* dy, int64_t rows, int32_
   float* wslab = (float*)workspace;
   float* scratch = (float*)((char*)workspace + p.off_scratch);  // gw_u (in) | gb_u (1) | db when the layer has no bias
   const dim3 grid(xcd_grid((long)p.S * p.tile_blocks, p.tiles_j * p.tiles_n / p.tile_blocks));
-  const size_t lds = std::max(2 * (sizeof(bf16_t) * (size_t)TL::BK * ((TL::BM + 32) + (TL::BN + 32)) + sizeof(float) * TL::BK),
-                              sizeof(float) * (size_t)TL::BM * (TL::BN + 4));
-  if (hipFuncSetAttribute((const void*)k_wgrad_bf16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return set_error("cannot reserve %zu bytes of LDS for k_wgrad_bf16", lds);
+  if (hipFuncSetAttribute((const void*)k_wgrad_pair_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgPairLds) !=
+      hipSuccess)
+    return set_error("cannot reserve %zu bytes of LDS for k_wgrad_pair_bf16", kWgPairLds);
   {
     PROFB("k_linear_wgrad_bf16");
-    hipLaunchKernelGGL(k_wgrad_bf16<true>, grid, dim3(kThreads), lds, st, (const bf16_t*)dy, (const bf16_t*)nullptr,
-                       (const bf16_t*)x, (const float*)nullptr, wslab, (int)rows, p.rps, 0, in, out, p.tile_blocks);
+    hipLaunchKernelGGL(k_wgrad_pair_bf16, grid, dim3(kWgPairThreads), kWgPairLds, st, (const bf16_t*)dy,
+                       (const bf16_t*)nullptr, (const bf16_t*)x, (const float*)nullptr, wslab, (int)rows, p.rps, 0, in,
+                       out, p.tile_blocks);
   }
   LAUNCH_CHECKB("k_linear_wgrad_bf16");
   const SlabOutputs o{{dW, db ? db : scratch + in + 4, scratch, scratch + in},

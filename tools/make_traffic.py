@@ -23,7 +23,7 @@ def classify(name, seq):
     table = [("k_conv_proj_fwd_bf16", "k_conv_proj_fwd_bf16"), ("k_gu_q_bf16", "k_gu_q_bf16"),
              ("k_relu_bwd_q_bf16", "k_relu_bwd_bf16"), ("k_proj_fwd_glds_bf16", "k_proj_fwd_bf16"), ("k_proj_fwd_bf16", "k_proj_fwd_bf16"),
              ("k_conv_bwd2_bf16", "k_conv_bwd_bf16"), ("k_conv_bwd_bf16", "k_conv_bwd_bf16"),
-             ("k_conv_fwd_bf16", "k_conv_fwd_bf16"), ("k_wgrad_bf16", "k_wgrad_bf16"),
+             ("k_conv_fwd_bf16", "k_conv_fwd_bf16"), ("k_wgrad_pair_bf16", "k_wgrad_bf16"), ("k_wgrad_bf16", "k_wgrad_bf16"),
              ("k_relu_bwd_bf16", "k_relu_bwd_bf16"), ("k_encode_fwd_bf16", "k_encode_fwd_bf16"),
              ("k_encode_bwd_bf16", "k_encode_bwd_bf16"), ("k_prep_weights", "k_prep_weights"),
              ("k_reduce_slabs_tall", "k_reduce_slabs_tall"), ("k_reduce_slabs", "k_reduce_slabs"),
