@@ -186,7 +186,8 @@ def test_oracle_backward_matches_torch_autograd():
 @pytest.mark.gpu
 @pytest.mark.parametrize("rows,K,N,with_bias", [(64, 8, 8, True), (25600, 384, 384, True), (1000, 80, 384, False),
                                                 (777, 384, 1152, True), (130, 200, 40, True),
-                                                (2000, 384, 34, True), (300, 64, 5, False)])
+                                                (2000, 384, 34, True), (300, 64, 5, False),
+                                                (1, 8, 8, True), (33, 24, 16, True), (95, 384, 384, False)])
 def test_training_linear_matches_oracle(rows, K, N, with_bias):
     """linear_train (forward, input gradient, weight and bias gradient through the HIP kernels) against the oracle:
     y and dx at the bf16 bar of the forward tests, dW and db (fp32 results of bf16 operands) to 1e-4 of their
