@@ -436,7 +436,12 @@ int linear_impl(const void* x, const void* W, const float* bias, int64_t rows, i
       return set_error("linear: y, res, gamma and beta must be 16-byte aligned");
   }
   hipStream_t st = (hipStream_t)stream;
-  if (K <= kWsKS * 32) {  // weight-stationary persistent kernel
+  // One round of 128-row tiles on a single column tile (the training step's 384 -> 384 layers at batch 64 x 400
+  // frames: 200 workgroups) is faster on the tiled kernel, 17.6 against 22.7 us: the persistent kernel's prologue
+  // (295 KB of W into registers per workgroup) is paid for one or two 64-row tiles only.  More rows, the wide q|k|v
+  // projection (38 against 47 us) and narrow outputs stay weight-stationary (tools/linear_shapes_bench.py).
+  const bool one_round_tiled = K > 96 && N > 128 && N <= TL::BN && rows <= (int64_t)TL::BM * kComputeUnits;
+  if (K <= kWsKS * 32 && !one_round_tiled) {  // weight-stationary persistent kernel
     const int col_blocks = (N + kWsCols - 1) / kWsCols;
     const long ntiles = (rows + kWsRows - 1) / kWsRows;
     long per_block = std::max(1L, (long)kComputeUnits / col_blocks);
