@@ -20,7 +20,7 @@ CONV_TOEPLITZ = 1
 CONV_FFT = 2
 CONV_SCAN = 3
 NOALLOC_SCRATCH_BYTES = 8 << 20
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 
 class Shape(ctypes.Structure):
@@ -33,6 +33,22 @@ class Shape(ctypes.Structure):
         ("M", ctypes.c_int32),
         ("Hd", ctypes.c_int32),
         ("ldH", ctypes.c_int32),
+    ]
+
+
+class WprepItem(ctypes.Structure):
+    """Mirror of `lmufft_wprep_item` (include/lmufft.h)."""
+
+    _fields_ = [
+        ("W", ctypes.c_void_p),
+        ("bias", ctypes.c_void_p),
+        ("N", ctypes.c_int32),
+        ("K", ctypes.c_int32),
+        ("N_pad", ctypes.c_int32),
+        ("Wb", ctypes.c_void_p),
+        ("WbT", ctypes.c_void_p),
+        ("ldT", ctypes.c_int64),
+        ("bias_rounded", ctypes.c_void_p),
     ]
 
 
@@ -163,6 +179,8 @@ def _load():
     lib.lmufft_dropout_epoch.argtypes = [vp]
     lib.lmufft_linear_wprep_bf16.restype = ci
     lib.lmufft_linear_wprep_bf16.argtypes = [vp, vp, i32, i32, i32, vp, vp, i64, vp, vp]
+    lib.lmufft_linear_wprep_many_bf16.restype = ci
+    lib.lmufft_linear_wprep_many_bf16.argtypes = [ctypes.POINTER(WprepItem), i32, vp]
     lib.lmufft_linear_wgrad_workspace_bytes.restype = sz
     lib.lmufft_linear_wgrad_workspace_bytes.argtypes = [i64, i32, i32]
     lib.lmufft_linear_wgrad_bf16.restype = ci
@@ -231,6 +249,7 @@ EXPORTS = (
     "lmufft_linear_bf16",
     "lmufft_linear_ln_bf16",
     "lmufft_linear_wprep_bf16",
+    "lmufft_linear_wprep_many_bf16",
     "lmufft_linear_wgrad_workspace_bytes",
     "lmufft_linear_wgrad_bf16",
     "lmufft_ctc_workspace_bytes",

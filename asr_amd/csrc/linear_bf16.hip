@@ -487,12 +487,13 @@ int linear_impl(const void* x, const void* W, const float* bias, int64_t rows, i
 // consecutive threads on consecutive j, so that the strided reads of W coalesce across lanes.
 // ---------------------------------------------------------------------------
 namespace lmufft {
-__global__ __launch_bounds__(256) void k_linear_wprep(const float* __restrict__ W, const float* __restrict__ bias, int N,
-                                                      int K, int Np, bf16_t* __restrict__ Wb, bf16_t* __restrict__ WbT,
-                                                      long ldT, float* __restrict__ bias_r) {
+// blocks `block` of `nblocks` of one weight's conversion
+__device__ __forceinline__ void wprep_body(const float* __restrict__ W, const float* __restrict__ bias, int N, int K,
+                                           int Np, bf16_t* __restrict__ Wb, bf16_t* __restrict__ WbT, long ldT,
+                                           float* __restrict__ bias_r, int block, int nblocks) {
   const int g1 = K / 8, g2 = Np / 8;
   const long n1 = (long)Np * g1, n2 = (long)K * g2, n3 = bias_r ? Np : 0;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < n1 + n2 + n3; i += (long)gridDim.x * 256) {
+  for (long i = block * 256L + threadIdx.x; i < n1 + n2 + n3; i += (long)nblocks * 256) {
     if (i < n1) {
       const int n = (int)(i / g1), k0 = (int)(i % g1) * 8;
       bf16x8 o;
@@ -512,17 +513,59 @@ __global__ __launch_bounds__(256) void k_linear_wprep(const float* __restrict__ 
     }
   }
 }
+
+__global__ __launch_bounds__(256) void k_linear_wprep(const float* __restrict__ W, const float* __restrict__ bias, int N,
+                                                      int K, int Np, bf16_t* __restrict__ Wb, bf16_t* __restrict__ WbT,
+                                                      long ldT, float* __restrict__ bias_r) {
+  wprep_body(W, bias, N, K, Np, Wb, WbT, ldT, bias_r, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Several weights in one launch (a training step converts every Linear layer's weight: one launch instead of one per
+// weight).  The table travels as a kernel argument; workgroup b belongs to the item whose block range holds it.
+constexpr int kWprepMaxItems = 32;
+struct WprepBatch {
+  const float* W[kWprepMaxItems];
+  const float* bias[kWprepMaxItems];
+  bf16_t* Wb[kWprepMaxItems];
+  bf16_t* WbT[kWprepMaxItems];
+  float* bias_r[kWprepMaxItems];
+  long ldT[kWprepMaxItems];
+  int N[kWprepMaxItems], K[kWprepMaxItems], Np[kWprepMaxItems];
+  int first_block[kWprepMaxItems + 1];
+  int count;
+};
+__global__ __launch_bounds__(256) void k_linear_wprep_many(WprepBatch) {
+  // The table is read where it lies, in the kernel-argument segment, through scalar loads at a run-time index.
+  // (Indexing the by-value parameter itself at run time makes every thread keep a private copy of the 2 KB table,
+  // and picking the item with compile-time indices and selects spills scalar registers: 68 and 43 us for the step's
+  // fifteen weights.)
+  typedef const __attribute__((address_space(4))) WprepBatch* table_ptr;
+  table_ptr b = (table_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+  int it = 0;
+  for (int i = 1; i < b->count; ++i) it += (int)blockIdx.x >= b->first_block[i] ? 1 : 0;  // uniform
+  const int first = b->first_block[it];
+  wprep_body(b->W[it], b->bias[it], b->N[it], b->K[it], b->Np[it], b->Wb[it], b->WbT[it], b->ldT[it], b->bias_r[it],
+             (int)blockIdx.x - first, b->first_block[it + 1] - first);
+}
 }  // namespace lmufft
 
-extern "C" int lmufft_linear_wprep_bf16(const float* W, const float* bias, int32_t N, int32_t K, int32_t N_pad, void* Wb,
-                                        void* WbT, int64_t ldT, float* bias_rounded, void* stream) {
+static int wprep_check(const float* W, int32_t N, int32_t K, int32_t N_pad, const void* Wb, const void* WbT, int64_t ldT) {
   if (N <= 0 || K <= 0 || N_pad < N) return set_error("linear wprep: bad shape (N=%d K=%d N_pad=%d)", N, K, N_pad);
   if (K % 8 || N_pad % 8 || ldT % 8 || ldT < N_pad)
     return set_error("linear wprep: K, N_pad and ldT must be multiples of 8, ldT >= N_pad (got %d, %d, %lld)", K, N_pad, (long long)ldT);
   if (!W || !Wb || !WbT) return set_error("linear wprep: NULL pointer");
   if ((((uintptr_t)Wb | (uintptr_t)WbT) & 15) != 0) return set_error("linear wprep: outputs must be 16-byte aligned");
-  const long items = (long)N_pad * (K / 8) + (long)K * (N_pad / 8) + (bias_rounded ? N_pad : 0);
-  const int blocks = (int)std::min<long>((items + 255) / 256, 2048);
+  return 0;
+}
+static int wprep_blocks(int32_t K, int32_t N_pad, bool with_bias, int cap) {
+  const long items = (long)N_pad * (K / 8) + (long)K * (N_pad / 8) + (with_bias ? N_pad : 0);
+  return (int)std::min<long>((items + 255) / 256, cap);
+}
+
+extern "C" int lmufft_linear_wprep_bf16(const float* W, const float* bias, int32_t N, int32_t K, int32_t N_pad, void* Wb,
+                                        void* WbT, int64_t ldT, float* bias_rounded, void* stream) {
+  if (int rc = wprep_check(W, N, K, N_pad, Wb, WbT, ldT)) return rc;
+  const int blocks = wprep_blocks(K, N_pad, bias_rounded != nullptr, 2048);
   hipStream_t st = (hipStream_t)stream;
   {
     ProfScope ps("k_linear_wprep", st);
@@ -531,6 +574,40 @@ extern "C" int lmufft_linear_wprep_bf16(const float* W, const float* bias, int32
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error("launch of k_linear_wprep failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
+extern "C" int lmufft_linear_wprep_many_bf16(const lmufft_wprep_item* items, int32_t count, void* stream) {
+  if (count < 0 || (count > 0 && !items)) return set_error("linear wprep: bad item list");
+  for (int i = 0; i < count; ++i)
+    if (int rc = wprep_check(items[i].W, items[i].N, items[i].K, items[i].N_pad, items[i].Wb, items[i].WbT, items[i].ldT))
+      return rc;
+  hipStream_t st = (hipStream_t)stream;
+  for (int i0 = 0; i0 < count; i0 += kWprepMaxItems) {
+    WprepBatch b;
+    b.count = std::min(count - i0, kWprepMaxItems);
+    b.first_block[0] = 0;
+    for (int i = 0; i < b.count; ++i) {
+      const lmufft_wprep_item& it = items[i0 + i];
+      b.W[i] = it.W;
+      b.bias[i] = it.bias;
+      b.Wb[i] = (bf16_t*)it.Wb;
+      b.WbT[i] = (bf16_t*)it.WbT;
+      b.bias_r[i] = it.bias_rounded;
+      b.ldT[i] = (long)it.ldT;
+      b.N[i] = it.N;
+      b.K[i] = it.K;
+      b.Np[i] = it.N_pad;
+      // 256 blocks per weight at most: a step's fourteen weights together fill the chip several times over
+      b.first_block[i + 1] = b.first_block[i] + wprep_blocks(it.K, it.N_pad, it.bias_rounded != nullptr, 256);
+    }
+    {
+      ProfScope ps("k_linear_wprep", st);
+      hipLaunchKernelGGL(k_linear_wprep_many, dim3(b.first_block[b.count]), dim3(256), 0, st, b);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error("launch of k_linear_wprep_many failed: %s", hipGetErrorString(e));
+  }
   return 0;
 }
 

@@ -27,7 +27,7 @@ from torch import nn
 from .attention import (SUPPORTED_HEAD_WIDTHS, masked_attention, masked_attention_packed, masked_attention_train,
                         masked_attention_train_packed)
 from .layernorm import MAX_WIDTH as _LN_MAX_WIDTH, add_layer_norm, add_layer_norm_train
-from .linear import (fused_linear_train, linear_bf16, linear_train, supported as linear_supported,
+from .linear import (fused_linear_train, linear_bf16, linear_train, prepare_weights, supported as linear_supported,
                      train_supported as linear_train_supported)
 from .ctc import CTCDecoder
 from .lmu import LMUFFT
@@ -254,7 +254,35 @@ class LMUEncoder(nn.Module):
         # the bf16 tolerance.  Off by default.
         self.bf16_stream = False
 
-    def forward(self, x: torch.Tensor, lengths: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, list]:
+    def linear_groups(self, x: torch.Tensor) -> list:
+        """The (weights, biases) groups of this encoder's training projections, as asr_amd.linear.prepare_weights
+        takes them: the layers that _linear / fused_linear_train will run on the HIP kernels for an input like x."""
+        def one(layer):
+            return ([layer.weight], None if layer.bias is None else [layer.bias])
+
+        groups = []
+        if linear_train_supported(x, self.input_projection.weight):
+            groups.append(one(self.input_projection))
+        h = torch.empty((1, self.hidden_size), device=x.device, dtype=x.dtype)  # what the inner layers see
+        if self.use_attention:
+            for blk in self.attention_layers:
+                a = blk.attention
+                qkv = (a.w_q, a.w_k, a.w_v)
+                if a.d_k not in SUPPORTED_HEAD_WIDTHS:
+                    continue
+                if all(l.bias is not None for l in qkv) and linear_train_supported(h, a.w_q.weight):
+                    groups.append(([l.weight for l in qkv], [l.bias for l in qkv]))
+                else:
+                    groups += [one(l) for l in qkv if linear_train_supported(h, l.weight)]
+                if linear_train_supported(h, a.w_o.weight):
+                    groups.append(one(a.w_o))
+        if linear_train_supported(h, self.output_projection.weight):
+            groups.append(one(self.output_projection))
+        return groups
+
+    def forward(self, x: torch.Tensor, lengths: Optional[torch.Tensor] = None,
+                prepared: bool = False) -> Tuple[torch.Tensor, list]:
+        """`prepared`: the caller has run prepare_weights over linear_groups itself (with layers of its own)."""
         stream = torch.bfloat16 if (self.bf16_stream and x.is_cuda and torch.is_autocast_enabled()
                                     and torch.get_autocast_dtype("cuda") == torch.bfloat16) else None
         # The attention block's output has one consumer, the LMU layer, which under bf16 autocast rounds it to bf16
@@ -268,6 +296,8 @@ class LMUEncoder(nn.Module):
         # takes both gradients back in its backward; the last block's output has one reader (the output
         # projection) and is written in bf16 only.
         autocast16 = att_out == torch.bfloat16 and stream is None and torch.is_grad_enabled()
+        if autocast16 and not prepared:
+            prepare_weights(self.linear_groups(x))  # every projection's bf16 operands in one launch
         x = _linear(self.input_projection, x)
         states = []
         x16 = None
@@ -340,8 +370,18 @@ class LMUASRModel(nn.Module):
         src/models/asr_model.py:110-128).  Under bf16 autocast on the GPU the LMUFFT layers, attention, layer norms
         and every Linear (the vocabulary projection included) run this package's forward and backward kernels;
         dropout after the layer norms, residual adds and the log-softmax are torch ops."""
-        encoded, _ = self.encoder(spectrograms, input_lengths)
-        logits = _linear(self.decoder.ctc_projection, encoded)
+        enc, proj = self.encoder, self.decoder.ctc_projection
+        prepared = False
+        if (spectrograms.is_cuda and torch.is_grad_enabled() and not enc.bf16_stream and torch.is_autocast_enabled()
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+            # the bf16 operands of every projection of the step, the vocabulary projection included, in one launch
+            groups = enc.linear_groups(spectrograms)
+            if linear_train_supported(torch.empty((1, enc.hidden_size), device=spectrograms.device), proj.weight):
+                groups.append(([proj.weight], None if proj.bias is None else [proj.bias]))
+            prepare_weights(groups)
+            prepared = True
+        encoded, _ = enc(spectrograms, input_lengths, prepared=prepared)
+        logits = _linear(proj, encoded)
         return torch.log_softmax(logits.float(), dim=-1)
 
     def compute_loss(self, log_probs: torch.Tensor, targets: torch.Tensor, input_lengths: torch.Tensor,

@@ -165,10 +165,9 @@ def _weight_grad_into_slots(xb, dyb, has_bias, slot_w, slot_b):
     return dW, db
 
 
-def linear_weight_prep(weights, biases):
-    """(W16 [N_pad, K], W16^T [K, N_pad], bias as autocast sees it [N_pad] fp32 or None) for the concatenation of the
-    given fp32 weights [N_i, K] (and biases, all or none): one kernel launch per weight instead of cast, transpose
-    and two bias casts.  N_pad rounds the total output width up to a multiple of 8 with zero rows."""
+def _prep_items(weights, biases):
+    """Output tensors and the kernel's items for the concatenation of the given fp32 weights [N_i, K] (biases: all or
+    none): ((w16, w16t, b32), [WprepItem, ...], tensors to keep alive until the launch)."""
     K = weights[0].shape[1]
     N = sum(w.shape[0] for w in weights)
     Np = -(-N // 8) * 8
@@ -177,25 +176,83 @@ def linear_weight_prep(weights, biases):
     w16 = torch.empty((Np, K), dtype=torch.bfloat16, device=dev)
     w16t = torch.empty((K, Np), dtype=torch.bfloat16, device=dev)
     b32 = torch.empty((Np,), dtype=torch.float32, device=dev) if has_bias else None
-    n0 = 0
-    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    items, keep, n0 = [], [], 0
+    for i, w in enumerate(weights):
+        wd = w.detach().contiguous()
+        n = wd.shape[0]
+        last = i == len(weights) - 1
+        if (n % 8 and not last) or wd.shape[1] != K or wd.dtype != torch.float32:
+            raise RuntimeError("linear_weight_prep: float32 weights of one input width; only the last output width "
+                               "may be other than a multiple of 8")
+        npad = Np - n0 if last else n
+        bd = biases[i].detach().contiguous() if has_bias else None
+        keep += [wd, bd]
+        items.append(_lib.WprepItem(wd.data_ptr(), None if bd is None else bd.data_ptr(), n, K, npad,
+                                    w16.data_ptr() + n0 * K * 2, w16t.data_ptr() + n0 * 2, Np,
+                                    None if b32 is None else b32.data_ptr() + n0 * 4))
+        n0 += n
+    return (w16, w16t, b32), items, keep
+
+
+def _launch_prep(items, dev):
+    arr = (_lib.WprepItem * len(items))(*items)
     with torch.cuda.device(dev):
-        for i, w in enumerate(weights):
-            wd = w.detach().contiguous()
-            n = wd.shape[0]
-            last = i == len(weights) - 1
-            if (n % 8 and not last) or wd.shape[1] != K or wd.dtype != torch.float32:
-                raise RuntimeError("linear_weight_prep: float32 weights of one input width; only the last output width "
-                                   "may be other than a multiple of 8")
-            npad = Np - n0 if last else n
-            bd = biases[i].detach().contiguous() if has_bias else None
-            rc = _lib.lib.lmufft_linear_wprep_bf16(
-                _ptr(wd), _ptr(bd), n, K, npad, ctypes.c_void_p(w16.data_ptr() + n0 * K * 2),
-                ctypes.c_void_p(w16t.data_ptr() + n0 * 2), Np, None if b32 is None else ctypes.c_void_p(b32.data_ptr() + n0 * 4),
-                st)
-            _lib.check(rc, "lmufft_linear_wprep_bf16")
-            n0 += n
-    return w16, w16t, b32
+        rc = _lib.lib.lmufft_linear_wprep_many_bf16(arr, len(items),
+                                                    ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    _lib.check(rc, "lmufft_linear_wprep_many_bf16")
+
+
+# Operands prepared ahead of the layers' calls by prepare_weights: id(first weight) -> (weights, biases, operands).
+# An entry is handed out once, to the call with the very same parameter objects, and prepare_weights starts from an
+# empty table, so nothing prepared for one forward pass is seen by another.
+_PREPARED = {}
+
+
+def prepare_weights(groups) -> None:
+    """The training operands of several Linear layers in ONE kernel launch (linear_weight_prep launches once per
+    weight: fifteen launches in a step of the three-block encoder).  `groups`: [(weights, biases), ...], a group
+    being what ONE later linear_train / fused_linear_train call takes -- a single layer, or the layers of a fused
+    projection in order.  Call it at the start of a forward pass, before the layers; a layer whose parameters are
+    not in the table prepares its own operands as before."""
+    _PREPARED.clear()
+    items, keep, dev = [], [], None
+    for weights, biases in groups:
+        weights = list(weights)
+        biases = None if biases is None else list(biases)
+        out, its, k = _prep_items(weights, biases)
+        dev = weights[0].device
+        items += its
+        keep += k
+        _PREPARED[id(weights[0])] = (weights, biases, out)
+    if items:
+        _launch_prep(items, dev)
+
+
+def _take_prepared(weights, biases):
+    hit = _PREPARED.pop(id(weights[0]), None)
+    if hit is None:
+        return None
+    pw, pb, out = hit
+    same = len(pw) == len(weights) and all(a is b for a, b in zip(pw, weights))
+    if biases is None or pb is None:
+        same = same and (biases is None or all(b is None for b in biases)) and (pb is None or all(b is None for b in pb))
+    else:
+        same = same and len(pb) == len(biases) and all(a is b for a, b in zip(pb, biases))
+    return out if same else None
+
+
+def linear_weight_prep(weights, biases):
+    """(W16 [N_pad, K], W16^T [K, N_pad], bias as autocast sees it [N_pad] fp32 or None) for the concatenation of the
+    given fp32 weights [N_i, K] (and biases, all or none): one kernel launch instead of cast, transpose and two bias
+    casts per weight -- or none, when prepare_weights has made them already.  N_pad rounds the total output width up
+    to a multiple of 8 with zero rows."""
+    weights = list(weights)
+    ready = _take_prepared(weights, biases)
+    if ready is not None:
+        return ready
+    out, items, keep = _prep_items(weights, biases)
+    _launch_prep(items, weights[0].device)
+    return out
 
 
 class _LinearTrain(torch.autograd.Function):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMUFFT_ABI_VERSION 20
+#define LMUFFT_ABI_VERSION 21
 
 /* element types of the activations (x, h, gh, gx, m) */
 #define LMUFFT_F32 0
@@ -530,6 +530,21 @@ int lmufft_linear_bf16(const void* x, const void* W, const float* bias, int64_t 
  *   a wider concatenated weight);  bias_rounded [N_pad] f32 (may be NULL) = the bias rounded to bf16, widened. */
 int lmufft_linear_wprep_bf16(const float* W, const float* bias, int32_t N, int32_t K, int32_t N_pad, void* Wb,
                              void* WbT, int64_t ldT, float* bias_rounded, void* stream);
+
+/* The same conversion for several weights in ONE launch: a training step under autocast casts every Linear layer's
+ * weight (src/models/lmu_encoder.py:40-43, 184, 229; src/models/asr_model.py's CTC projection) -- fifteen launches of
+ * ~4 us at the reference's encoder sizes.  `items` is a HOST array (copied into the kernel's arguments); every item's
+ * fields mean what the arguments of lmufft_linear_wprep_bf16 mean. */
+typedef struct lmufft_wprep_item {
+  const float* W;
+  const float* bias;
+  int32_t N, K, N_pad;
+  void* Wb;
+  void* WbT;
+  int64_t ldT;
+  float* bias_rounded;
+} lmufft_wprep_item;
+int lmufft_linear_wprep_many_bf16(const lmufft_wprep_item* items, int32_t count, void* stream);
 
 /* The same GEMM followed, in its epilogue, by the residual add and layer norm of
  * the attention block: y = LN(bf16(x W^T + bias) + res) * gamma + beta

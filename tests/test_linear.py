@@ -296,3 +296,35 @@ def test_fused_linear_train_matches_the_separate_layers(adjacent):
         assert torch.allclose(a.bias.grad, b.bias.grad, rtol=1e-4, atol=1e-4 * float(b.bias.grad.abs().max()))
     lo, hi = buckets.arena.data_ptr(), buckets.arena.data_ptr() + buckets.arena.numel() * 4
     assert all(lo <= p.grad.data_ptr() < hi for l in layers for p in l.parameters())
+
+
+@pytest.mark.gpu
+def test_prepare_weights_matches_the_per_layer_preparation():
+    """One launch for several layers' training operands: the same bits as a launch per weight, handed out once and
+    only to a call with the very same parameter objects."""
+    from asr_amd import linear as L
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    mk = lambda n, k: (torch.nn.Parameter(torch.randn(n, k, device=dev)), torch.nn.Parameter(torch.randn(n, device=dev)))
+    (wq, bq), (wk, bk), (wv, bv) = mk(384, 384), mk(384, 384), mk(384, 384)
+    (wo, bo), (wi, bi), (wc, _) = mk(384, 384), mk(384, 80), mk(29, 384)
+    groups = [([wi], [bi]), ([wq, wk, wv], [bq, bk, bv]), ([wo], [bo]), ([wc], None)]
+    L._PREPARED.clear()
+    ref = [L.linear_weight_prep(w, b) for w, b in groups]  # a launch per weight
+    L.prepare_weights(groups)
+    assert len(L._PREPARED) == len(groups)
+    for (w, b), r in zip(groups, ref):
+        got = L.linear_weight_prep(w, b)  # from the table: no launch
+        for a, e in zip(got, r):
+            assert (a is None) == (e is None)
+            if a is not None:
+                assert a.shape == e.shape and torch.equal(a, e)
+    assert not L._PREPARED  # handed out once
+    # other parameter objects under the same first weight: not taken from the table
+    L.prepare_weights([([wq, wk, wv], [bq, bk, bv])])
+    assert L._take_prepared([wq, wk], [bq, bk]) is None and not L._PREPARED
+    # a vocabulary projection (29 rows) is padded to 32 with zero rows
+    w16, w16t, b32 = ref[3]
+    assert w16.shape == (32, 384) and w16t.shape == (384, 32) and b32 is None
+    assert torch.equal(w16[:29], wc.detach().to(torch.bfloat16)) and not w16[29:].any()
