@@ -821,6 +821,44 @@ int lmufft_ctc_pack_targets(const int64_t* targets, const int32_t* target_length
   return 0;
 }
 
+}  // extern "C" (reopened below)
+
+namespace lmufft {
+// loss = mean_b( nll[b] / max(target_lengths[b], 1) ), infinite terms zeroed when asked: the tail of
+// nn.CTCLoss(reduction='mean', zero_infinity) (src/models/asr_model.py:105) as one launch instead of seven
+// elementwise ones.  One workgroup; a fixed summation order.
+__global__ __launch_bounds__(256) void k_ctc_mean_loss(const float* __restrict__ nll, const int32_t* __restrict__ target_lengths,
+                                                       int B, int zero_infinity, float* __restrict__ loss) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const int len = target_lengths[b];
+    const float per = nll[b] / (float)(len < 1 ? 1 : len);
+    s += (zero_infinity && isinf(per)) ? 0.f : per;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = red[0] / (float)B;
+}
+}  // namespace lmufft
+
+extern "C" {
+
+int lmufft_ctc_mean_loss(const float* nll, const int32_t* target_lengths, int32_t B, int zero_infinity, float* loss,
+                         void* stream) {
+  if (B <= 0) return set_error("ctc mean loss: bad batch size %d", B);
+  if (!nll || !target_lengths || !loss) return set_error("ctc mean loss: NULL pointer");
+  hipLaunchKernelGGL(lmufft::k_ctc_mean_loss, dim3(1), dim3(256), 0, (hipStream_t)stream, nll, target_lengths, B,
+                     zero_infinity, loss);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error("launch of k_ctc_mean_loss failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
 // waves per workgroup: one thread per label position and one more, rounded up to 1, 2, 4, 8 or 16 waves
 static int ctc_loss_waves(int Lmax) {
   const int need = (Lmax + 1 + 63) / 64;

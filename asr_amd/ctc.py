@@ -127,13 +127,15 @@ class _CTCLoss(torch.autograd.Function):
             rc = _lib.lib.lmufft_ctc_loss(p(lp), p(targets), targets.stride(0), p(input_lengths), p(target_lengths), B, T, V,
                                           Lmax, blank, 1, 1 if zero_infinity else 0, p(nll), p(grad), p(ws), ws.numel(),
                                           ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
-        _lib.check(rc, "lmufft_ctc_loss")
-        per = nll / target_lengths.clamp(min=1).to(torch.float32)
-        if zero_infinity:
-            per = torch.where(torch.isinf(per), torch.zeros_like(per), per)
+            _lib.check(rc, "lmufft_ctc_loss")
+            # mean over the batch of nll / max(length, 1), infinite terms zeroed: one launch
+            loss = torch.empty((), dtype=torch.float32, device=dev)
+            rc = _lib.lib.lmufft_ctc_mean_loss(p(nll), p(target_lengths), B, 1 if zero_infinity else 0, p(loss),
+                                               ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        _lib.check(rc, "lmufft_ctc_mean_loss")
         ctx.save_for_backward(grad)
         ctx.in_dtype = log_probs.dtype
-        return per.mean()
+        return loss
 
     @staticmethod
     def backward(ctx, gout):

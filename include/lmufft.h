@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMUFFT_ABI_VERSION 21
+#define LMUFFT_ABI_VERSION 22
 
 /* element types of the activations (x, h, gh, gx, m) */
 #define LMUFFT_F32 0
@@ -422,6 +422,11 @@ int lmufft_ctc_loss(const float* log_probs, const int64_t* targets, int64_t ld, 
                     const int32_t* target_lengths, int32_t B, int32_t T, int32_t V, int32_t Lmax, int32_t blank,
                     int reduction_mean, int zero_infinity, float* nll, float* grad, void* workspace,
                     size_t workspace_bytes, void* stream);
+/* loss[0] = mean_b(nll[b] / max(target_lengths[b], 1)), infinite terms replaced by 0 when zero_infinity != 0: the
+ * 'mean' reduction of nn.CTCLoss (src/models/asr_model.py:105, 144-154) from lmufft_ctc_loss's nll, one launch, a
+ * fixed summation order; nll, target_lengths and loss in device memory. */
+int lmufft_ctc_mean_loss(const float* nll, const int32_t* target_lengths, int32_t B, int zero_infinity, float* loss,
+                         void* stream);
 
 /* ------------------------------------------------------------------------
  * Optimizer step of the training loop on flat fp32 arenas.  Replaces the per-parameter
