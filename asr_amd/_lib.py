@@ -20,7 +20,7 @@ CONV_TOEPLITZ = 1
 CONV_FFT = 2
 CONV_SCAN = 3
 NOALLOC_SCRATCH_BYTES = 8 << 20
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 
 class Shape(ctypes.Structure):
@@ -191,6 +191,10 @@ def _load():
     lib.lmufft_ctc_loss.argtypes = [vp, vp, i64, vp, vp, i32, i32, i32, i32, i32, ci, ci, vp, vp, vp, sz, vp]
     lib.lmufft_ctc_mean_loss.restype = ci
     lib.lmufft_ctc_mean_loss.argtypes = [vp, vp, i32, ci, vp, vp]
+    lib.lmufft_log_softmax_rows.restype = ci
+    lib.lmufft_log_softmax_rows.argtypes = [vp, ci, i64, i64, i32, vp, vp]
+    lib.lmufft_log_softmax_rows_bwd.restype = ci
+    lib.lmufft_log_softmax_rows_bwd.argtypes = [vp, vp, i64, i32, vp, ci, i64, vp]
     lib.lmufft_ctc_pack_targets.restype = ci
     lib.lmufft_ctc_pack_targets.argtypes = [vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, vp, vp, vp]
     lib.lmufft_grad_norm_workspace_bytes.restype = sz
@@ -260,6 +264,8 @@ EXPORTS = (
     "lmufft_ctc_loss_workspace_bytes",
     "lmufft_ctc_loss",
     "lmufft_ctc_mean_loss",
+    "lmufft_log_softmax_rows",
+    "lmufft_log_softmax_rows_bwd",
     "lmufft_grad_norm_workspace_bytes",
     "lmufft_grad_norm2_f32",
     "lmufft_adamw_step_f32",

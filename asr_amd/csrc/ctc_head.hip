@@ -859,6 +859,86 @@ int lmufft_ctc_mean_loss(const float* nll, const int32_t* target_lengths, int32_
   return 0;
 }
 
+}  // extern "C" (reopened below)
+
+namespace lmufft {
+// Row-wise log-softmax over a vocabulary of at most 64 entries and its backward: one wave per row, lane v holds
+// entry v.  The logits are rows of `ld` elements (the Linear kernel pads the vocabulary to a multiple of 8), bf16 or
+// f32; the log-probabilities and their gradient are dense f32 [rows][V], as the CTC kernel takes and returns them.
+//   forward:  lp = x - max - log(sum exp(x - max))            (torch.log_softmax(logits.float(), -1))
+//   backward: dx = dlp - exp(lp) * sum_v dlp, columns V .. ld-1 zero
+template <bool BF16>
+__global__ __launch_bounds__(256) void k_log_softmax_rows(const void* __restrict__ logits, long ld, long rows, int V,
+                                                          float* __restrict__ lp) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int v = threadIdx.x & 63;
+  if (row >= rows) return;
+  float x = -INFINITY;
+  if (v < V)
+    x = BF16 ? (float)reinterpret_cast<const __bf16*>(logits)[row * ld + v] : reinterpret_cast<const float*>(logits)[row * ld + v];
+  float m = x;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  float e = v < V ? expf(x - m) : 0.f;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
+  if (v < V) lp[row * V + v] = x - m - logf(e);
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void k_log_softmax_rows_bwd(const float* __restrict__ dlp, const float* __restrict__ lp,
+                                                              long rows, int V, void* __restrict__ dlogits, long ld) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int v = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float g = v < V ? dlp[row * V + v] : 0.f;
+  float s = g;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float d = v < V ? g - expf(lp[row * V + v]) * s : 0.f;
+  if (v < ld) {
+    if (BF16) reinterpret_cast<__bf16*>(dlogits)[row * ld + v] = (__bf16)d;
+    else reinterpret_cast<float*>(dlogits)[row * ld + v] = d;
+  }
+}
+}  // namespace lmufft
+
+extern "C" {
+
+int lmufft_log_softmax_rows(const void* logits, int dtype, int64_t ld, int64_t rows, int32_t V, float* log_probs,
+                            void* stream) {
+  if (rows < 0 || V <= 0 || V > 64 || ld < V || ld > 64) return set_error("log softmax: bad shape (rows=%lld V=%d ld=%lld; V <= ld <= 64)", (long long)rows, V, (long long)ld);
+  if (dtype != LMUFFT_F32 && dtype != LMUFFT_BF16) return set_error("log softmax: unknown dtype %d", dtype);
+  if (rows == 0) return 0;
+  if (!logits || !log_probs) return set_error("log softmax: NULL pointer");
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == LMUFFT_BF16)
+    hipLaunchKernelGGL(lmufft::k_log_softmax_rows<true>, grid, dim3(256), 0, st, logits, (long)ld, (long)rows, V, log_probs);
+  else
+    hipLaunchKernelGGL(lmufft::k_log_softmax_rows<false>, grid, dim3(256), 0, st, logits, (long)ld, (long)rows, V, log_probs);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error("launch of k_log_softmax_rows failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
+int lmufft_log_softmax_rows_bwd(const float* dlog_probs, const float* log_probs, int64_t rows, int32_t V, void* dlogits,
+                                int dtype, int64_t ld, void* stream) {
+  if (rows < 0 || V <= 0 || V > 64 || ld < V || ld > 64) return set_error("log softmax backward: bad shape (rows=%lld V=%d ld=%lld; V <= ld <= 64)", (long long)rows, V, (long long)ld);
+  if (dtype != LMUFFT_F32 && dtype != LMUFFT_BF16) return set_error("log softmax backward: unknown dtype %d", dtype);
+  if (rows == 0) return 0;
+  if (!dlog_probs || !log_probs || !dlogits) return set_error("log softmax backward: NULL pointer");
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == LMUFFT_BF16)
+    hipLaunchKernelGGL(lmufft::k_log_softmax_rows_bwd<true>, grid, dim3(256), 0, st, dlog_probs, log_probs, (long)rows, V, dlogits, (long)ld);
+  else
+    hipLaunchKernelGGL(lmufft::k_log_softmax_rows_bwd<false>, grid, dim3(256), 0, st, dlog_probs, log_probs, (long)rows, V, dlogits, (long)ld);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error("launch of k_log_softmax_rows_bwd failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
 // waves per workgroup: one thread per label position and one more, rounded up to 1, 2, 4, 8 or 16 waves
 static int ctc_loss_waves(int Lmax) {
   const int need = (Lmax + 1 + 63) / 64;

@@ -143,6 +143,53 @@ class _CTCLoss(torch.autograd.Function):
         return (grad * gout).to(ctx.in_dtype), None, None, None, None, None
 
 
+class _LogSoftmaxRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, V):
+        x = logits.detach()
+        if x.stride(-1) != 1 or not x.is_contiguous():
+            x = x.contiguous()
+        ld = x.shape[-1]
+        rows = x.numel() // ld
+        lp = torch.empty((*x.shape[:-1], V), dtype=torch.float32, device=x.device)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        with torch.cuda.device(x.device):
+            rc = _lib.lib.lmufft_log_softmax_rows(p(x), 1 if x.dtype == torch.bfloat16 else 0, ld, rows, V, p(lp),
+                                                  ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        _lib.check(rc, "lmufft_log_softmax_rows")
+        ctx.save_for_backward(lp)
+        ctx.ld, ctx.in_dtype = ld, logits.dtype
+        return lp
+
+    @staticmethod
+    def backward(ctx, dlp):
+        (lp,) = ctx.saved_tensors
+        V = lp.shape[-1]
+        g = dlp.to(torch.float32).contiguous()
+        rows = lp.numel() // V
+        dx = torch.empty((*lp.shape[:-1], ctx.ld), dtype=ctx.in_dtype, device=lp.device)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        with torch.cuda.device(lp.device):
+            rc = _lib.lib.lmufft_log_softmax_rows_bwd(p(g), p(lp), rows, V, p(dx), 1 if dx.dtype == torch.bfloat16 else 0,
+                                                      ctx.ld, ctypes.c_void_p(torch.cuda.current_stream(lp.device).cuda_stream))
+        _lib.check(rc, "lmufft_log_softmax_rows_bwd")
+        return dx, None
+
+
+def log_softmax_rows(logits: torch.Tensor, vocab_size: int) -> torch.Tensor:
+    """torch.log_softmax(logits[..., :vocab_size].float(), dim=-1) with autograd, as one HIP kernel each way: the
+    logits may carry padding columns behind the vocabulary (asr_amd.linear.linear_train(..., keep_padding=True)),
+    which the forward ignores and the backward fills with zeros.  float32 or bfloat16 logits of at most 64 columns;
+    the result is float32 [..., vocab_size]."""
+    if not logits.is_cuda:
+        raise RuntimeError(f"log_softmax_rows: logits live on {logits.device}; this runs only as a HIP kernel on a GPU "
+                           "(there is no CPU fallback)")
+    if logits.dtype not in (torch.float32, torch.bfloat16) or not (0 < vocab_size <= logits.shape[-1] <= 64):
+        raise RuntimeError(f"log_softmax_rows: float32 or bfloat16 logits with vocab_size <= width <= 64 "
+                           f"(got {logits.dtype}, width {logits.shape[-1]}, vocab_size {vocab_size})")
+    return _LogSoftmaxRows.apply(logits, int(vocab_size))
+
+
 def ctc_loss(log_probs: torch.Tensor, targets: torch.Tensor, input_lengths: torch.Tensor, target_lengths: torch.Tensor,
              blank: int, zero_infinity: bool = True) -> torch.Tensor:
     """Mean-reduced CTC loss of log_probs [batch, frames, vocab] (batch first, as the model produces them) against

@@ -381,6 +381,13 @@ class LMUASRModel(nn.Module):
             prepare_weights(groups)
             prepared = True
         encoded, _ = enc(spectrograms, input_lengths, prepared=prepared)
+        if prepared and proj.weight.shape[0] <= 64 and linear_train_supported(encoded, proj.weight):
+            # the projection's padded bf16 logits go straight into the log-softmax kernel (and its gradient straight
+            # back): no slice, widening cast, pad or narrowing cast in between
+            from .ctc import log_softmax_rows
+            _took("hip", "linear")
+            _took("hip", "log_softmax")
+            return log_softmax_rows(linear_train(encoded, proj.weight, proj.bias, keep_padding=True), proj.weight.shape[0])
         logits = _linear(proj, encoded)
         return torch.log_softmax(logits.float(), dim=-1)
 

@@ -261,9 +261,10 @@ class _LinearTrain(torch.autograd.Function):
     An output width that is not a multiple of 8 (the vocabulary projection) runs on zero rows of padding."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, keep_padding=False):
         N = weight.shape[0]
         pad = -N % 8
+        ctx.keep_padding = bool(keep_padding) and pad > 0
         xb = x.to(torch.bfloat16)
         w16, w16t, b32 = linear_weight_prep([weight], None if bias is None else [bias])
         ctx.save_for_backward(xb, w16t)
@@ -272,13 +273,13 @@ class _LinearTrain(torch.autograd.Function):
         ctx.params = (weight, bias)
         ctx.pad = pad
         y = linear_bf16(xb, w16, b32)
-        return y[..., :N] if pad else y
+        return y[..., :N] if pad and not ctx.keep_padding else y
 
     @staticmethod
     def backward(ctx, dy):
         xb, w16t = ctx.saved_tensors
         dyb = dy.to(torch.bfloat16)
-        if ctx.pad:
+        if ctx.pad and not ctx.keep_padding:  # (with keep_padding the gradient arrives with its padding columns)
             dyb = torch.nn.functional.pad(dyb, (0, ctx.pad))
         dyb = dyb.contiguous()
         dx = dW = db = None
@@ -298,7 +299,7 @@ class _LinearTrain(torch.autograd.Function):
                 n = weight.shape[0]
                 dW = dW[:n]
                 db = None if db is None else db[:n]
-        return dx, dW, db
+        return dx, dW, db, None
 
 
 class _FusedLinearTrain(torch.autograd.Function):
@@ -358,9 +359,13 @@ def train_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
             and weight.shape[1] % 8 == 0)
 
 
-def linear_train(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
-    """torch.nn.functional.linear(x, weight, bias) as bf16 autocast computes it, with autograd, on HIP kernels."""
+def linear_train(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                 keep_padding: bool = False) -> torch.Tensor:
+    """torch.nn.functional.linear(x, weight, bias) as bf16 autocast computes it, with autograd, on HIP kernels.
+    `keep_padding`: an output width that is not a multiple of 8 comes back with the kernel's zero-weight padding
+    columns (width rounded up to 8) instead of a slice, and its gradient is expected with them (zeros there): the
+    vocabulary projection hands both to log_softmax_rows without a slice forward and a pad backward."""
     if not train_supported(x, weight):
         raise RuntimeError("linear_train: needs GPU tensors, a float32 weight [N, K] with K a multiple of 8 and a "
                            "float32 or bfloat16 input [..., K]")
-    return _LinearTrain.apply(x, weight, bias)
+    return _LinearTrain.apply(x, weight, bias, keep_padding)

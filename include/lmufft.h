@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMUFFT_ABI_VERSION 22
+#define LMUFFT_ABI_VERSION 23
 
 /* element types of the activations (x, h, gh, gx, m) */
 #define LMUFFT_F32 0
@@ -427,6 +427,15 @@ int lmufft_ctc_loss(const float* log_probs, const int64_t* targets, int64_t ld, 
  * fixed summation order; nll, target_lengths and loss in device memory. */
 int lmufft_ctc_mean_loss(const float* nll, const int32_t* target_lengths, int32_t B, int zero_infinity, float* loss,
                          void* stream);
+
+/* Log-softmax over the vocabulary and its backward, around the CTC loss: `torch.log_softmax(logits, dim=-1)` of
+ * LMUASRModel.forward (src/models/asr_model.py:126) on the padded bf16 (or f32) logits the projection kernel writes.
+ *   logits / dlogits: [rows][ld], V <= ld <= 64 (columns V .. ld-1 are padding: ignored forward, zeroed backward);
+ *   log_probs / dlog_probs: dense f32 [rows][V]. */
+int lmufft_log_softmax_rows(const void* logits, int dtype, int64_t ld, int64_t rows, int32_t V, float* log_probs,
+                            void* stream);
+int lmufft_log_softmax_rows_bwd(const float* dlog_probs, const float* log_probs, int64_t rows, int32_t V, void* dlogits,
+                                int dtype, int64_t ld, void* stream);
 
 /* ------------------------------------------------------------------------
  * Optimizer step of the training loop on flat fp32 arenas.  Replaces the per-parameter

@@ -234,3 +234,51 @@ def test_ctc_loss_kernel_matches_torch_on_the_gpu_and_is_deterministic():
     x.grad = None
     ctc_loss(x, targets.to(dev), il.to(dev), tl.to(dev), 33, True).backward()
     assert torch.equal(g1, x.grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("rows,V,ld", [((3, 7), 34, 40), ((64, 400), 34, 40), ((5,), 29, 32), ((2, 3), 64, 64), ((9,), 1, 8)])
+def test_log_softmax_rows_matches_torch(rows, V, ld, dtype):
+    """The log-softmax kernel around the CTC loss against torch.log_softmax(logits[..., :V].float(), -1) in float64,
+    forward and backward; padding columns are ignored forward and come back as zeros."""
+    from asr_amd.ctc import log_softmax_rows
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(V + ld)
+    x = (4 * torch.randn(*rows, ld, device=dev, generator=g)).to(dtype).requires_grad_(True)
+    dlp = torch.randn(*rows, V, device=dev, generator=g)
+    lp = log_softmax_rows(x, V)
+    assert lp.dtype == torch.float32 and lp.shape == (*rows, V)
+    lp.backward(dlp)
+    xr = x.detach().double()[..., :V].requires_grad_(True)
+    ref = torch.log_softmax(xr, dim=-1)
+    ref.backward(dlp.double())
+    assert (lp.detach().double() - ref.detach()).abs().max() <= 2e-6 * (1 + ref.detach().abs().max())
+    assert x.grad.dtype == dtype and x.grad.shape == x.shape
+    tol = 2.0 ** -7 if dtype == torch.bfloat16 else 1e-5
+    assert (x.grad.double()[..., :V] - xr.grad).abs().max() <= tol * (1e-3 + xr.grad.abs().max())
+    assert not x.grad[..., V:].any()
+
+
+@pytest.mark.gpu
+def test_linear_train_keeps_the_padding_columns_when_asked():
+    """keep_padding: the vocabulary projection returns its kernel's padded width and takes the gradient back with it:
+    the same numbers as the sliced form."""
+    from asr_amd.linear import linear_train
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    x = torch.randn(6, 50, 384, device=dev).bfloat16()
+    w = torch.nn.Parameter(torch.randn(34, 384, device=dev) / 20)
+    b = torch.nn.Parameter(torch.randn(34, device=dev))
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya = linear_train(xa, w, b)
+    yb = linear_train(xb, w, b, keep_padding=True)
+    assert ya.shape[-1] == 34 and yb.shape[-1] == 40 and torch.equal(ya, yb[..., :34]) and not yb[..., 34:].any()
+    dy = torch.randn_like(ya)
+    ya.backward(dy)
+    ga, gw, gb = xa.grad.clone(), w.grad.clone(), b.grad.clone()
+    w.grad = b.grad = None
+    yb.backward(torch.nn.functional.pad(dy, (0, 6)))
+    assert torch.equal(ga, xb.grad) and torch.equal(gw, w.grad) and torch.equal(gb, b.grad)
