@@ -296,6 +296,9 @@ class LMUEncoder(nn.Module):
         # takes both gradients back in its backward; the last block's output has one reader (the output
         # projection) and is written in bf16 only.
         autocast16 = att_out == torch.bfloat16 and stream is None and torch.is_grad_enabled()
+        if lengths is not None and x.is_cuda and self.use_attention:
+            # the attention kernels read int32 lengths on the device: converted once, not once per block
+            lengths = lengths.to(device=x.device, dtype=torch.int32).contiguous()
         if autocast16 and not prepared:
             prepare_weights(self.linear_groups(x))  # every projection's bf16 operands in one launch
         x = _linear(self.input_projection, x)
