@@ -908,6 +908,7 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 2 : 1) void k_attention_bwd_dkv
   __shared__ __attribute__((aligned(16))) attn_bf16 Qt[32 * VP];
   __shared__ __attribute__((aligned(16))) attn_bf16 Gt[32 * VP];
   __shared__ __attribute__((aligned(16))) float Ms[32], Ls[32], Ds[32];
+  __shared__ __attribute__((aligned(8))) uint2 Hs[32];  // the dropout hash's per-query-row part, made once per tile
   __shared__ float Os[NW * 8 * OP];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -964,7 +965,7 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 2 : 1) void k_attention_bwd_dkv
       dst = *(qq < T ? dsum + bh * T + qq : zp);
     }
   };
-  auto stage = [&]() {
+  auto stage = [&](int i0) {
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
       const int idx = tid + n * (64 * NW);
@@ -980,13 +981,17 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 2 : 1) void k_attention_bwd_dkv
       Ms[tid] = mst;
       Ls[tid] = lst * dr.inv_keep;
       Ds[tid] = dst / dr.inv_keep;
+      if (dr.threshold) {
+        const HashRow hr = hash_row(dr, (unsigned long long)bh * T + (i0 + tid), (unsigned)(T + 1) >> 1);
+        Hs[tid] = make_uint2(hr.lo, hr.c);
+      }
     }
   };
 
   fetch(0);
   for (int i0 = 0; i0 < T; i0 += 32) {
     __syncthreads();
-    stage();
+    stage(i0);
     __syncthreads();
     if (i0 + 32 < T) fetch(i0 + 32);
     if (!wave_live) continue;  // a wave whose 32 keys all lie past T only helps staging the tiles
@@ -1012,8 +1017,8 @@ __global__ __launch_bounds__(64 * NW, DK <= 64 ? 2 : 1) void k_attention_bwd_dkv
       for (int ii = 0; ii < 8; ++ii) {
         const int i = 2 * ii;  // this lane hashes register i + odd: query row rho(i) + odd
         const int row = (i & 3) + 8 * (i >> 2) + 4 * hh + odd;
-        const uint32_t mine = hash_pair(hash_row(dr, (unsigned long long)bh * T + (i0 + row), (unsigned)(T + 1) >> 1),
-                                        (unsigned)kj >> 1);
+        const uint2 hq = Hs[row];
+        const uint32_t mine = hash_pair(HashRow{hq.x, hq.y}, (unsigned)kj >> 1);
         const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xF, 0xF, false);  // lane ^ 1
         xq[i] = odd ? other : mine;
         xq[i + 1] = odd ? mine : other;
