@@ -504,9 +504,11 @@ def causal_conv_adjoint_scan_bf16(gm, scanprep, workspace=None):
     return gu
 
 
-def conv_pair_runner(u, H, conv_algo, dtype, scanprep=None):
+def conv_pair_runner(u, H, conv_algo, dtype, scanprep=None, split=False):
     """A callable that runs the causal convolution of u and the adjoint of its result through the
-    C ABI's conv-only entry points with every buffer preallocated (benchmarks)."""
+    C ABI's conv-only entry points with every buffer preallocated (benchmarks).  `split` (bf16 Toeplitz and fp32
+    routes): returns (forward, adjoint) callables instead -- the adjoint then reads a gradient tensor of its own and
+    has a workspace of its own, so the two may run on different streams."""
     dev = u.device
     B, T = u.shape
     M, ldH = H.shape
@@ -531,27 +533,43 @@ def conv_pair_runner(u, H, conv_algo, dtype, scanprep=None):
         gu = torch.empty((B, T), dtype=torch.float32, device=dev)
         ws = _workspace(_lib.lib.lmufft_conv_workspace_bytes(ctypes.byref(shp), _lib.BF16, _lib.CONV_AUTO), dev)
 
-        def run():
+        gm = torch.randn((B, T, M), device=dev).to(torch.bfloat16) if split else m
+
+        def fwd():
             st = _stream(dev)  # the stream current at the call (a capturing stream under graph capture)
             _lib.check(_lib.lib.lmufft_conv_forward_bf16(ctypes.byref(shp), _ptr(u), _ptr(hprep), _ptr(m), st),
                        "lmufft_conv_forward_bf16")
-            _lib.check(_lib.lib.lmufft_conv_backward_bf16(ctypes.byref(shp), _ptr(m), _ptr(hprep), _ptr(gu), _ptr(ws),
-                                                         ws.numel(), st), "lmufft_conv_backward_bf16")
+
+        def adj():
+            _lib.check(_lib.lib.lmufft_conv_backward_bf16(ctypes.byref(shp), _ptr(gm), _ptr(hprep), _ptr(gu), _ptr(ws),
+                                                         ws.numel(), _stream(dev)), "lmufft_conv_backward_bf16")
+
+        def run():
+            fwd()
+            adj()
             return m, gu
 
-        return run
+        return (fwd, adj) if split else run
     algo = _ALGOS[conv_algo]
     fftprep = prepare_impulse_fft(H, T) if conv_algo == "fft" else None
     m = torch.empty((B, T, M), dtype=torch.float32, device=dev)
     gu = torch.empty((B, T), dtype=torch.float32, device=dev)
     ws = _workspace(_lib.lib.lmufft_conv_workspace_bytes(ctypes.byref(shp), _lib.F32, algo), dev)
 
-    def run():
-        st = _stream(dev)
+    gm = torch.randn((B, T, M), device=dev) if split else m
+    ws2 = _workspace(ws.numel(), dev) if split else ws
+
+    def fwd():
         _lib.check(_lib.lib.lmufft_conv_forward_f32(ctypes.byref(shp), _ptr(u), _ptr(H), _ptr(fftprep), _ptr(m), algo,
-                                                   _ptr(ws), ws.numel(), st), "lmufft_conv_forward_f32")
-        _lib.check(_lib.lib.lmufft_conv_backward_f32(ctypes.byref(shp), _ptr(m), _ptr(H), _ptr(fftprep), _ptr(gu), algo,
-                                                    _ptr(ws), ws.numel(), st), "lmufft_conv_backward_f32")
+                                                   _ptr(ws), ws.numel(), _stream(dev)), "lmufft_conv_forward_f32")
+
+    def adj():
+        _lib.check(_lib.lib.lmufft_conv_backward_f32(ctypes.byref(shp), _ptr(gm), _ptr(H), _ptr(fftprep), _ptr(gu), algo,
+                                                    _ptr(ws2), ws2.numel(), _stream(dev)), "lmufft_conv_backward_f32")
+
+    def run():
+        fwd()
+        adj()
         return m, gu
 
-    return run
+    return (fwd, adj) if split else run

@@ -294,6 +294,37 @@ def bench_conv(args, dev):
         out[route] = {"wall_us": wall * 1e6, "kernels_us": t_k * 1e6, "algorithmic_bytes": nbytes,
                       "achieved_GBs": nbytes / wall / 1e9, "frac": nbytes / wall / 1e9 / HBM_PEAK_GBS,
                       "kernels": per_kernel}
+        if route != "scan":
+            # Supplementary, NOT the line's value: the same ten forwards and ten adjoints as two independent chains
+            # on two branches of one graph (the adjoint reads a gradient tensor of its own), i.e. what the pair costs
+            # when each direction's launch gaps are filled by the other -- as they are inside a training step,
+            # where other kernels sit between them.
+            fwd, adj = F.conv_pair_runner(u, H, route, args.dtype, scanprep=scanprep, split=True)
+            fwd(), adj()
+            torch.cuda.synchronize(dev)
+            g2 = torch.cuda.CUDAGraph()
+            s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+            s1.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s1):
+                with torch.cuda.graph(g2, stream=s1):
+                    s2.wait_stream(s1)
+                    for _ in range(reps):
+                        fwd()
+                    with torch.cuda.stream(s2):
+                        for _ in range(reps):
+                            adj()
+                    s1.wait_stream(s2)
+            torch.cuda.current_stream(dev).wait_stream(s1)
+            for _ in range(3):
+                g2.replay()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(n_replays):
+                g2.replay()
+            torch.cuda.synchronize(dev)
+            wall2 = (time.perf_counter() - t0) / (n_replays * reps)
+            out[route]["two_branches"] = {"wall_us": wall2 * 1e6, "frac": nbytes / wall2 / 1e9 / HBM_PEAK_GBS,
+                                          "note": "forward chain and adjoint chain on parallel graph branches"}
     best = max(out, key=lambda r: out[r]["frac"])
     return {
         "metric": "LMU causal convolution fwd+adjoint frames/sec", "value": B * T / (out[best]["wall_us"] * 1e-6),
