@@ -59,12 +59,12 @@ def impulse_response(A: torch.Tensor, B: torch.Tensor, seq_len: int):
 
 
 def _AUTO_PREFERS_FFT(T, M):
-    """Shape policy of conv_algo="auto" on the fp32 path, from kernel timings on MI355X
-    (batch 64, 192 memory channels, forward + adjoint, all kernels of a route): T=100 Toeplitz
-    37 us / FFT 48 us, T=200 61 / 61, T=400 125 / 84, T=512 167 / 88; batch 32, T=3000 (partitioned
-    FFT) 1970 / 620.  The Toeplitz kernels' work grows with T^2, the FFT's with the transform length
-    (256 / 512 / 1024 points) and, beyond one transform, with the number of partition products."""
-    return T >= 192
+    """Shape policy of conv_algo="auto" on the fp32 path, from kernel timings on MI355X (tools/fft_bench.py: batch 64,
+    192 memory channels, forward + adjoint, event-bracketed kernels of a route, us): T=100 Toeplitz 36 / FFT 38,
+    T=128 37 / 39, T=160 46 / 46, T=200 52 / 48, T=256 55 / 52, T=300 77 / 64, T=400 99 / 70, T=512 115 / 83;
+    batch 32, T=3000 (partitioned FFT) 1970 / 620.  The Toeplitz kernels' work grows with T^2, the FFT's with the
+    transform length (256 / 512 / 1024 points) and, beyond one transform, with the number of partition products."""
+    return T >= 160
 
 
 # bf16 path: sequence length from which conv_algo="auto" takes the state-space ("scan") route.  Its work per

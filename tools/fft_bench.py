@@ -4,7 +4,7 @@ import torch
 from asr_amd import _lib, causal_conv, causal_conv_adjoint, prepare_impulse_fft
 
 dev = torch.device("cuda:0")
-for (B, T, M) in [(64, 400, 192), (64, 200, 192), (64, 100, 192), (64, 512, 192), (16, 400, 192), (256, 400, 192)]:
+for (B, T, M) in [(64, 100, 192), (64, 128, 192), (64, 160, 192), (64, 200, 192), (64, 256, 192), (64, 300, 192), (64, 400, 192), (64, 512, 192), (16, 400, 192), (256, 400, 192)]:
     u = torch.relu(torch.randn(B, T, device=dev))
     gm = torch.randn(B, T, M, device=dev)
     H = torch.randn(M, T, device=dev) * 0.05
@@ -20,4 +20,5 @@ for (B, T, M) in [(64, 400, 192), (64, 200, 192), (64, 100, 192), (64, 512, 192)
         torch.cuda.synchronize()
         prof = _lib.profile_read()
         _lib.profile_enable(False)
-        print(B, T, M, algo, {k: round(v[0] / v[1] * 1e3, 1) for k, v in prof.items() if v[1]}, flush=True)
+        per = {k: round(v[0] / v[1] * 1e3, 1) for k, v in prof.items() if v[1]}
+        print(B, T, M, algo, f"pair {sum(v[0] for v in prof.values()) / 10 * 1e3:.1f} us", per, flush=True)
