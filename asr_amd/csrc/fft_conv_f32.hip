@@ -188,6 +188,50 @@ __device__ __forceinline__ void wave_fft(const float2* __restrict__ tw, float2* 
   constexpr int R3 = N / 256;
   static_assert(R3 == 1 || R3 == 2 || R3 == 4, "N in {256, 512, 1024}");
   fft_stage<N, 16, 1, INV>(tw, src, [&](int i, float2 v, int) { buf[fpad(i)] = v; });
+#ifdef LMUFFT_FFT_SHUFFLE
+  // Measured alternative (off by default, see the note at the end of this function): the exchange between the
+  // second radix-16 stage and the radix-4 stage through v_permlane32_swap / v_permlane16_swap instead of LDS.
+  if constexpr (R3 == 4) {
+    float2 keep[16];
+    fft_stage<N, 16, 16, INV>(tw, [&](int i, int) { return buf[fpad(i)]; }, [&](int, float2 v, int slot) { keep[slot] = v; });
+    // Lane (row b = lane / 16, c = lane % 16) holds elements 256 b + c + 16 r in register r.  The radix-4 butterfly
+    // at position p = c + 16 r takes the elements p + 256 r' from the rows r' = 0..3, register r: the four lanes
+    // c, 16 + c, 32 + c, 48 + c transpose register group (r / 4) against row, after which lane (b, c) owns the
+    // butterflies p = c + 16 (4 b + q), q = 0..3.
+    const int lane = threadIdx.x & 63, brow = lane >> 4, c = lane & 15;
+    float2 X[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int comp = 0; comp < 2; ++comp) {
+        unsigned g[4];
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) g[gi] = __float_as_uint(comp ? keep[4 * gi + q].y : keep[4 * gi + q].x);
+        auto s02 = __builtin_amdgcn_permlane32_swap(g[0], g[2], false, false);
+        auto s13 = __builtin_amdgcn_permlane32_swap(g[1], g[3], false, false);
+        auto t01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+        auto t23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+        const unsigned x[4] = {t01[0], t01[1], t23[0], t23[1]};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (comp) X[q][r].y = __uint_as_float(x[r]);
+          else X[q][r].x = __uint_as_float(x[r]);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = c + 16 * (4 * brow + q);
+#pragma unroll
+      for (int r = 1; r < 4; ++r) X[q][r] = twiddle<INV>(X[q][r], tw[(r * j) & (N - 1)]);
+      dft4<INV>(X[q]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst(j + r * 256, X[q][r], q * 4 + r);
+    }
+    wave_lds_fence();
+    return;
+  }
+#endif
   if constexpr (R3 == 1) {
     fft_stage<N, 16, 16, INV>(tw, [&](int i, int) { return buf[fpad(i)]; }, dst);
   } else {
