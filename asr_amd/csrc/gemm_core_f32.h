@@ -2,9 +2,13 @@
 // GEMM-shaped kernel of the LMUFFT layer.
 //
 // One 256-thread workgroup (4 waves, one per SIMD) computes a BM x BN tile of
-// C = A * B with v_mfma_f32_32x32x2_f32, whose result is bit-for-bit a
-// k-ordered fp32 fma chain -- the fp32 path therefore has the same numerics
-// class as the reference's fp32 GEMMs.
+// C = A * B from fp32 operands with fp32 accumulation: every product as six bf16
+// products of a three-way split of its factors on v_mfma_f32_32x32x16_bf16
+// (tile_compute_split below: about one fp32 rounding of error per product), or,
+// built with -DLMUFFT_F32_MFMA, with v_mfma_f32_32x32x2_f32, whose result is
+// bit-for-bit a k-ordered fp32 fma chain.  Either way the fp32 path has the
+// numerics class of the reference's fp32 GEMMs (measured against its goldens:
+// 4e-7 against 3e-7 of the largest magnitude, tools/f32_error.py).
 //
 // Operands are described by loader functors, so that a kernel can generate an
 // operand on the fly (Toeplitz matrix from u, ReLU-masked gradient, [m;x]
@@ -175,9 +179,98 @@ __device__ __forceinline__ void tile_zero(f32x16 (&acc)[T::TM][T::TN]) {
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 }
 
+// ---- fp32 products on the bf16 matrix cores -------------------------------------------------------
+// x = hi + mid + lo with three bf16 (8 significant bits each: the 24 of an fp32, each difference exact),
+// and a * b = sum of the six products whose weight is at least 2^-16 of the largest:
+//   hi hi + (hi mid + mid hi) + (hi lo + lo hi + mid mid)      (mid lo, lo mid, lo lo: below 2^-24)
+// bf16 x bf16 is exact in fp32 and the MFMA accumulates in fp32, so a product carries a relative error of about
+// 2^-23 -- one fp32 rounding -- instead of being bit-for-bit the fma chain of v_mfma_f32_32x32x2_f32.  Six
+// v_mfma_f32_32x32x16_bf16 (8 passes each) cover 16 k where the fp32 instruction needs eight of 16 passes:
+// 2.7 times fewer matrix-core cycles.  The split costs ~5 VALU operations per operand element and k-step, which
+// run beside the MFMAs.  -DLMUFFT_F32_MFMA restores the fp32 instruction.
+typedef __bf16 split_bf16x8 __attribute__((ext_vector_type(8)));
+struct Split3 {
+  split_bf16x8 hi, mid, lo;
+};
+__device__ __forceinline__ Split3 split3(const float (&x)[8]) {
+  Split3 s;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 h = (__bf16)x[j];
+    const float r1 = x[j] - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    s.hi[j] = h;
+    s.mid[j] = m;
+    s.lo[j] = (__bf16)r2;
+  }
+  return s;
+}
+
+template <class T>
+__device__ __forceinline__ void tile_compute_split(const float* As, const float* Bs,
+                                                   f32x16 (&acc)[T::TM][T::TN], const WavePos<T>& w) {
+  static_assert(T::BK % 16 == 0, "k-steps of 16");
+#pragma unroll
+  for (int ks = 0; ks < T::BK / 16; ++ks) {
+    Split3 a[T::TM], b[T::TN];
+    const int kb = ks * 16 + w.hh * 8;  // this lane's eight k of the step
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm) {
+      const int row = w.wm0 + tm * 32 + w.r;
+      float x[8];
+      if (T::ALAY == KC) {
+        const f32x4 lo4 = *reinterpret_cast<const f32x4*>(&As[row * T::LDK + kb]);
+        const f32x4 hi4 = *reinterpret_cast<const f32x4*>(&As[row * T::LDK + kb + 4]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = lo4[j], x[4 + j] = hi4[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = As[(kb + j) * T::BM + row];
+      }
+      a[tm] = split3(x);
+    }
+#pragma unroll
+    for (int tn = 0; tn < T::TN; ++tn) {
+      const int col = w.wn0 + tn * 32 + w.r;
+      float x[8];
+      if (T::BLAY == KC) {
+        const f32x4 lo4 = *reinterpret_cast<const f32x4*>(&Bs[col * T::LDK + kb]);
+        const f32x4 hi4 = *reinterpret_cast<const f32x4*>(&Bs[col * T::LDK + kb + 4]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = lo4[j], x[4 + j] = hi4[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = Bs[(kb + j) * T::BN + col];
+      }
+      b[tn] = split3(x);
+    }
+    // smallest terms first
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < T::TN; ++tn) {
+        f32x16 c = acc[tm][tn];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm].mid, b[tn].mid, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm].lo, b[tn].hi, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm].hi, b[tn].lo, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm].mid, b[tn].hi, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm].hi, b[tn].mid, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm].hi, b[tn].hi, c, 0, 0, 0);
+        acc[tm][tn] = c;
+      }
+  }
+}
+
 template <class T>
 __device__ __forceinline__ void tile_compute(const float* As, const float* Bs,
                                              f32x16 (&acc)[T::TM][T::TN], const WavePos<T>& w) {
+#ifndef LMUFFT_F32_MFMA
+  if constexpr (T::BK % 16 == 0) {
+    tile_compute_split<T>(As, Bs, acc, w);
+    return;
+  }
+#endif
 #pragma unroll
   for (int kk = 0; kk < T::BK / 8; ++kk) {
     f32x4 a[T::TM], b[T::TN];
