@@ -793,7 +793,10 @@ def main():
             os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
         dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        # a collective that never completes (a rank lost, a capture RCCL cannot replay) ends the run with an error
+        # after three minutes instead of holding the node until somebody kills it
+        import datetime
+        dist.init_process_group(backend="nccl", device_id=dev, timeout=datetime.timedelta(seconds=180))
         if dist.get_world_size() != args.gpus or dist.get_backend() != "nccl":
             raise SystemExit(f"process group has {dist.get_world_size()} ranks on {dist.get_backend()}, "
                              f"expected {args.gpus} on nccl")
