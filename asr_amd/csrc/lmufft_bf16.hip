@@ -557,8 +557,10 @@ __global__ __launch_bounds__(ProjGldsTile::THREADS) void k_conv_proj_fwd_bf16(
       },
       ldHb, ldHb);
   constexpr int NSH = kFusedHbStages;
+  const int nkt = kend_pad / TC::BK;  // k-tiles of the conv phase (2 .. 8): only these are fetched
 #pragma unroll
-  for (int st = 0; st < NSH - 1; ++st) oh.issue(st, st * TC::BK);
+  for (int st = 0; st < NSH - 1; ++st)
+    if (st < nkt) oh.issue(st, st * TC::BK);
 
   // time-reversed u around the tile, eight shifted copies (see k_conv_fwd_bf16).  (The barriers here also wait
   // for the Hb tiles just issued -- the compiler orders LDS writes behind outstanding LDS-DMA; giving this work
@@ -615,12 +617,18 @@ __global__ __launch_bounds__(ProjGldsTile::THREADS) void k_conv_proj_fwd_bf16(
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[tn][i] = 0.f;
     static_assert(TC::TM == 1, "one row tile per wave");
-    constexpr int KEEP = OpH::NI * (NSH - 2);
+    static_assert(NSH == 4, "the counted waits below are written for three tiles in flight");
     int stage = 0, pf = NSH - 1;
-    for (int k0 = 0; k0 < kend; k0 += TC::BK) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
+    for (int k0 = 0, kt = 0; k0 < kend; k0 += TC::BK, ++kt) {
+      // tile kt has landed when at most the tiles behind it are outstanding: two of them, or what is left of the
+      // sequence at its end (no dummy tiles are fetched to keep the count constant: with two to seven k-tiles per
+      // workgroup three dummies were up to 60 % of the phase's LDS-DMA instructions)
+      const int behind = nkt - 1 - kt;  // uniform
+      if (behind >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OpH::NI * 2) : "memory");
+      else if (behind == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OpH::NI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      oh.issue(pf, k0 + (NSH - 1) * TC::BK);
+      if (kt + NSH - 1 < nkt) oh.issue(pf, k0 + (NSH - 1) * TC::BK);
 #pragma unroll
       for (int kl = 0; kl < TC::BK; kl += 16) {
         const bf16x8 af = oa.frag(w.wm0 + w.r, k0, kl, w.hh);
