@@ -966,14 +966,17 @@ void k_gu_q_bf16(const bf16_t* __restrict__ gz, const bf16_t* __restrict__ QT, f
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[tn][i] = 0.f;
 
-  {  // K loop: NS - 1 k-tiles in flight, counted waits, raw barriers
+  {  // K loop: NS - 1 k-tiles in flight, counted waits, raw barriers; only the Hd / BK real k-tiles are fetched
+    const int nkt = Hd / TL::BK;
 #pragma unroll
-    for (int st = 0; st < NS - 1; ++st) issue(st, st * TL::BK);
+    for (int st = 0; st < NS - 1; ++st)
+      if (st < nkt) issue(st, st * TL::BK);
     int stage = 0, pf = NS - 1;
-    for (int k0 = 0; k0 < Hd; k0 += TL::BK) {
-      wait_tile();
+    for (int k0 = 0, kt = 0; k0 < Hd; k0 += TL::BK, ++kt) {
+      if (kt + NS - 2 < nkt) wait_tile();  // NS - 2 newer tiles are outstanding behind this one ...
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... or none (NS = 3), at the end of the sequence
       __builtin_amdgcn_s_barrier();
-      issue(pf, k0 + (NS - 1) * TL::BK);
+      if (kt + NS - 1 < nkt) issue(pf, k0 + (NS - 1) * TL::BK);
 #pragma unroll
       for (int kl = 0; kl < TL::BK; kl += 16) {
         const bf16x8 af = frag(stage, 0, w.wm0 + w.r, kl, w.hh);
