@@ -80,3 +80,14 @@ def test_whole_model_step(exchange):
     assert 0 < d["config"]["learning_rate_on_device"] < 1.5e-3  # inside the 1500-step warm-up
     first, last = d["loss_first_last"]
     assert last == last and first == first
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_conv_only_unit_line(dtype):
+    d, err = _run("--unit", "conv", "--dtype", dtype, "--batch", "8", "--frames", "200", "--steps", "20", "--warmup", "2")
+    assert d["metric"] == "LMU causal convolution fwd+adjoint frames/sec" and d["dtype"] == dtype and d["value"] > 0
+    assert d["config"]["route"] in d["routes"] and 0 < d["roofline"]["frac"] < 1
+    for name, r in d["routes"].items():
+        assert r["wall_us"] > 0 and r["algorithmic_bytes"] == 8 * 200 * (2 * 192 + 2) * (2 if dtype == "bf16" else 4)
+        if name != "scan":  # the supplementary figure: both directions as independent chains of one graph
+            assert r["two_branches"]["wall_us"] > 0 and 0 < r["two_branches"]["frac"] < 1  # (a short run: no bound on the ratio)
