@@ -20,7 +20,7 @@ CONV_TOEPLITZ = 1
 CONV_FFT = 2
 CONV_SCAN = 3
 NOALLOC_SCRATCH_BYTES = 8 << 20
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 
 class Shape(ctypes.Structure):
@@ -185,6 +185,10 @@ def _load():
     lib.lmufft_linear_wgrad_workspace_bytes.argtypes = [i64, i32, i32]
     lib.lmufft_linear_wgrad_bf16.restype = ci
     lib.lmufft_linear_wgrad_bf16.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp, sz, vp]
+    lib.lmufft_linear_wgrad_slabs_bf16.restype = ci
+    lib.lmufft_linear_wgrad_slabs_bf16.argtypes = [vp, vp, i64, i32, i32, vp, sz, vp]
+    lib.lmufft_linear_wgrad_sum_bf16.restype = ci
+    lib.lmufft_linear_wgrad_sum_bf16.argtypes = [i64, i32, i32, vp, vp, vp, sz, vp]
     lib.lmufft_ctc_loss_workspace_bytes.restype = sz
     lib.lmufft_ctc_loss_workspace_bytes.argtypes = [i32, i32, i32]
     lib.lmufft_ctc_loss.restype = ci
@@ -258,6 +262,8 @@ EXPORTS = (
     "lmufft_linear_wprep_many_bf16",
     "lmufft_linear_wgrad_workspace_bytes",
     "lmufft_linear_wgrad_bf16",
+    "lmufft_linear_wgrad_slabs_bf16",
+    "lmufft_linear_wgrad_sum_bf16",
     "lmufft_ctc_workspace_bytes",
     "lmufft_ctc_greedy",
     "lmufft_ctc_pack_targets",

@@ -2734,18 +2734,23 @@ size_t lmufft_linear_wgrad_workspace_bytes(int64_t rows, int32_t in, int32_t out
   return plan_linear_wgrad(rows, in, out).total;
 }
 
-int lmufft_linear_wgrad_bf16(const void* x, const void* dy, int64_t rows, int32_t in, int32_t out, float* dW, float* db,
-                             void* workspace, size_t workspace_bytes, void* stream) {
-  using TL = WgradTileB;
+static int linear_wgrad_check(const void* x, const void* dy, int64_t rows, int32_t in, int32_t out, const void* workspace,
+                              size_t workspace_bytes, bool slabs) {
   if (rows <= 0 || rows > 0x7fffffff || in <= 0 || out <= 0) return set_error("linear wgrad: bad shape (rows=%lld in=%d out=%d)", (long long)rows, in, out);
   if (in % 8 || out % 8) return set_error("linear wgrad: in and out must be multiples of 8 (got %d, %d)", in, out);
-  if (!x || !dy || !dW || !workspace) return set_error("linear wgrad: NULL pointer");
-  if (!al16(x) || !al16(dy) || !al16(workspace)) return set_error("linear wgrad: x, dy and the workspace must be 16-byte aligned");
+  if (!workspace || (slabs && (!x || !dy))) return set_error("linear wgrad: NULL pointer");
+  if (!al16(workspace) || (slabs && (!al16(x) || !al16(dy)))) return set_error("linear wgrad: x, dy and the workspace must be 16-byte aligned");
   const LinWgradPlan p = plan_linear_wgrad(rows, in, out);
   if (workspace_bytes < p.total) return set_error("linear wgrad: workspace of %zu bytes needed, %zu given", p.total, workspace_bytes);
+  return 0;
+}
+
+int lmufft_linear_wgrad_slabs_bf16(const void* x, const void* dy, int64_t rows, int32_t in, int32_t out, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  if (int rc = linear_wgrad_check(x, dy, rows, in, out, workspace, workspace_bytes, true)) return rc;
+  const LinWgradPlan p = plan_linear_wgrad(rows, in, out);
   hipStream_t st = (hipStream_t)stream;
   float* wslab = (float*)workspace;
-  float* scratch = (float*)((char*)workspace + p.off_scratch);  // gw_u (in) | gb_u (1) | db when the layer has no bias
   const dim3 grid(xcd_grid((long)p.S * p.tile_blocks, p.tiles_j * p.tiles_n / p.tile_blocks));
   if (hipFuncSetAttribute((const void*)k_wgrad_pair_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgPairLds) !=
       hipSuccess)
@@ -2757,10 +2762,28 @@ int lmufft_linear_wgrad_bf16(const void* x, const void* dy, int64_t rows, int32_
                        out, p.tile_blocks);
   }
   LAUNCH_CHECKB("k_linear_wgrad_bf16");
+  return 0;
+}
+
+int lmufft_linear_wgrad_sum_bf16(int64_t rows, int32_t in, int32_t out, float* dW, float* db, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  using TL = WgradTileB;
+  if (int rc = linear_wgrad_check(nullptr, nullptr, rows, in, out, workspace, workspace_bytes, false)) return rc;
+  if (!dW) return set_error("linear wgrad: NULL pointer");
+  const LinWgradPlan p = plan_linear_wgrad(rows, in, out);
+  float* wslab = (float*)workspace;
+  float* scratch = (float*)((char*)workspace + p.off_scratch);  // gw_u (in) | gb_u (1) | db when the layer has no bias
   const SlabOutputs o{{dW, db ? db : scratch + in + 4, scratch, scratch + in},
                       {(long)out * in, out, in, 1},
                       {1, p.tiles_j * TL::WGN, p.tiles_n * TL::WGM, 1}};
-  return launch_reduce_slabs(wslab, p.S, o, st);
+  return launch_reduce_slabs(wslab, p.S, o, (hipStream_t)stream);
+}
+
+int lmufft_linear_wgrad_bf16(const void* x, const void* dy, int64_t rows, int32_t in, int32_t out, float* dW, float* db,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+  if (!dW) return set_error("linear wgrad: NULL pointer");
+  if (int rc = lmufft_linear_wgrad_slabs_bf16(x, dy, rows, in, out, workspace, workspace_bytes, stream)) return rc;
+  return lmufft_linear_wgrad_sum_bf16(rows, in, out, dW, db, workspace, workspace_bytes, stream);
 }
 
 int lmufft_conv_forward_bf16(const lmufft_shape* s, const float* u, const void* hprep, void* m, void* stream) {

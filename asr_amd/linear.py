@@ -103,7 +103,8 @@ def linear_add_layer_norm_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Opti
 
 
 def linear_weight_grad_bf16(x: torch.Tensor, dy: torch.Tensor, want_bias: bool = True,
-                            out_weight: Optional[torch.Tensor] = None, out_bias: Optional[torch.Tensor] = None):
+                            out_weight: Optional[torch.Tensor] = None, out_bias: Optional[torch.Tensor] = None,
+                            sum_stream: Optional["torch.cuda.Stream"] = None):
     """(dW [N, K] fp32, db [N] fp32 or None) of y = x W^T + b from x [..., K] and dy [..., N], both bf16:
     dW = sum over rows of dy^T x, db = sum over rows of dy (HIP kernel k_wgrad_bf16, fp32 accumulation in a
     fixed order).  K and N must be multiples of 8.  `out_weight` / `out_bias`: contiguous float32 tensors to write
@@ -128,17 +129,33 @@ def linear_weight_grad_bf16(x: torch.Tensor, dy: torch.Tensor, want_bias: bool =
     if want_bias:
         db = out_bias if out_bias is not None else torch.empty((N,), dtype=torch.float32, device=x.device)
     ws = torch.empty(_lib.lib.lmufft_linear_wgrad_workspace_bytes(rows, K, N), dtype=torch.uint8, device=x.device)
+    cur = torch.cuda.current_stream(x.device)
     with torch.cuda.device(x.device):
-        rc = _lib.lib.lmufft_linear_wgrad_bf16(_ptr(x), _ptr(dy), rows, K, N, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(),
-                                               ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
-    _lib.check(rc, "lmufft_linear_wgrad_bf16")
-    return dW, db
+        if sum_stream is None:
+            rc = _lib.lib.lmufft_linear_wgrad_bf16(_ptr(x), _ptr(dy), rows, K, N, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(),
+                                                   ctypes.c_void_p(cur.cuda_stream))
+            _lib.check(rc, "lmufft_linear_wgrad_bf16")
+            return dW, db
+        # the GEMM here, the sum of its row ranges' partial results on `sum_stream` (the caller joins that stream
+        # before the gradient is read and keeps `ws` alive until then: it is returned as a third value)
+        rc = _lib.lib.lmufft_linear_wgrad_slabs_bf16(_ptr(x), _ptr(dy), rows, K, N, _ptr(ws), ws.numel(),
+                                                     ctypes.c_void_p(cur.cuda_stream))
+        _lib.check(rc, "lmufft_linear_wgrad_slabs_bf16")
+        sum_stream.wait_stream(cur)
+        rc = _lib.lib.lmufft_linear_wgrad_sum_bf16(rows, K, N, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(),
+                                                   ctypes.c_void_p(sum_stream.cuda_stream))
+        _lib.check(rc, "lmufft_linear_wgrad_sum_bf16")
+    return dW, db, ws
 
 
 # True: weight gradients that are written straight into a gradient bucket run on a side stream, beside the rest of
 # the backward (nothing downstream depends on them); asr_amd.parallel.GradBuckets joins the stream before it
 # exchanges or hands out gradients.  Off by default; the results are the same numbers either way.
 ASYNC_WEIGHT_GRAD = False
+# True: only the SUM of a weight gradient's partial slabs runs on that side stream (a short memory-bound kernel with
+# no LDS).  Off by default as well: inside the one-graph training step the nine forks and their join cost more than
+# the sums they take off the main chain (2.26 -> 2.33 ms per step).
+ASYNC_SLAB_SUMS = False
 
 
 def _weight_grad_into_slots(xb, dyb, has_bias, slot_w, slot_b):
@@ -146,8 +163,18 @@ def _weight_grad_into_slots(xb, dyb, has_bias, slot_w, slot_b):
     output is a bucket slice (a gradient handed back to autograd could be accumulated on this stream at once)."""
     from . import functional as F
 
-    if not (ASYNC_WEIGHT_GRAD and slot_w is not None and (slot_b is not None or not has_bias)):
-        if ASYNC_WEIGHT_GRAD:
+    into_slots = slot_w is not None and (slot_b is not None or not has_bias)
+    if not (ASYNC_WEIGHT_GRAD and into_slots):
+        if ASYNC_SLAB_SUMS and into_slots:
+            dev = xb.device
+            side = F._wgrad_stream(dev)
+            dW, db, ws = linear_weight_grad_bf16(xb, dyb, has_bias, slot_w, slot_b, sum_stream=side)
+            done = torch.cuda.Event()
+            done.record(side)
+            key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+            F._ASYNC_WGRAD.setdefault(key, []).append((done, (ws, dW, db)))
+            return dW, db
+        if ASYNC_WEIGHT_GRAD or ASYNC_SLAB_SUMS:
             # this gradient goes back to autograd, which may add it into `.grad` -- a bucket slice that a gradient
             # of the same step may still be writing on the side stream -- on this stream at once
             F.join_async_weight_grads(xb.device)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMUFFT_ABI_VERSION 23
+#define LMUFFT_ABI_VERSION 24
 
 /* element types of the activations (x, h, gh, gx, m) */
 #define LMUFFT_F32 0
@@ -387,6 +387,14 @@ int lmufft_dropout_epoch(const uint32_t* epoch_dev);
 size_t lmufft_linear_wgrad_workspace_bytes(int64_t rows, int32_t in, int32_t out);
 int lmufft_linear_wgrad_bf16(const void* x, const void* dy, int64_t rows, int32_t in, int32_t out,
                              float* dW, float* db, void* workspace, size_t workspace_bytes, void* stream);
+/* The same gradient in two calls: the partial sums of the row ranges into the workspace (the GEMM), then their sum
+ * into dW / db (a short memory-bound kernel that only has to finish before the gradient is consumed, so a caller may
+ * run it on another stream, beside the rest of the backward, once that stream waits for the first call).  Same
+ * workspace for both; the results are the numbers lmufft_linear_wgrad_bf16 writes. */
+int lmufft_linear_wgrad_slabs_bf16(const void* x, const void* dy, int64_t rows, int32_t in, int32_t out,
+                                   void* workspace, size_t workspace_bytes, void* stream);
+int lmufft_linear_wgrad_sum_bf16(int64_t rows, int32_t in, int32_t out, float* dW, float* db, void* workspace,
+                                 size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * CTC target packing.  Replaces the label concatenation at the head of

@@ -220,7 +220,7 @@ def test_training_linear_matches_oracle(rows, K, N, with_bias):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("side_stream", [False, True])
+@pytest.mark.parametrize("side_stream", [False, True, "sums"])
 def test_training_linear_writes_into_gradient_buckets(side_stream, monkeypatch):
     """Parameters of a GradBuckets: the weight-gradient kernel writes into the bucket, `.grad` IS the bucket's slice
     (no clearing between steps, no accumulation kernel), a second use in the same step adds; the padded
@@ -230,7 +230,8 @@ def test_training_linear_writes_into_gradient_buckets(side_stream, monkeypatch):
     from asr_amd.linear import linear_train
     from asr_amd.parallel import GradBuckets
 
-    monkeypatch.setattr(lin, "ASYNC_WEIGHT_GRAD", side_stream)
+    monkeypatch.setattr(lin, "ASYNC_WEIGHT_GRAD", side_stream is True)
+    monkeypatch.setattr(lin, "ASYNC_SLAB_SUMS", side_stream == "sums")  # only the slab sums on the side stream
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     a, head = torch.nn.Linear(64, 48).to(dev), torch.nn.Linear(48, 34).to(dev)
