@@ -20,7 +20,7 @@ CONV_TOEPLITZ = 1
 CONV_FFT = 2
 CONV_SCAN = 3
 NOALLOC_SCRATCH_BYTES = 8 << 20
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 
 class Shape(ctypes.Structure):
@@ -33,6 +33,20 @@ class Shape(ctypes.Structure):
         ("M", ctypes.c_int32),
         ("Hd", ctypes.c_int32),
         ("ldH", ctypes.c_int32),
+    ]
+
+
+class WgradSumItem(ctypes.Structure):
+    """Mirror of `lmufft_wgrad_sum_item` (include/lmufft.h)."""
+
+    _fields_ = [
+        ("rows", ctypes.c_int64),
+        ("in_", ctypes.c_int32),
+        ("out", ctypes.c_int32),
+        ("dW", ctypes.c_void_p),
+        ("db", ctypes.c_void_p),
+        ("workspace", ctypes.c_void_p),
+        ("workspace_bytes", ctypes.c_size_t),
     ]
 
 
@@ -189,6 +203,8 @@ def _load():
     lib.lmufft_linear_wgrad_slabs_bf16.argtypes = [vp, vp, i64, i32, i32, vp, sz, vp]
     lib.lmufft_linear_wgrad_sum_bf16.restype = ci
     lib.lmufft_linear_wgrad_sum_bf16.argtypes = [i64, i32, i32, vp, vp, vp, sz, vp]
+    lib.lmufft_linear_wgrad_sum_many_bf16.restype = ci
+    lib.lmufft_linear_wgrad_sum_many_bf16.argtypes = [ctypes.POINTER(WgradSumItem), i32, vp]
     lib.lmufft_ctc_loss_workspace_bytes.restype = sz
     lib.lmufft_ctc_loss_workspace_bytes.argtypes = [i32, i32, i32]
     lib.lmufft_ctc_loss.restype = ci
@@ -264,6 +280,7 @@ EXPORTS = (
     "lmufft_linear_wgrad_bf16",
     "lmufft_linear_wgrad_slabs_bf16",
     "lmufft_linear_wgrad_sum_bf16",
+    "lmufft_linear_wgrad_sum_many_bf16",
     "lmufft_ctc_workspace_bytes",
     "lmufft_ctc_greedy",
     "lmufft_ctc_pack_targets",

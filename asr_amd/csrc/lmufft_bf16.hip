@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "gemm_core_bf16.h"
 #include "gemm_glds_bf16.h"
@@ -2777,6 +2778,27 @@ int lmufft_linear_wgrad_sum_bf16(int64_t rows, int32_t in, int32_t out, float* d
                       {(long)out * in, out, in, 1},
                       {1, p.tiles_j * TL::WGN, p.tiles_n * TL::WGM, 1}};
   return launch_reduce_slabs(wslab, p.S, o, (hipStream_t)stream);
+}
+
+int lmufft_linear_wgrad_sum_many_bf16(const lmufft_wgrad_sum_item* items, int32_t count, void* stream) {
+  using TL = WgradTileB;
+  if (count < 0 || (count > 0 && !items)) return set_error("linear wgrad: bad item list");
+  std::vector<const float*> in(count);
+  std::vector<int> S(count);
+  std::vector<SlabOutputs> o(count);
+  for (int i = 0; i < count; ++i) {
+    const lmufft_wgrad_sum_item& it = items[i];
+    if (int rc = linear_wgrad_check(nullptr, nullptr, it.rows, it.in, it.out, it.workspace, it.workspace_bytes, false)) return rc;
+    if (!it.dW) return set_error("linear wgrad: NULL pointer");
+    const LinWgradPlan p = plan_linear_wgrad(it.rows, it.in, it.out);
+    float* scratch = (float*)((char*)it.workspace + p.off_scratch);
+    in[i] = (const float*)it.workspace;
+    S[i] = p.S;
+    o[i] = SlabOutputs{{it.dW, it.db ? it.db : scratch + it.in + 4, scratch, scratch + it.in},
+                       {(long)it.out * it.in, it.out, it.in, 1},
+                       {1, p.tiles_j * TL::WGN, p.tiles_n * TL::WGM, 1}};
+  }
+  return launch_reduce_slabs_many(in.data(), S.data(), o.data(), count, (hipStream_t)stream);
 }
 
 int lmufft_linear_wgrad_bf16(const void* x, const void* dy, int64_t rows, int32_t in, int32_t out, float* dW, float* db,

@@ -491,10 +491,10 @@ __device__ __forceinline__ void slab_store4(const SlabOutputs& o, int seg, long 
     if (local + j < nn) dst[local + j] = v[j];
 }
 
-__global__ __launch_bounds__(kThreads) void k_reduce_slabs(const float* __restrict__ in, int S, long stride,
-                                                           SlabOutputs o, SlabBounds sb) {
+__device__ __forceinline__ void reduce_slabs_body(const float* __restrict__ in, int S, long stride, const SlabOutputs& o,
+                                                  const SlabBounds& sb, int block, int nblocks) {
   // tb[4] and the grid stride are multiples of 8: the eight lanes of a group leave the loop together
-  for (long t = blockIdx.x * (long)kThreads + threadIdx.x; t < sb.tb[4]; t += (long)gridDim.x * kThreads) {
+  for (long t = block * (long)kThreads + threadIdx.x; t < sb.tb[4]; t += (long)nblocks * kThreads) {
     const int seg = slab_segment(sb.tb, t);
     const long lt = t - pick4(sb.tb, seg);
     const int L = pick4(sb.lanes, seg);
@@ -527,6 +527,48 @@ __global__ __launch_bounds__(kThreads) void k_reduce_slabs(const float* __restri
       }
     if (r0 == 0 && local < pn) slab_store4(o, seg, local, o4);
   }
+}
+
+__global__ __launch_bounds__(kThreads) void k_reduce_slabs(const float* __restrict__ in, int S, long stride,
+                                                           SlabOutputs o, SlabBounds sb) {
+  reduce_slabs_body(in, S, stride, o, sb, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Several independent slab sums in one launch (the weight gradients of a training step's Linear layers, summed
+// together at the end of the backward instead of one launch each).  The table travels in the kernel's arguments and
+// is read there with scalar loads; a workgroup belongs to the item whose block range holds it.
+constexpr int kReduceManyMax = 12;
+struct ReduceBatch {
+  const float* in[kReduceManyMax];
+  long stride[kReduceManyMax];
+  SlabOutputs o[kReduceManyMax];
+  SlabBounds sb[kReduceManyMax];
+  int S[kReduceManyMax];
+  int first_block[kReduceManyMax + 1];
+  int count;
+};
+static_assert(sizeof(ReduceBatch) <= 4096, "fits the kernel-argument segment");
+__global__ __launch_bounds__(kThreads) void k_reduce_slabs_many(ReduceBatch) {
+  typedef const __attribute__((address_space(4))) ReduceBatch* table_ptr;
+  table_ptr b = (table_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+  int it = 0;
+  for (int i = 1; i < b->count; ++i) it += (int)blockIdx.x >= b->first_block[i] ? 1 : 0;  // uniform
+  SlabOutputs o;
+  SlabBounds sb;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    o.out[q] = b->o[it].out[q];
+    o.n[q] = b->o[it].n[q];
+    o.reps[q] = b->o[it].reps[q];
+    sb.so[q] = b->sb[it].so[q];
+    sb.pn[q] = b->sb[it].pn[q];
+    sb.reps[q] = b->sb[it].reps[q];
+    sb.lanes[q] = b->sb[it].lanes[q];
+  }
+#pragma unroll
+  for (int q = 0; q < 5; ++q) sb.tb[q] = b->sb[it].tb[q];
+  const int first = b->first_block[it];
+  reduce_slabs_body(b->in[it], b->S[it], b->stride[it], o, sb, (int)blockIdx.x - first, b->first_block[it + 1] - first);
 }
 
 // Same sum for FEW outputs and MANY slabs (the encoder's weight gradient: D + 1 outputs, one
@@ -647,9 +689,7 @@ static int check_shape(const lmufft_shape* s) {
     if (e_ != hipSuccess) return set_error("launch of %s failed: %s", name, hipGetErrorString(e_)); \
   } while (0)
 
-int launch_reduce_slabs(const float* in, int S, const SlabOutputs& o, hipStream_t st) {
-  if (!aligned16(in)) return set_error("workspace must be 16-byte aligned");
-  const long stride = slab_stride(o);
+static SlabBounds slab_bounds(const SlabOutputs& o, bool* single_out) {
   SlabBounds sb;
   bool single = true;
   sb.tb[0] = 0;
@@ -662,6 +702,38 @@ int launch_reduce_slabs(const float* in, int S, const SlabOutputs& o, hipStream_
     sb.tb[q + 1] = sb.tb[q] + ((slots + 7) & ~7L);
     single = single && sb.reps[q] == 1;
   }
+  if (single_out) *single_out = single;
+  return sb;
+}
+
+int launch_reduce_slabs_many(const float* const* in, const int* S, const SlabOutputs* o, int count, hipStream_t st) {
+  for (int i0 = 0; i0 < count; i0 += kReduceManyMax) {
+    ReduceBatch b;
+    b.count = std::min(count - i0, kReduceManyMax);
+    b.first_block[0] = 0;
+    for (int i = 0; i < b.count; ++i) {
+      if (!aligned16(in[i0 + i])) return set_error("workspace must be 16-byte aligned");
+      b.in[i] = in[i0 + i];
+      b.S[i] = S[i0 + i];
+      b.o[i] = o[i0 + i];
+      b.stride[i] = slab_stride(o[i0 + i]);
+      b.sb[i] = slab_bounds(o[i0 + i], nullptr);
+      b.first_block[i + 1] = b.first_block[i] + (int)min(cdiv(b.sb[i].tb[4], kThreads), 1024L);
+    }
+    {
+      PROF("k_reduce_slabs");
+      hipLaunchKernelGGL(k_reduce_slabs_many, dim3(b.first_block[b.count]), dim3(kThreads), 0, st, b);
+    }
+    LAUNCH_CHECK("k_reduce_slabs_many");
+  }
+  return 0;
+}
+
+int launch_reduce_slabs(const float* in, int S, const SlabOutputs& o, hipStream_t st) {
+  if (!aligned16(in)) return set_error("workspace must be 16-byte aligned");
+  const long stride = slab_stride(o);
+  bool single = true;
+  const SlabBounds sb = slab_bounds(o, &single);
   if (single && stride <= 4096 && S >= 64) {  // few outputs, many slabs
     {
       PROF("k_reduce_slabs_tall");

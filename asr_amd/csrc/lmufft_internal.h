@@ -41,6 +41,8 @@ inline long slab_seg_offset(const SlabOutputs& o, int q) {
 inline long slab_stride(const SlabOutputs& o) { return slab_seg_offset(o, 4); }
 // out[q][i] = sum over slabs and copies, added in a fixed order (deterministic); defined in lmufft_f32.hip
 int launch_reduce_slabs(const float* in, int S, const SlabOutputs& o, hipStream_t st);
+// `count` such sums in one launch (each item's slabs, slab count and outputs)
+int launch_reduce_slabs_many(const float* const* in, const int* S, const SlabOutputs* o, int count, hipStream_t st);
 int launch_gu_reduce(const float* gu_part, const float* u, float* out, int B, int T, int ntt, int tile_t,
                      hipStream_t st);
 // workspace sizes of the bf16 path (defined in lmufft_bf16.hip)

@@ -104,7 +104,7 @@ def linear_add_layer_norm_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Opti
 
 def linear_weight_grad_bf16(x: torch.Tensor, dy: torch.Tensor, want_bias: bool = True,
                             out_weight: Optional[torch.Tensor] = None, out_bias: Optional[torch.Tensor] = None,
-                            sum_stream: Optional["torch.cuda.Stream"] = None):
+                            sum_stream: Optional["torch.cuda.Stream"] = None, defer_sum: bool = False):
     """(dW [N, K] fp32, db [N] fp32 or None) of y = x W^T + b from x [..., K] and dy [..., N], both bf16:
     dW = sum over rows of dy^T x, db = sum over rows of dy (HIP kernel k_wgrad_bf16, fp32 accumulation in a
     fixed order).  K and N must be multiples of 8.  `out_weight` / `out_bias`: contiguous float32 tensors to write
@@ -131,6 +131,15 @@ def linear_weight_grad_bf16(x: torch.Tensor, dy: torch.Tensor, want_bias: bool =
     ws = torch.empty(_lib.lib.lmufft_linear_wgrad_workspace_bytes(rows, K, N), dtype=torch.uint8, device=x.device)
     cur = torch.cuda.current_stream(x.device)
     with torch.cuda.device(x.device):
+        if defer_sum:
+            # the GEMM now; the sum of its row ranges' partial results with every other deferred one, in ONE launch,
+            # when flush_weight_grad_sums() is called (GradBuckets does, before it exchanges or hands out gradients)
+            rc = _lib.lib.lmufft_linear_wgrad_slabs_bf16(_ptr(x), _ptr(dy), rows, K, N, _ptr(ws), ws.numel(),
+                                                         ctypes.c_void_p(cur.cuda_stream))
+            _lib.check(rc, "lmufft_linear_wgrad_slabs_bf16")
+            _PENDING_SUMS.append((x.device, _lib.WgradSumItem(rows, K, N, dW.data_ptr(), None if db is None else db.data_ptr(),
+                                                              ws.data_ptr(), ws.numel()), (ws, dW, db)))
+            return dW, db
         if sum_stream is None:
             rc = _lib.lib.lmufft_linear_wgrad_bf16(_ptr(x), _ptr(dy), rows, K, N, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(),
                                                    ctypes.c_void_p(cur.cuda_stream))
@@ -146,6 +155,30 @@ def linear_weight_grad_bf16(x: torch.Tensor, dy: torch.Tensor, want_bias: bool =
                                                    ctypes.c_void_p(sum_stream.cuda_stream))
         _lib.check(rc, "lmufft_linear_wgrad_sum_bf16")
     return dW, db, ws
+
+
+# Weight gradients whose slab sums wait for one common launch: (device, item, tensors kept alive).
+_PENDING_SUMS = []
+# True: a weight gradient that is written straight into a gradient bucket leaves the sum of its partial slabs to ONE
+# launch for all such gradients of the step, made when the bucket's owner asks for the gradients
+# (flush_weight_grad_sums; asr_amd.parallel.GradBuckets calls it before it exchanges or hands out gradients).
+DEFER_SLAB_SUMS = True
+
+
+def flush_weight_grad_sums() -> None:
+    """Sum the partial slabs of every weight gradient whose sum was deferred, one launch per device, on the current
+    stream.  The same numbers as the immediate sums."""
+    if not _PENDING_SUMS:
+        return
+    pending = list(_PENDING_SUMS)
+    _PENDING_SUMS.clear()
+    for dev in {d for d, _, _ in pending}:
+        items = [it for d, it, _ in pending if d == dev]
+        arr = (_lib.WgradSumItem * len(items))(*items)
+        with torch.cuda.device(dev):
+            rc = _lib.lib.lmufft_linear_wgrad_sum_many_bf16(arr, len(items),
+                                                            ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        _lib.check(rc, "lmufft_linear_wgrad_sum_many_bf16")
 
 
 # True: weight gradients that are written straight into a gradient bucket run on a side stream, beside the rest of
@@ -164,6 +197,12 @@ def _weight_grad_into_slots(xb, dyb, has_bias, slot_w, slot_b):
     from . import functional as F
 
     into_slots = slot_w is not None and (slot_b is not None or not has_bias)
+    if DEFER_SLAB_SUMS and into_slots and not ASYNC_WEIGHT_GRAD and not ASYNC_SLAB_SUMS:
+        return linear_weight_grad_bf16(xb, dyb, has_bias, slot_w, slot_b, defer_sum=True)
+    if _PENDING_SUMS and not into_slots:
+        # this gradient goes back to autograd, which may add it into `.grad` -- a bucket slice whose deferred sum
+        # would overwrite the result afterwards: sum first
+        flush_weight_grad_sums()
     if not (ASYNC_WEIGHT_GRAD and into_slots):
         if ASYNC_SLAB_SUMS and into_slots:
             dev = xb.device

@@ -268,7 +268,9 @@ class GradBuckets:
     def _join_side_streams() -> None:
         # weight gradients that layers with `async_weight_grad` run on a side stream write into the buckets
         from .functional import join_async_weight_grads
+        from .linear import flush_weight_grad_sums
 
+        flush_weight_grad_sums()  # Linear weight gradients whose slab sums wait for one common launch
         join_async_weight_grads()
 
     # -- step protocol ----------------------------------------------------------------------

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMUFFT_ABI_VERSION 24
+#define LMUFFT_ABI_VERSION 25
 
 /* element types of the activations (x, h, gh, gx, m) */
 #define LMUFFT_F32 0
@@ -395,6 +395,18 @@ int lmufft_linear_wgrad_slabs_bf16(const void* x, const void* dy, int64_t rows, 
                                    void* workspace, size_t workspace_bytes, void* stream);
 int lmufft_linear_wgrad_sum_bf16(int64_t rows, int32_t in, int32_t out, float* dW, float* db, void* workspace,
                                  size_t workspace_bytes, void* stream);
+/* The second call for several layers at once: one launch sums every item's partial results (the weight gradients of
+ * a training step's Linear layers, at the end of the backward).  `items` is a HOST array; an item's fields mean what
+ * the arguments of lmufft_linear_wgrad_sum_bf16 mean. */
+typedef struct lmufft_wgrad_sum_item {
+  int64_t rows;
+  int32_t in, out;
+  float* dW;
+  float* db;
+  void* workspace;
+  size_t workspace_bytes;
+} lmufft_wgrad_sum_item;
+int lmufft_linear_wgrad_sum_many_bf16(const lmufft_wgrad_sum_item* items, int32_t count, void* stream);
 
 /* ------------------------------------------------------------------------
  * CTC target packing.  Replaces the label concatenation at the head of

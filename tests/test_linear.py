@@ -220,7 +220,7 @@ def test_training_linear_matches_oracle(rows, K, N, with_bias):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("side_stream", [False, True, "sums"])
+@pytest.mark.parametrize("side_stream", [False, True, "sums", "immediate"])
 def test_training_linear_writes_into_gradient_buckets(side_stream, monkeypatch):
     """Parameters of a GradBuckets: the weight-gradient kernel writes into the bucket, `.grad` IS the bucket's slice
     (no clearing between steps, no accumulation kernel), a second use in the same step adds; the padded
@@ -232,6 +232,9 @@ def test_training_linear_writes_into_gradient_buckets(side_stream, monkeypatch):
 
     monkeypatch.setattr(lin, "ASYNC_WEIGHT_GRAD", side_stream is True)
     monkeypatch.setattr(lin, "ASYNC_SLAB_SUMS", side_stream == "sums")  # only the slab sums on the side stream
+    # default (False): the slab sums of the bucket-bound gradients wait for ONE launch in finish(); "immediate": each
+    # weight gradient sums its own slabs at once
+    monkeypatch.setattr(lin, "DEFER_SLAB_SUMS", side_stream is False)
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     a, head = torch.nn.Linear(64, 48).to(dev), torch.nn.Linear(48, 34).to(dev)
