@@ -20,7 +20,7 @@ CONV_TOEPLITZ = 1
 CONV_FFT = 2
 CONV_SCAN = 3
 NOALLOC_SCRATCH_BYTES = 8 << 20
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 
 class Shape(ctypes.Structure):
@@ -33,6 +33,18 @@ class Shape(ctypes.Structure):
         ("M", ctypes.c_int32),
         ("Hd", ctypes.c_int32),
         ("ldH", ctypes.c_int32),
+    ]
+
+
+class LnSumItem(ctypes.Structure):
+    """Mirror of `lmufft_ln_sum_item` (include/lmufft.h)."""
+
+    _fields_ = [
+        ("rows", ctypes.c_int64),
+        ("C", ctypes.c_int32),
+        ("dgamma", ctypes.c_void_p),
+        ("dbeta", ctypes.c_void_p),
+        ("workspace", ctypes.c_void_p),
     ]
 
 
@@ -187,6 +199,8 @@ def _load():
     lib.lmufft_layernorm_dropout_bwd.restype = ci
     lib.lmufft_layernorm_dropout_bwd.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, vp, f32, i64, i32, f32, u32, u32, vp, vp,
                                                  vp, vp, vp, sz, vp]
+    lib.lmufft_layernorm_param_sum_many.restype = ci
+    lib.lmufft_layernorm_param_sum_many.argtypes = [ctypes.POINTER(LnSumItem), i32, vp]
     lib.lmufft_backward_needs_gm_bf16.restype = ci
     lib.lmufft_backward_needs_gm_bf16.argtypes = [sp, ci, ci]
     lib.lmufft_dropout_epoch.restype = ci
@@ -271,6 +285,7 @@ EXPORTS = (
     "lmufft_layernorm_bwd",
     "lmufft_add_layernorm_dropout",
     "lmufft_layernorm_dropout_bwd",
+    "lmufft_layernorm_param_sum_many",
     "lmufft_dropout_epoch",
     "lmufft_linear_bf16",
     "lmufft_linear_ln_bf16",

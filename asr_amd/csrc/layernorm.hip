@@ -291,9 +291,43 @@ __global__ __launch_bounds__(kLnThreads) void k_layernorm_param_reduce(const flo
   }
 }
 
+// the same sums for several layer norms in one launch (the table travels in the kernel's arguments)
+constexpr int kLnSumManyMax = 32;
+struct LnSumBatch {
+  const float* partial[kLnSumManyMax];
+  float* dgamma[kLnSumManyMax];
+  float* dbeta[kLnSumManyMax];
+  int nblocks[kLnSumManyMax], C[kLnSumManyMax];
+  int first_block[kLnSumManyMax + 1];
+  int count;
+};
+__global__ __launch_bounds__(kLnThreads) void k_layernorm_param_reduce_many(LnSumBatch) {
+  typedef const __attribute__((address_space(4))) LnSumBatch* table_ptr;
+  table_ptr b = (table_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+  int it = 0;
+  for (int i = 1; i < b->count; ++i) it += (int)blockIdx.x >= b->first_block[i] ? 1 : 0;  // uniform
+  const int C = b->C[it], nblocks = b->nblocks[it];
+  const float* partial = b->partial[it];
+  const int i = ((int)blockIdx.x - b->first_block[it]) * (kLnThreads / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= 2 * C) return;
+  float t = 0.f;
+  for (int k = lane; k < nblocks; k += 64) t += partial[(long)k * 2 * C + i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+  if (lane == 0) {
+    if (i < C) b->dgamma[it][i] = t;
+    else b->dbeta[it][i - C] = t;
+  }
+}
+
 }  // namespace lmufft
 
 using namespace lmufft;
+
+static int ln_bwd_blocks(int64_t rows) {
+  const long blocks = (rows + kLnThreads / 32 - 1) / (kLnThreads / 32);
+  return (int)std::min<long>(blocks, kLnBwdMaxBlocks);
+}
 
 static int add_layernorm_any(const void* x, int x_dtype, const void* res, int res_dtype, const float* gamma,
                             const float* beta, float eps, int64_t rows, int32_t C, void* out, int out_dtype,
@@ -406,7 +440,7 @@ extern "C" int lmufft_layernorm_dropout_bwd(const void* x, int x_dtype, const vo
   auto known = [](int d) { return d == LMUFFT_F32 || d == LMUFFT_BF16; };
   if (!known(x_dtype) || !known(dy_dtype) || (res && !known(res_dtype)) || (dy2 && !known(dy2_dtype)))
     return set_error("layernorm backward: unknown dtype");
-  if (!x || !dy || !gamma || !dx || !dgamma || !dbeta || !workspace) return set_error("layernorm backward: NULL pointer");
+  if (!x || !dy || !gamma || !dx || !workspace || (!dgamma != !dbeta)) return set_error("layernorm backward: NULL pointer");
   if (dres && !res) return set_error("layernorm backward: dres without res");
   if (workspace_bytes < lmufft_layernorm_bwd_workspace_bytes(C))
     return set_error("layernorm backward: workspace of %zu bytes needed, %zu given", lmufft_layernorm_bwd_workspace_bytes(C),
@@ -420,8 +454,7 @@ extern "C" int lmufft_layernorm_dropout_bwd(const void* x, int x_dtype, const vo
     return set_error("layernorm backward: rows must start on 16-byte (f32) / 8-byte (bf16) boundaries");
   hipStream_t st = (hipStream_t)stream;
   const int ng = (C / 4 + 31) / 32;
-  const long blocks = (rows + kLnThreads / 32 - 1) / (kLnThreads / 32);
-  const int nb = (int)std::min<long>(blocks, kLnBwdMaxBlocks);
+  const int nb = ln_bwd_blocks(rows);
   const size_t lds = sizeof(float) * (kLnThreads / 32) * 2 * (size_t)C;
   float* partial = (float*)workspace;
   {
@@ -437,10 +470,43 @@ extern "C" int lmufft_layernorm_dropout_bwd(const void* x, int x_dtype, const vo
     else if (ng <= 6) LN_BWD(6);
     else LN_BWD(8);
 #undef LN_BWD
-    hipLaunchKernelGGL(k_layernorm_param_reduce, dim3((2 * C + kLnThreads / 64 - 1) / (kLnThreads / 64)), dim3(kLnThreads), 0, st,
-                       (const float*)partial, nb, C, dgamma, dbeta);
+    if (dgamma)  // (NULL: the workgroups' partial sums stay in the workspace for lmufft_layernorm_param_sum_many)
+      hipLaunchKernelGGL(k_layernorm_param_reduce, dim3((2 * C + kLnThreads / 64 - 1) / (kLnThreads / 64)), dim3(kLnThreads), 0, st,
+                         (const float*)partial, nb, C, dgamma, dbeta);
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error("launch of k_layernorm_bwd failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
+extern "C" int lmufft_layernorm_param_sum_many(const lmufft_ln_sum_item* items, int32_t count, void* stream) {
+  if (count < 0 || (count > 0 && !items)) return set_error("layernorm parameter sums: bad item list");
+  for (int i = 0; i < count; ++i) {
+    const lmufft_ln_sum_item& it = items[i];
+    if (it.rows <= 0 || it.C <= 0 || it.C % 4 != 0 || it.C > 32 * 4 * kLnMaxGroups)
+      return set_error("layernorm parameter sums: bad shape (rows=%lld C=%d)", (long long)it.rows, it.C);
+    if (!it.dgamma || !it.dbeta || !it.workspace) return set_error("layernorm parameter sums: NULL pointer");
+  }
+  hipStream_t st = (hipStream_t)stream;
+  for (int i0 = 0; i0 < count; i0 += kLnSumManyMax) {
+    LnSumBatch b;
+    b.count = std::min(count - i0, kLnSumManyMax);
+    b.first_block[0] = 0;
+    for (int i = 0; i < b.count; ++i) {
+      const lmufft_ln_sum_item& it = items[i0 + i];
+      b.partial[i] = (const float*)it.workspace;
+      b.dgamma[i] = it.dgamma;
+      b.dbeta[i] = it.dbeta;
+      b.nblocks[i] = ln_bwd_blocks(it.rows);
+      b.C[i] = it.C;
+      b.first_block[i + 1] = b.first_block[i] + (2 * it.C + kLnThreads / 64 - 1) / (kLnThreads / 64);
+    }
+    {
+      ProfScope ps("k_layernorm_bwd", st);
+      hipLaunchKernelGGL(k_layernorm_param_reduce_many, dim3(b.first_block[b.count]), dim3(kLnThreads), 0, st, b);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error("launch of k_layernorm_param_reduce_many failed: %s", hipGetErrorString(e));
+  }
   return 0;
 }

@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from .dropout import check_capturable
-from .parallel import adopt, grad_slot
+from .parallel import adopt, grad_slot, register_deferred_sums
 
 _DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
 MAX_WIDTH = 1024
@@ -68,10 +68,37 @@ def add_layer_norm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: to
     return (out, out16) if twin else out
 
 
+# Layer-norm backwards whose parameter sums wait for one common launch: (device, item, tensors kept alive).
+_PENDING_PARAM_SUMS = []
+# True: a layer-norm backward whose parameter gradients go straight into a gradient bucket leaves the sum of its
+# workgroups' partial results to ONE launch for all such layer norms of the step (flush_param_sums; GradBuckets
+# calls it before it exchanges or hands out gradients).
+DEFER_PARAM_SUMS = True
+
+
+def flush_param_sums() -> None:
+    """Sum the partial parameter gradients of every layer-norm backward that deferred them: one launch per device on
+    the current stream, the same numbers as the immediate sums."""
+    if not _PENDING_PARAM_SUMS:
+        return
+    pending = list(_PENDING_PARAM_SUMS)
+    _PENDING_PARAM_SUMS.clear()
+    for dev in {d for d, _, _ in pending}:
+        items = [it for d, it, _ in pending if d == dev]
+        arr = (_lib.LnSumItem * len(items))(*items)
+        with torch.cuda.device(dev):
+            rc = _lib.lib.lmufft_layernorm_param_sum_many(arr, len(items),
+                                                          ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        _lib.check(rc, "lmufft_layernorm_param_sum_many")
+
+
+register_deferred_sums(flush_param_sums)
+
+
 def add_layer_norm_backward(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor, dy: torch.Tensor,
                             eps: float = 1e-5, out_weight: Optional[torch.Tensor] = None,
                             out_bias: Optional[torch.Tensor] = None, p_drop: float = 0.0, seeds=(0, 0),
-                            dy2: Optional[torch.Tensor] = None):
+                            dy2: Optional[torch.Tensor] = None, defer_param_sums: bool = False):
     """(dx, dresidual or None, dweight, dbias) of add_layer_norm: dx / dresidual carry the same values in the dtype
     of x / residual (one tensor when the dtypes agree); dweight, dbias float32, written into `out_weight` /
     `out_bias` (contiguous float32 [C]) when given.  `p_drop`, `seeds`: those of the forward call; dy passes
@@ -110,9 +137,13 @@ def add_layer_norm_backward(x: torch.Tensor, residual: Optional[torch.Tensor], w
             p(x), _DTYPES[x.dtype], p(residual), _DTYPES[residual.dtype] if residual is not None else 0, p(dy),
             _DTYPES[dy.dtype], p(dy2), _DTYPES[dy2.dtype] if dy2 is not None else 0, p(weight), float(eps), rows, C,
             float(p_drop), int(seeds[0]) & 0xFFFFFFFF,
-            int(seeds[1]) & 0xFFFFFFFF, p(dx), p(dres), p(dgamma), p(dbeta), p(ws), ws.numel(),
+            int(seeds[1]) & 0xFFFFFFFF, p(dx), p(dres), None if defer_param_sums else p(dgamma),
+            None if defer_param_sums else p(dbeta), p(ws), ws.numel(),
             ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
     _lib.check(rc, "lmufft_layernorm_dropout_bwd")
+    if defer_param_sums:  # dgamma / dbeta are complete after flush_param_sums()
+        _PENDING_PARAM_SUMS.append((x.device, _lib.LnSumItem(rows, C, dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr()),
+                                    (ws, dgamma, dbeta)))
     if residual is None:
         return dx, None, dgamma, dbeta
     return dx, (dx if dres is None else dres), dgamma, dbeta
@@ -136,7 +167,11 @@ class _AddLayerNormTrain(torch.autograd.Function):
             dy, dy16 = dy16, None
         # parameters of a GradBuckets: the kernel writes into the bucket and autograd adopts the slices as .grad
         slot_w, slot_b = grad_slot(ctx.params[0]), grad_slot(ctx.params[1])
-        dx, dres, dgamma, dbeta = add_layer_norm_backward(x, residual, weight, dy, ctx.eps, slot_w, slot_b, *ctx.drop, dy16)
+        defer = DEFER_PARAM_SUMS and slot_w is not None and slot_b is not None
+        if not defer and _PENDING_PARAM_SUMS:
+            flush_param_sums()  # a gradient handed to autograd may be added into a slice that a deferred sum still owes
+        dx, dres, dgamma, dbeta = add_layer_norm_backward(x, residual, weight, dy, ctx.eps, slot_w, slot_b, *ctx.drop, dy16,
+                                                          defer_param_sums=defer)
         dgamma = adopt(dgamma) if slot_w is not None else dgamma.to(weight.dtype)
         dbeta = adopt(dbeta) if slot_b is not None else dbeta.to(weight.dtype)
         return (dx if ctx.needs_input_grad[0] else None, dres if ctx.needs_input_grad[1] else None,

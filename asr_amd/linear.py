@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from .parallel import adopt, fused_slot, grad_slot
+from .parallel import adopt, fused_slot, grad_slot, register_deferred_sums
 
 _DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
 FUSED_LAYER_NORM_MAX_WIDTH = 384
@@ -179,6 +179,9 @@ def flush_weight_grad_sums() -> None:
             rc = _lib.lib.lmufft_linear_wgrad_sum_many_bf16(arr, len(items),
                                                             ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
         _lib.check(rc, "lmufft_linear_wgrad_sum_many_bf16")
+
+
+register_deferred_sums(flush_weight_grad_sums)
 
 
 # True: weight gradients that are written straight into a gradient bucket run on a side stream, beside the rest of

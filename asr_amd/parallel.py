@@ -35,6 +35,22 @@ import torch.distributed as dist
 _ALIGN = 64  # every gradient starts on a 256-byte boundary of its bucket (vector stores in the kernels)
 
 
+# Functions that complete gradients whose last reduction step was left for one common launch per step; a layer
+# module registers its own (register_deferred_sums) and GradBuckets runs them all before it exchanges or hands out
+# gradients.
+_DEFERRED_SUMS = []
+
+
+def register_deferred_sums(fn) -> None:
+    if fn not in _DEFERRED_SUMS:
+        _DEFERRED_SUMS.append(fn)
+
+
+def run_deferred_sums() -> None:
+    for fn in _DEFERRED_SUMS:
+        fn()
+
+
 def grad_slot(p):
     """The slice of a gradient bucket a backward may write `p`'s gradient into, or None: `p` belongs to a
     GradBuckets, is float32 and no backward has asked for the slice in this step.  Return `adopt(slot)` as the gradient:
@@ -268,9 +284,8 @@ class GradBuckets:
     def _join_side_streams() -> None:
         # weight gradients that layers with `async_weight_grad` run on a side stream write into the buckets
         from .functional import join_async_weight_grads
-        from .linear import flush_weight_grad_sums
 
-        flush_weight_grad_sums()  # Linear weight gradients whose slab sums wait for one common launch
+        run_deferred_sums()  # gradient sums that layers left for one common launch (asr_amd.linear, asr_amd.layernorm)
         join_async_weight_grads()
 
     # -- step protocol ----------------------------------------------------------------------

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMUFFT_ABI_VERSION 25
+#define LMUFFT_ABI_VERSION 26
 
 /* element types of the activations (x, h, gh, gx, m) */
 #define LMUFFT_F32 0
@@ -364,6 +364,17 @@ int lmufft_layernorm_dropout_bwd(const void* x, int x_dtype, const void* res, in
                                  int64_t rows, int32_t C, float p_drop, uint32_t seed0, uint32_t seed1, void* dx,
                                  void* dres, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
                                  void* stream);
+/* dgamma == dbeta == NULL in either backward: the workgroups' partial sums of the parameter gradients stay in the
+ * workspace, and ONE later launch sums them for every layer norm of the step (six per step in the reference's
+ * encoder).  `items` is a HOST array; rows and C as given to the backward call whose workspace the item names. */
+typedef struct lmufft_ln_sum_item {
+  int64_t rows;
+  int32_t C;
+  float* dgamma;
+  float* dbeta;
+  const void* workspace;
+} lmufft_ln_sum_item;
+int lmufft_layernorm_param_sum_many(const lmufft_ln_sum_item* items, int32_t count, void* stream);
 
 /* ------------------------------------------------------------------------
  * Dropout masks under HIP graph replay.  The reference draws a fresh mask at every call of nn.Dropout

@@ -269,3 +269,47 @@ def test_training_layer_norm_twin_output(p):
         assert torch.equal(got[0], want[0])
         for a, c in zip(got[1:], want[1:]):
             assert torch.allclose(a.float(), c.float(), rtol=2.0 ** -7, atol=1e-5 * float(c.float().abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("defer", [True, False])
+def test_training_layer_norm_writes_into_gradient_buckets(defer, monkeypatch):
+    """Parameters of a GradBuckets: dgamma / dbeta land in the bucket's slices; with DEFER_PARAM_SUMS the sums of the
+    workgroups' partial results of ALL layer norms of the step are one launch made by finish() -- the same bits as
+    the immediate sums, and as the gradients without buckets; a second use of a layer norm in the step adds."""
+    import asr_amd.layernorm as lnm
+    from asr_amd.layernorm import add_layer_norm_train
+    from asr_amd.parallel import GradBuckets
+
+    monkeypatch.setattr(lnm, "DEFER_PARAM_SUMS", defer)
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    lns = [torch.nn.LayerNorm(384).to(dev) for _ in range(3)]
+    for ln in lns:
+        torch.nn.init.normal_(ln.weight, 1.0, 0.1)
+        torch.nn.init.normal_(ln.bias, 0.0, 0.1)
+    x = torch.randn(700, 384, device=dev)
+    res = torch.randn(700, 384, device=dev)
+
+    def loss(mods):
+        y = add_layer_norm_train(x, res, mods[0].weight, mods[0].bias)
+        y = add_layer_norm_train(y, None, mods[1].weight, mods[1].bias)
+        y = add_layer_norm_train(y, x, mods[2].weight, mods[2].bias)
+        y = add_layer_norm_train(y, None, mods[1].weight, mods[1].bias)  # second use of the middle one
+        return (y * torch.linspace(-1, 1, 384, device=dev)).sum()
+
+    ref = [torch.nn.LayerNorm(384).to(dev) for _ in range(3)]
+    for a, b in zip(ref, lns):
+        a.load_state_dict(b.state_dict())
+    loss(ref).backward()
+    buckets = GradBuckets([list(ln.parameters()) for ln in reversed(lns)], overlap=False)
+    for _ in range(2):
+        buckets.zero_grad()
+        buckets.arena.fill_(55.0)
+        loss(lns).backward()
+        assert bool(lnm._PENDING_PARAM_SUMS) == defer
+        buckets.finish()
+        assert not lnm._PENDING_PARAM_SUMS
+        for a, b in zip(ref, lns):
+            assert torch.allclose(b.weight.grad, a.weight.grad, rtol=1e-6, atol=1e-6 * float(a.weight.grad.abs().max()))
+            assert torch.allclose(b.bias.grad, a.bias.grad, rtol=1e-6, atol=1e-6 * float(a.bias.grad.abs().max()))
