@@ -20,7 +20,7 @@ CONV_TOEPLITZ = 1
 CONV_FFT = 2
 CONV_SCAN = 3
 NOALLOC_SCRATCH_BYTES = 8 << 20
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 
 class Shape(ctypes.Structure):
@@ -45,6 +45,20 @@ class LnSumItem(ctypes.Structure):
         ("dgamma", ctypes.c_void_p),
         ("dbeta", ctypes.c_void_p),
         ("workspace", ctypes.c_void_p),
+    ]
+
+
+class LmuSumItem(ctypes.Structure):
+    """Mirror of `lmufft_lmu_sum_item` (include/lmufft.h)."""
+
+    _fields_ = [
+        ("shape", Shape),
+        ("gw_u", ctypes.c_void_p),
+        ("gb_u", ctypes.c_void_p),
+        ("gW_h", ctypes.c_void_p),
+        ("gb_h", ctypes.c_void_p),
+        ("workspace", ctypes.c_void_p),
+        ("workspace_bytes", ctypes.c_size_t),
     ]
 
 
@@ -170,6 +184,10 @@ def _load():
     lib.lmufft_backward_bf16.argtypes = [sp] + [vp] * 17 + [ci, vp, sz, vp]
     lib.lmufft_backward_data_bf16.restype = ci
     lib.lmufft_backward_data_bf16.argtypes = [sp] + [vp] * 13 + [ci, vp, sz, vp]
+    lib.lmufft_backward_partial_bf16.restype = ci
+    lib.lmufft_backward_partial_bf16.argtypes = [sp] + [vp] * 13 + [ci, vp, sz, vp]
+    lib.lmufft_backward_weights_sum_many_bf16.restype = ci
+    lib.lmufft_backward_weights_sum_many_bf16.argtypes = [ctypes.POINTER(LmuSumItem), ctypes.c_int32, vp]
     lib.lmufft_backward_weights_bf16.restype = ci
     lib.lmufft_backward_weights_bf16.argtypes = [sp] + [vp] * 6 + [vp, sz, vp]
     lib.lmufft_scan_chunk.restype = ctypes.c_int32
@@ -318,6 +336,8 @@ EXPORTS = (
     "lmufft_backward_bf16",
     "lmufft_backward_data_bf16",
     "lmufft_backward_weights_bf16",
+    "lmufft_backward_partial_bf16",
+    "lmufft_backward_weights_sum_many_bf16",
     "lmufft_conv_forward_bf16",
     "lmufft_conv_backward_bf16",
     "lmufft_scan_chunk",

@@ -2501,7 +2501,7 @@ static int backward_bf16_parts(int parts, const lmufft_shape* s, const void* x_,
   if (int rc = check_shape_b(s)) return rc;
   if (!x_ || !m_) return set_error("backward: NULL pointer");
   if ((parts & 1) && (!w_u || !wprep || !hprep || !u || !h_)) return set_error("backward: NULL pointer");
-  if ((parts & 2) && (!gw_u || !gb_u || !gW_h || !gb_h)) return set_error("backward: NULL pointer");
+  if ((parts & 2) && !(parts & 4) && (!gw_u || !gb_u || !gW_h || !gb_h)) return set_error("backward: NULL pointer");
   bool scan = false;
   if (parts & 1)
     if (int rc = use_scan_route(conv_algo, scanprep, &scan)) return rc;
@@ -2663,7 +2663,8 @@ static int backward_bf16_parts(int parts, const lmufft_shape* s, const void* x_,
                            (const float*)ga, wslab, (int)rows, p.rps, s->M, s->D, s->Hd);
     }
     LAUNCH_CHECKB("k_wgrad_bf16");
-    if (int rc = launch_reduce_slabs(wslab, p.S, wgrad_outputs(*s, gW_h, gb_h, gw_u, gb_u), st)) return rc;
+    if (!(parts & 4))  // (4: the slabs stay in the workspace for lmufft_backward_weights_sum_many_bf16)
+      if (int rc = launch_reduce_slabs(wslab, p.S, wgrad_outputs(*s, gW_h, gb_h, gw_u, gb_u), st)) return rc;
   }
   return 0;
 }
@@ -2683,6 +2684,33 @@ int lmufft_backward_bf16(const lmufft_shape* s, const void* x, const float* w_u,
                          void* stream) {
   return backward_bf16_parts(3, s, x, w_u, wprep, hprep, scanprep, u, m, h, hmask, gh, gh_n, gx, gw_u, gb_u, gW_h, gb_h, gm,
                              conv_algo, workspace, workspace_bytes, stream);
+}
+
+int lmufft_backward_partial_bf16(const lmufft_shape* s, const void* x, const float* w_u, const void* wprep,
+                                 const void* hprep, const void* scanprep, const float* u, const void* m, const void* h,
+                                 const void* hmask, const void* gh, const void* gh_n, void* gx, void* gm, int conv_algo,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  return backward_bf16_parts(3 | 4, s, x, w_u, wprep, hprep, scanprep, u, m, h, hmask, gh, gh_n, gx, nullptr, nullptr,
+                             nullptr, nullptr, gm, conv_algo, workspace, workspace_bytes, stream);
+}
+
+int lmufft_backward_weights_sum_many_bf16(const lmufft_lmu_sum_item* items, int32_t count, void* stream) {
+  if (count < 0 || (count > 0 && !items)) return set_error("backward weight sums: bad item list");
+  std::vector<const float*> in(count);
+  std::vector<int> S(count);
+  std::vector<SlabOutputs> o(count);
+  for (int i = 0; i < count; ++i) {
+    const lmufft_lmu_sum_item& it = items[i];
+    if (int rc = check_shape_b(&it.shape)) return rc;
+    if (!it.gw_u || !it.gb_u || !it.gW_h || !it.gb_h || !it.workspace) return set_error("backward weight sums: NULL pointer");
+    const BwdPlanB p = plan_backward_b(it.shape);
+    if (it.workspace_bytes < p.total)
+      return set_error("backward weight sums: workspace of %zu bytes needed, %zu given", p.total, it.workspace_bytes);
+    in[i] = (const float*)((const char*)it.workspace + p.off_wslab);
+    S[i] = p.S;
+    o[i] = wgrad_outputs(it.shape, it.gW_h, it.gb_h, it.gw_u, it.gb_u);
+  }
+  return launch_reduce_slabs_many(in.data(), S.data(), o.data(), count, (hipStream_t)stream);
 }
 
 int lmufft_backward_data_bf16(const lmufft_shape* s, const void* x, const float* w_u, const void* wprep,

@@ -10,6 +10,7 @@ import ctypes
 import torch
 
 from . import _lib
+from .parallel import register_deferred_sums
 
 # True: the bf16 backward always forms the memory gradient gm = gz W_h[:, :M] and runs the adjoint convolution
 # on it (the reference's own order of operations); False: where the library can, it takes the encoder gradient
@@ -126,6 +127,32 @@ def _wgrad_stream(device):
     if st is None:
         st = _WGRAD_STREAMS[key] = torch.cuda.Stream(device)
     return st
+
+
+# LMUFFT layers whose weight-gradient slabs wait for one common sum: (device, item, tensors kept alive).
+_PENDING_WEIGHT_SUMS = []
+# True: a bf16 backward that writes its parameter gradients straight into a gradient bucket leaves the sum of the
+# weight-gradient kernel's partial slabs to ONE launch for all such layers of the step, made when the bucket's owner
+# asks for the gradients (flush_weight_sums; asr_amd.parallel.GradBuckets calls it before it exchanges or hands out
+# gradients).  The same numbers as the immediate sums.
+DEFER_WEIGHT_SUMS = True
+
+
+def flush_weight_sums() -> None:
+    """Sum the deferred weight-gradient slabs, one launch per device, on the current stream."""
+    if not _PENDING_WEIGHT_SUMS:
+        return
+    pending = list(_PENDING_WEIGHT_SUMS)
+    _PENDING_WEIGHT_SUMS.clear()
+    for dev in {d for d, _, _ in pending}:
+        items = [it for d, it, _ in pending if d == dev]
+        arr = (_lib.LmuSumItem * len(items))(*items)
+        with torch.cuda.device(dev):
+            rc = _lib.lib.lmufft_backward_weights_sum_many_bf16(arr, len(items), _stream(dev))
+        _lib.check(rc, "lmufft_backward_weights_sum_many_bf16")
+
+
+register_deferred_sums(flush_weight_sums)
 
 
 def join_async_weight_grads(device=None) -> None:
@@ -267,6 +294,7 @@ class _LMUFFTFunction(torch.autograd.Function):
             # `.grad` -- the sink's views -- on this stream.  If the first backward's weight gradient is
             # still running on the side stream it is writing those same views: wait for it first.
             join_async_weight_grads(dev)
+            flush_weight_sums()  # (a deferred sum would overwrite what autograd is about to add)
         direct = sink is not None and sink.usable(ctx.needs_input_grad[1:5])
         if direct:
             gw_u, gb_u, gW_h, gb_h = sink.views
@@ -310,6 +338,15 @@ class _LMUFFTFunction(torch.autograd.Function):
                 key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
                 _ASYNC_WGRAD.setdefault(key, []).append((done, (x, m, ws, gw_u, gb_u, gW_h, gb_h)))
                 what = "lmufft_backward_weights_bf16"
+            elif DEFER_WEIGHT_SUMS and direct:
+                rc = _lib.lib.lmufft_backward_partial_bf16(
+                    ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(wprep), _ptr(hprep), _ptr(scanprep), _ptr(u), _ptr(m),
+                    _ptr(h), _ptr(hmask), _ptr(gh), _ptr(gh_n), _ptr(gx), _ptr(gm), ctx.conv_algo, _ptr(ws), ws.numel(),
+                    _stream(dev))
+                what = "lmufft_backward_partial_bf16"
+                _PENDING_WEIGHT_SUMS.append((dev, _lib.LmuSumItem(shp, gw_u.data_ptr(), gb_u.data_ptr(), gW_h.data_ptr(),
+                                                                  gb_h.data_ptr(), ws.data_ptr(), ws.numel()),
+                                             (ws, gw_u, gb_u, gW_h, gb_h)))
             else:
                 rc = _lib.lib.lmufft_backward_bf16(
                     ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(wprep), _ptr(hprep), _ptr(scanprep), _ptr(u), _ptr(m),

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMUFFT_ABI_VERSION 26
+#define LMUFFT_ABI_VERSION 27
 
 /* element types of the activations (x, h, gh, gx, m) */
 #define LMUFFT_F32 0
@@ -260,6 +260,23 @@ int lmufft_backward_data_bf16(const lmufft_shape* s, const void* x, const float*
 int lmufft_backward_weights_bf16(const lmufft_shape* s, const void* x, const void* m, float* gw_u,
                                  float* gb_u, float* gW_h, float* gb_h, void* workspace,
                                  size_t workspace_bytes, void* stream);
+/* lmufft_backward_bf16 with the last step left out: the weight-gradient kernel's partial slabs stay in the workspace
+ * (gx is complete), and ONE later launch sums them for every layer of the step -- three launches less per step of the
+ * reference's three-block encoder.  `items` is a HOST array; shape and workspace as given to the partial call. */
+int lmufft_backward_partial_bf16(const lmufft_shape* s, const void* x, const float* w_u, const void* wprep,
+                                 const void* hprep, const void* scanprep, const float* u, const void* m,
+                                 const void* h, const void* hmask, const void* gh, const void* gh_n, void* gx,
+                                 void* gm, int conv_algo, void* workspace, size_t workspace_bytes, void* stream);
+typedef struct lmufft_lmu_sum_item {
+  lmufft_shape shape;
+  float* gw_u;
+  float* gb_u;
+  float* gW_h;
+  float* gb_h;
+  const void* workspace;
+  size_t workspace_bytes;
+} lmufft_lmu_sum_item;
+int lmufft_backward_weights_sum_many_bf16(const lmufft_lmu_sum_item* items, int32_t count, void* stream);
 
 /* ------------------------------------------------------------------------
  * Log-mel frontend.  Replaces AudioPreprocessor.extract_mel_features and

@@ -346,3 +346,36 @@ def test_gradient_sink_matches_autograd_accumulation(dtype):
             _close(pb.grad.cpu().numpy(), pa.grad.cpu().numpy(), f"{n} step {step}", rtol=1e-5, atol_rel=1e-6)
             assert buckets.buckets[0].data_ptr() <= pb.grad.data_ptr() < buckets.buckets[0].data_ptr() + \
                 buckets.buckets[0].numel() * 4
+
+
+def test_deferred_weight_sums_match_the_immediate_ones(monkeypatch):
+    """Three stacked bf16 layers whose weight-gradient slabs are summed by one launch at finish() give bit-identical
+    gradients to the same layers summing their slabs inside their own backward."""
+    import copy
+
+    from asr_amd import LMUFFT
+    from asr_amd import functional as F
+    from asr_amd.parallel import GradBuckets
+
+    dev = _dev()
+    torch.manual_seed(11)
+    sizes = [(48, 40), (40, 40), (40, 24)]
+    ref = [LMUFFT(d, hd, 24, 96, 16).to(dev) for d, hd in sizes]
+    x = torch.randn(5, 96, 48, device=dev).to(torch.bfloat16)
+    gy = torch.randn(5, 96, 24, device=dev).to(torch.bfloat16)
+    grads = {}
+    for defer in (False, True):
+        monkeypatch.setattr(F, "DEFER_WEIGHT_SUMS", defer)
+        layers = copy.deepcopy(ref)
+        buckets = GradBuckets(list(reversed(layers)))
+        buckets.zero_grad()
+        y = x
+        for l in layers:
+            y, _ = l(y)
+        y.backward(gy)
+        assert len(F._PENDING_WEIGHT_SUMS) == (3 if defer else 0)
+        buckets.finish()
+        assert not F._PENDING_WEIGHT_SUMS
+        grads[defer] = [p.grad.clone() for l in layers for p in l.parameters()]
+    for g0, g1 in zip(grads[False], grads[True]):
+        assert torch.equal(g0, g1)
