@@ -20,7 +20,7 @@ CONV_TOEPLITZ = 1
 CONV_FFT = 2
 CONV_SCAN = 3
 NOALLOC_SCRATCH_BYTES = 8 << 20
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 
 class Shape(ctypes.Structure):
@@ -46,6 +46,12 @@ class LnSumItem(ctypes.Structure):
         ("dbeta", ctypes.c_void_p),
         ("workspace", ctypes.c_void_p),
     ]
+
+
+# options of lmufft_backward_flags_bf16 (include/lmufft.h)
+BWD_GH_MASKED = 1
+BWD_MASK_GX = 2
+BWD_PARTIAL_SUMS = 4
 
 
 class LmuSumItem(ctypes.Structure):
@@ -184,6 +190,8 @@ def _load():
     lib.lmufft_backward_bf16.argtypes = [sp] + [vp] * 17 + [ci, vp, sz, vp]
     lib.lmufft_backward_data_bf16.restype = ci
     lib.lmufft_backward_data_bf16.argtypes = [sp] + [vp] * 13 + [ci, vp, sz, vp]
+    lib.lmufft_backward_flags_bf16.restype = ci
+    lib.lmufft_backward_flags_bf16.argtypes = [sp] + [vp] * 17 + [ci, vp, sz, vp, ctypes.c_uint32]
     lib.lmufft_backward_partial_bf16.restype = ci
     lib.lmufft_backward_partial_bf16.argtypes = [sp] + [vp] * 13 + [ci, vp, sz, vp]
     lib.lmufft_backward_weights_sum_many_bf16.restype = ci
@@ -337,6 +345,7 @@ EXPORTS = (
     "lmufft_backward_data_bf16",
     "lmufft_backward_weights_bf16",
     "lmufft_backward_partial_bf16",
+    "lmufft_backward_flags_bf16",
     "lmufft_backward_weights_sum_many_bf16",
     "lmufft_conv_forward_bf16",
     "lmufft_conv_backward_bf16",

@@ -110,6 +110,42 @@ __global__ __launch_bounds__(kThreads) void k_prep_H(const float* __restrict__ H
   }
 }
 
+// Q^T[tau][n] = sum_k H^T[tau][k] W_h[n][k] (k < M) in bf16, for the backward's Q route (see k_gu_q_bf16): one
+// 64 x 64 tile per workgroup on the matrix cores.
+using QPrepTile = TileB<64, 64, 64, 2, 2>;
+struct QPrep {
+  const bf16_t *HbT, *Wb;
+  bf16_t* QT;
+  int rowsQ, rowsHT, Hd, M, ldHT, ldW, ldQ;
+};
+constexpr int kQPrepLdsElems = 2 * 64 * (64 + 8);
+__device__ __forceinline__ void qprep_block(const QPrep& q, int block, bf16_t* qsmem) {
+  using TL = QPrepTile;
+  const int tiles_n = (q.Hd + TL::BN - 1) / TL::BN;
+  const int tau0 = (block / tiles_n) * TL::BM, n0 = (block % tiles_n) * TL::BN;
+  auto la = plain_load_b([=](int r, int k) -> bf16x8 {
+    const int tau = tau0 + r;
+    return bload8<true>(q.HbT, (long)tau * q.ldHT + k, k, q.ldHT, tau < q.rowsHT);
+  });
+  auto lb = plain_load_b([=](int r, int k) -> bf16x8 {
+    const int n = n0 + r;
+    return bload8<true>(q.Wb, (long)n * q.ldW + k, k, q.M, n < q.Hd);
+  });
+  typedef LdsOperandKC<TL::BM, TL::BK, decltype(la)> OpA;
+  typedef LdsOperandKC<TL::BN, TL::BK, decltype(lb)> OpB;
+  static_assert(OpA::ELEMS + OpB::ELEMS == kQPrepLdsElems, "LDS carve");
+  OpA oa(qsmem, la);
+  OpB ob(qsmem + OpA::ELEMS, lb);
+  WavePos<TL> w;
+  f32x16 acc[TL::TM][TL::TN];
+  tileb_zero<TL>(acc);
+  gemm_loop_kc<TL>(oa, ob, acc, 0, q.M, w);
+  tileb_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
+    const int tau = tau0 + mm, n = n0 + nn;
+    if (tau < q.rowsQ && n < q.ldQ) q.QT[(long)tau * q.ldQ + n] = (bf16_t)(n < q.Hd ? v : 0.f);
+  });
+}
+
 // ---------------------------------------------------------------------------
 // u = relu(x . w_u + b_u), x bf16, fp32 accumulate             src/lmu.py:300
 // ---------------------------------------------------------------------------
@@ -771,12 +807,6 @@ __global__ __launch_bounds__(kThreads) void k_relu_bwd_bf16(const bf16_t* __rest
 // H^T (hprep) and W_h (wprep) -- 30 MFLOP that would otherwise be a launch of their own.
 // ---------------------------------------------------------------------------
 constexpr int kGuQMaxT = 512;
-using QPrepTile = TileB<64, 64, 64, 2, 2>;
-struct QPrep {
-  const bf16_t *HbT, *Wb;
-  bf16_t* QT;
-  int rowsQ, rowsHT, Hd, M, ldHT, ldW, ldQ;
-};
 
 __global__ __launch_bounds__(kThreads) void k_relu_bwd_q_bf16(const bf16_t* __restrict__ h,
                                                               const unsigned char* __restrict__ hmask,
@@ -784,32 +814,9 @@ __global__ __launch_bounds__(kThreads) void k_relu_bwd_q_bf16(const bf16_t* __re
                                                               const bf16_t* __restrict__ gh_n,
                                                               bf16_t* __restrict__ gz, int rows, int T, int Hd, QPrep q,
                                                               int qblocks) {
-  __shared__ __attribute__((aligned(16))) bf16_t qsmem[2 * 64 * (64 + 8)];
+  __shared__ __attribute__((aligned(16))) bf16_t qsmem[kQPrepLdsElems];
   if ((int)blockIdx.x < qblocks) {
-    using TL = QPrepTile;
-    const int tiles_n = (q.Hd + TL::BN - 1) / TL::BN;
-    const int tau0 = ((int)blockIdx.x / tiles_n) * TL::BM, n0 = ((int)blockIdx.x % tiles_n) * TL::BN;
-    auto la = plain_load_b([=](int r, int k) -> bf16x8 {
-      const int tau = tau0 + r;
-      return bload8<true>(q.HbT, (long)tau * q.ldHT + k, k, q.ldHT, tau < q.rowsHT);
-    });
-    auto lb = plain_load_b([=](int r, int k) -> bf16x8 {
-      const int n = n0 + r;
-      return bload8<true>(q.Wb, (long)n * q.ldW + k, k, q.M, n < q.Hd);
-    });
-    typedef LdsOperandKC<TL::BM, TL::BK, decltype(la)> OpA;
-    typedef LdsOperandKC<TL::BN, TL::BK, decltype(lb)> OpB;
-    static_assert(OpA::ELEMS + OpB::ELEMS == 2 * 64 * (64 + 8), "LDS carve");
-    OpA oa(qsmem, la);
-    OpB ob(qsmem + OpA::ELEMS, lb);
-    WavePos<TL> w;
-    f32x16 acc[TL::TM][TL::TN];
-    tileb_zero<TL>(acc);
-    gemm_loop_kc<TL>(oa, ob, acc, 0, q.M, w);
-    tileb_epilogue<TL>(acc, w, [&](int mm, int nn, float v) {
-      const int tau = tau0 + mm, n = n0 + nn;
-      if (tau < q.rowsQ && n < q.ldQ) q.QT[(long)tau * q.ldQ + n] = (bf16_t)(n < q.Hd ? v : 0.f);
-    });
+    qprep_block(q, (int)blockIdx.x, qsmem);
     return;
   }
   const unsigned CH = (unsigned)Hd / 8;  // 16-byte chunks per row
@@ -1126,7 +1133,8 @@ __global__ __launch_bounds__(TL::THREADS) void k_dgrad_glds_bf16(const bf16_t* _
                                                                  const float* __restrict__ ga,
                                                                  const float* __restrict__ w_u, int rows_all, int Hd,
                                                                  int ldWT, int j_begin, int ncols, GaParts gp,
-                                                                 int rpw, int col_tiles) {
+                                                                 int rpw, int col_tiles,
+                                                                 const bf16_t* __restrict__ relu_src) {
   // A workgroup owns rpw <= BM rows (rpw is chosen so that the grid fills the chip: the tile's remaining rows
   // are computed on zeros and not stored) and one column tile; the column tiles of a row range are neighbours
   // on one XCD (1-D grid, xcd_slot), so that the rows they share come from HBM once.
@@ -1150,6 +1158,23 @@ __global__ __launch_bounds__(TL::THREADS) void k_dgrad_glds_bf16(const bf16_t* _
     for (int i = 0; i < kGaPer; ++i) {
       const int p = ga_grp + i * kGaGroups;
       ga_part[i] = load_or_zero(gp.part + (long)p * gp.stride + m0 + ga_row, p < gp.P && m0 + ga_row < rows);
+    }
+  }
+
+  // relu_src: out[row][j] is kept only where relu_src[row][j] > 0 (relu_src = the [rows_all][ncols] tensor whose ReLU
+  // backward is the next thing to happen to this gradient).  The 16-byte pieces of it that match the pieces of `out`
+  // this thread stores are fetched here, so that they arrive behind the GEMM loop.
+  constexpr int LDT = TL::BN + 8, CH = TL::BN / 8;
+  constexpr int PER = TL::BM * CH / TL::THREADS;
+  static_assert(TL::BM * CH % TL::THREADS == 0, "whole chunks per thread");
+  bf16x8 src[PER];
+  if (relu_src) {
+#pragma unroll
+    for (int n = 0; n < PER; ++n) {
+      const int idx = threadIdx.x + n * TL::THREADS;
+      const long row = m0 + idx / CH;
+      const int col = n0 + (idx % CH) * 8;
+      src[n] = (row < rows && col < ncols) ? *reinterpret_cast<const bf16x8*>(relu_src + row * ncols + col) : bzero8();
     }
   }
 
@@ -1204,8 +1229,26 @@ __global__ __launch_bounds__(TL::THREADS) void k_dgrad_glds_bf16(const bf16_t* _
     preload_rows<TL>(grow, w, [&](int mm) { return load_or_zero(ga + m0 + mm, ga && m0 + mm < rows); });
   }
   bf16_t* tile = reinterpret_cast<bf16_t*>(smem_raw);
-  store_tile_bf16<TL>(acc, w, tile, out, ncols, m0, n0, rows, ncols,
-                      [&](int tm, int tn, int i, int, int, float v) { return v + grow[tm][i] * wcol[tn]; });
+  auto value = [&](int tm, int tn, int i, int, int, float v) { return v + grow[tm][i] * wcol[tn]; };
+  if (!relu_src) {
+    store_tile_bf16<TL>(acc, w, tile, out, ncols, m0, n0, rows, ncols, value);
+    return;
+  }
+  // the tile goes to LDS as usual; the store pass applies the mask fetched at the start
+  store_tile_bf16<TL>(acc, w, tile, nullptr, 0, 0, 0, 0, 0, value);
+#pragma unroll
+  for (int n = 0; n < PER; ++n) {
+    const int idx = threadIdx.x + n * TL::THREADS;
+    const int mm = idx / CH, c = idx % CH;
+    const long row = m0 + mm;
+    const int col = n0 + c * 8;
+    if (row < rows && col < ncols) {
+      bf16x8 v = *reinterpret_cast<const bf16x8*>(&tile[mm * LDT + c * 8]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (float)src[n][j] > 0.f ? v[j] : (bf16_t)0.f;
+      *reinterpret_cast<bf16x8*>(out + row * ncols + col) = v;
+    }
+  }
 }
 
 using DgradMTileB = TileB<64, 192, 64, 2, 2>;    // memory columns (M = 192): one column tile
@@ -2497,8 +2540,10 @@ static int backward_bf16_parts(int parts, const lmufft_shape* s, const void* x_,
                                const void* h_, const void* hmask, const void* gh_, const void* gh_n_, void* gx_,
                                float* gw_u,
                                float* gb_u, float* gW_h, float* gb_h, void* gm_, int conv_algo, void* workspace,
-                               size_t workspace_bytes, void* stream) {
+                               size_t workspace_bytes, void* stream, unsigned flags = 0) {
   if (int rc = check_shape_b(s)) return rc;
+  if (flags & ~(unsigned)(LMUFFT_BWD_GH_MASKED | LMUFFT_BWD_MASK_GX)) return set_error("backward: unknown flags %u", flags);
+  if (flags && parts != 3 && parts != 7) return set_error("backward: flags need the whole backward in one call");
   if (!x_ || !m_) return set_error("backward: NULL pointer");
   if ((parts & 1) && (!w_u || !wprep || !hprep || !u || !h_)) return set_error("backward: NULL pointer");
   if ((parts & 2) && !(parts & 4) && (!gw_u || !gb_u || !gW_h || !gb_h)) return set_error("backward: NULL pointer");
@@ -2529,6 +2574,12 @@ static int backward_bf16_parts(int parts, const lmufft_shape* s, const void* x_,
   const HprepLayout hl = hprep_layout(s->M, s->ldH);
   const bf16_t* HbT = hprep ? (const bf16_t*)((const char*)hprep + hl.off_HbT) : nullptr;
   bf16_t* gz = (bf16_t*)(ws + p.off_gz);
+  const bool gh_masked = flags & LMUFFT_BWD_GH_MASKED;
+  if (gh_masked) {
+    // the caller vouches that gh is already zero wherever h <= 0: gh IS gz, the masking pass is not run
+    if (!gh || gh_n || !al16(gh)) return set_error("backward: LMUFFT_BWD_GH_MASKED needs a 16-byte aligned gh and no gh_n");
+    gz = const_cast<bf16_t*>(gh);
+  }
   const bool vec_h = (s->Hd % 8 == 0) && (s->Hd / 8 <= kThreads) && al16(h) && (!gh || al16(gh)) &&
                      (!gh_n || al16(gh_n));
   // gm == NULL selects the Q route: the encoder gradient straight from gz, gm is never formed
@@ -2542,16 +2593,15 @@ static int backward_bf16_parts(int parts, const lmufft_shape* s, const void* x_,
     const QPrep q{HbT, (const bf16_t*)((const char*)wprep + wl.off_Wb), (bf16_t*)(ws + p.off_q), p.q_rows, hl.ldHb,
                   s->Hd, s->M, hl.ldHT, wl.ldW, p.q_ld};
     const int qblocks = (p.q_rows / QPrepTile::BM) * cdivb(s->Hd, QPrepTile::BN);
-    const long work = rows * (s->Hd / 8);
+    const long work = gh_masked ? 0 : rows * (s->Hd / 8);  // (gh already masked: only Q^T is made)
     const dim3 grid(qblocks + (int)std::min<long>((work + kThreads - 1) / kThreads, 8192));
     {
       PROFB("k_relu_bwd_bf16");
       hipLaunchKernelGGL(k_relu_bwd_q_bf16, grid, dim3(kThreads), 0, st, h, (const unsigned char*)hmask, gh, gh_n, gz,
-                         (int)rows, s->T, s->Hd, q,
-                         qblocks);
+                         gh_masked ? 0 : (int)rows, s->T, s->Hd, q, qblocks);
     }
     LAUNCH_CHECKB("k_relu_bwd_q_bf16");
-  } else {  // gz = relu'(h) * (gh + gh_n)
+  } else if (!gh_masked) {  // gz = relu'(h) * (gh + gh_n)
     const long work = vec_h ? rows * (s->Hd / 8) : rows * s->Hd;
     const dim3 grid(std::min<long>((work + kThreads - 1) / kThreads, 8192));
     {
@@ -2567,10 +2617,13 @@ static int backward_bf16_parts(int parts, const lmufft_shape* s, const void* x_,
 
   // out = gz W_h[:, j_begin : j_begin + ncols] (+ ga w_u), LDS-DMA kernel when everything is 16-byte friendly
   auto dgrad = [&](auto glds_tag, auto fallback_tag, const char* name, bf16_t* out, int j_begin, int ncols,
-                   const float* ga_, const float* wu_, GaParts gparts) -> int {
+                   const float* ga_, const float* wu_, GaParts gparts, const bf16_t* relu_src = nullptr) -> int {
     using TG = decltype(glds_tag);
     using TF = decltype(fallback_tag);
     const bool fast = (s->Hd % 8 == 0) && (ncols % 8 == 0) && al16(out);
+    if (relu_src && !(fast && al16(relu_src)))
+      return set_error("backward: LMUFFT_BWD_MASK_GX needs hidden and input sizes that are multiples of 8 and 16-byte "
+                       "aligned x / gx");
     if (fast) {
       // rows per workgroup: the whole tile when that already gives a workgroup per CU, otherwise the row
       // ranges are shortened until the grid fills the chip (batch 64 x 400 frames: 200 rows, 256 workgroups)
@@ -2586,7 +2639,7 @@ static int backward_bf16_parts(int parts, const lmufft_shape* s, const void* x_,
         return set_error("cannot reserve %zu bytes of LDS for k_dgrad_glds_bf16", lds);
       PROFB(name);
       hipLaunchKernelGGL(k_dgrad_glds_bf16<TG>, grid, dim3(TG::THREADS), lds, st, (const bf16_t*)gz, WbT, out, ga_,
-                         wu_, (int)rows, s->Hd, wl.ldWT, j_begin, ncols, gparts, rpw, col_tiles);
+                         wu_, (int)rows, s->Hd, wl.ldWT, j_begin, ncols, gparts, rpw, col_tiles, relu_src);
     } else {
       const dim3 grid(cdivb(ncols, TF::BN), cdivb(rows, TF::BM));
       const size_t lds = sizeof(bf16_t) * (size_t)(TF::BM + TF::BN) * (TF::BK + 8);
@@ -2631,8 +2684,11 @@ static int backward_bf16_parts(int parts, const lmufft_shape* s, const void* x_,
   }
   // gx = gz W_h[:, M:] + ga w_u
   if (gx) {
-    if (int rc = dgrad(DgradXGldsTile{}, DgradXTileB{}, "k_dgrad_x_bf16", gx, s->M, s->D, (const float*)ga, w_u, ga_parts))
+    if (int rc = dgrad(DgradXGldsTile{}, DgradXTileB{}, "k_dgrad_x_bf16", gx, s->M, s->D, (const float*)ga, w_u, ga_parts,
+                       (flags & LMUFFT_BWD_MASK_GX) ? x : nullptr))
       return rc;
+  } else if (flags & LMUFFT_BWD_MASK_GX) {
+    return set_error("backward: LMUFFT_BWD_MASK_GX without gx");
   } else if (ga_parts.part) {  // no input gradient wanted: nobody has summed the adjoint's slabs into ga yet
     if (int rc = launch_sum_slabs_masked(ga_parts.part, u, ga, rows, ga_parts.P, st)) return rc;
   }
@@ -2692,6 +2748,18 @@ int lmufft_backward_partial_bf16(const lmufft_shape* s, const void* x, const flo
                                  void* workspace, size_t workspace_bytes, void* stream) {
   return backward_bf16_parts(3 | 4, s, x, w_u, wprep, hprep, scanprep, u, m, h, hmask, gh, gh_n, gx, nullptr, nullptr,
                              nullptr, nullptr, gm, conv_algo, workspace, workspace_bytes, stream);
+}
+
+int lmufft_backward_flags_bf16(const lmufft_shape* s, const void* x, const float* w_u, const void* wprep,
+                               const void* hprep, const void* scanprep, const float* u, const void* m, const void* h,
+                               const void* hmask, const void* gh, const void* gh_n, void* gx, float* gw_u, float* gb_u,
+                               float* gW_h, float* gb_h, void* gm, int conv_algo, void* workspace,
+                               size_t workspace_bytes, void* stream, uint32_t flags) {
+  const uint32_t known = LMUFFT_BWD_GH_MASKED | LMUFFT_BWD_MASK_GX | LMUFFT_BWD_PARTIAL_SUMS;
+  if (flags & ~known) return set_error("backward: unknown flags %u", flags);
+  return backward_bf16_parts((flags & LMUFFT_BWD_PARTIAL_SUMS) ? 7 : 3, s, x, w_u, wprep, hprep, scanprep, u, m, h, hmask,
+                             gh, gh_n, gx, gw_u, gb_u, gW_h, gb_h, gm, conv_algo, workspace, workspace_bytes, stream,
+                             flags & ~(uint32_t)LMUFFT_BWD_PARTIAL_SUMS);
 }
 
 int lmufft_backward_weights_sum_many_bf16(const lmufft_lmu_sum_item* items, int32_t count, void* stream) {

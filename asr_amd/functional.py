@@ -201,7 +201,7 @@ class _LMUFFTFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_u, b_u, W_h, b_h, H, conv_algo, hprep, fftprep, grad_sink, scanprep=None,
-                async_wgrad=False):
+                async_wgrad=False, relu_input=False, grad_masked=False):
         _require_gpu(x, "x")
         if x.dtype not in _DTYPES:
             raise RuntimeError(f"LMUFFT: x has dtype {x.dtype}; supported: float32, bfloat16")
@@ -267,6 +267,8 @@ class _LMUFFTFunction(torch.autograd.Function):
                               fftprep if dt == torch.float32 else None, scanprep if dt != torch.float32 else None, hmask)
         ctx.conv_algo = conv_algo
         ctx.async_wgrad = bool(async_wgrad)
+        ctx.relu_input = bool(relu_input)
+        ctx.grad_masked = bool(grad_masked)
         ctx.grad_sink = grad_sink
         ctx.shape = (B, T, D, M, Hd, ldH)
         ctx.set_materialize_grads(False)
@@ -280,7 +282,7 @@ class _LMUFFTFunction(torch.autograd.Function):
         dt = x.dtype
         need_x = ctx.needs_input_grad[0]
         if gh is None and gh_n is None:
-            return (None,) * 12
+            return (None,) * 14
         if gh is not None:
             gh = gh.to(dt).contiguous()
         if gh_n is not None:
@@ -317,7 +319,7 @@ class _LMUFFTFunction(torch.autograd.Function):
                     _ptr(h), _ptr(gh), _ptr(gh_n), _ptr(gx), _ptr(gw_u), _ptr(gb_u), _ptr(gW_h), _ptr(gb_h),
                     _ptr(gm), ctx.conv_algo, _ptr(ws), ws.numel(), _stream(dev))
                 what = "lmufft_backward_f32"
-            elif ctx.async_wgrad and direct:
+            elif ctx.async_wgrad and direct and not (ctx.relu_input and need_x):
                 # The parameter gradients depend on nothing after gx and nothing below this layer depends on
                 # them: they run on a side stream, beside the backward of the layers below, and are joined by
                 # whoever consumes the gradient bucket (join_async_weight_grads).  Only with a gradient sink:
@@ -338,32 +340,37 @@ class _LMUFFTFunction(torch.autograd.Function):
                 key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
                 _ASYNC_WGRAD.setdefault(key, []).append((done, (x, m, ws, gw_u, gb_u, gW_h, gb_h)))
                 what = "lmufft_backward_weights_bf16"
-            elif DEFER_WEIGHT_SUMS and direct:
-                rc = _lib.lib.lmufft_backward_partial_bf16(
-                    ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(wprep), _ptr(hprep), _ptr(scanprep), _ptr(u), _ptr(m),
-                    _ptr(h), _ptr(hmask), _ptr(gh), _ptr(gh_n), _ptr(gx), _ptr(gm), ctx.conv_algo, _ptr(ws), ws.numel(),
-                    _stream(dev))
-                what = "lmufft_backward_partial_bf16"
-                _PENDING_WEIGHT_SUMS.append((dev, _lib.LmuSumItem(shp, gw_u.data_ptr(), gb_u.data_ptr(), gW_h.data_ptr(),
-                                                                  gb_h.data_ptr(), ws.data_ptr(), ws.numel()),
-                                             (ws, gw_u, gb_u, gW_h, gb_h)))
             else:
-                rc = _lib.lib.lmufft_backward_bf16(
+                flags = 0
+                if ctx.relu_input and need_x:
+                    # x is a ReLU's output and that ReLU's backward comes next: gx leaves already multiplied by (x > 0).
+                    # The layer below may rely on it (grad_masked), so this is never skipped silently: shapes the
+                    # kernel does not take are an error of the C call.
+                    flags |= _lib.BWD_MASK_GX
+                if ctx.grad_masked and gh is not None and gh_n is None and gh.data_ptr() % 16 == 0:
+                    # gh is zero wherever h <= 0 already (the layer above ran with relu_input on this h): it is
+                    # used as the masked gradient as it is.  Otherwise the masking pass runs, which is always right.
+                    flags |= _lib.BWD_GH_MASKED
+                if DEFER_WEIGHT_SUMS and direct:
+                    flags |= _lib.BWD_PARTIAL_SUMS
+                    _PENDING_WEIGHT_SUMS.append((dev, _lib.LmuSumItem(shp, gw_u.data_ptr(), gb_u.data_ptr(),
+                                                                      gW_h.data_ptr(), gb_h.data_ptr(), ws.data_ptr(),
+                                                                      ws.numel()), (ws, gw_u, gb_u, gW_h, gb_h)))
+                rc = _lib.lib.lmufft_backward_flags_bf16(
                     ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(wprep), _ptr(hprep), _ptr(scanprep), _ptr(u), _ptr(m),
                     _ptr(h), _ptr(hmask), _ptr(gh), _ptr(gh_n), _ptr(gx), _ptr(gw_u), _ptr(gb_u), _ptr(gW_h), _ptr(gb_h),
-                    _ptr(gm), ctx.conv_algo, _ptr(ws), ws.numel(), _stream(dev))
-                what = "lmufft_backward_bf16"
+                    _ptr(gm), ctx.conv_algo, _ptr(ws), ws.numel(), _stream(dev), flags)
+                what = "lmufft_backward_flags_bf16"
         _lib.check(rc, what)
         if direct:
             sink.commit()
-            return (gx,) + (None,) * 11
+            return (gx,) + (None,) * 13
         pd = ctx.param_dtypes
-        return (gx, gw_u.to(pd[0]), gb_u.to(pd[1]), gW_h.to(pd[2]), gb_h.to(pd[3]), None, None, None, None, None, None,
-                None)
+        return (gx, gw_u.to(pd[0]), gb_u.to(pd[1]), gW_h.to(pd[2]), gb_h.to(pd[3])) + (None,) * 9
 
 
 def lmufft_layer(x, w_u, b_u, W_h, b_h, H, conv_algo="auto", hprep=None, fftprep=None, grad_sink=None,
-                 scanprep=None, async_weight_grad=False):
+                 scanprep=None, async_weight_grad=False, relu_input=False, grad_masked=False):
     """h, h_n = LMUFFT forward with autograd support (HIP kernels only).
 
     x float32 -> exact-fp32 kernels; x bfloat16 -> bf16 kernels with fp32
@@ -375,9 +382,13 @@ def lmufft_layer(x, w_u, b_u, W_h, b_h, H, conv_algo="auto", hprep=None, fftprep
     (conv_algo "auto" or "scan"; required for "scan").
     `async_weight_grad` (bf16 path, with a grad_sink only): the parameter gradients are launched on a side stream
     and joined by the sink's owner (join_async_weight_grads).
+    `relu_input`, `grad_masked` (bf16 path; set in pairs, see asr_amd.lmu.fuse_relu_backward): `relu_input` -- x is
+    the output of a ReLU whose backward is the next thing to happen to x's gradient, so that gradient is returned
+    already multiplied by (x > 0); `grad_masked` -- the gradient of h arrives already zero wherever h <= 0, the
+    layer's own masking pass is skipped.
     """
     return _LMUFFTFunction.apply(x, w_u, b_u, W_h, b_h, H, _ALGOS[conv_algo], hprep, fftprep, grad_sink, scanprep,
-                                 async_weight_grad)
+                                 async_weight_grad, relu_input, grad_masked)
 
 
 def lmufft_layer_norm_inference(x, w_u, b_u, W_h, b_h, H, ln_weight, ln_bias, eps=1e-5, out_dtype=torch.float32,

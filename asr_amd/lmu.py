@@ -16,7 +16,7 @@ from torch import nn
 from .functional import (fft_supported, lmufft_layer, prepare_impulse_bf16, prepare_impulse_fft, prepare_scan_bf16,
                          scan_supported)
 
-__all__ = ["LMUFFT", "LMU", "legendre_state_space", "impulse_response"]
+__all__ = ["LMUFFT", "LMU", "legendre_state_space", "impulse_response", "fuse_relu_backward"]
 
 
 def legendre_state_space(memory_size: int, theta: float):
@@ -115,6 +115,9 @@ class LMUFFT(nn.Module):
         # bf16 path, with a grad_sink: run the parameter gradients on a side stream, beside the backward of the
         # layers below (GradBuckets joins them before it exchanges or hands out gradients)
         self.async_weight_grad = False
+        # set in pairs by fuse_relu_backward(lower, upper) for two directly stacked layers (bf16 path)
+        self.input_is_relu_output = False  # the input gradient is returned already multiplied by (x > 0)
+        self.grad_is_masked = False        # the gradient of h arrives already zero wherever h <= 0
 
     _FFTPREP_MAX = 8  # cached FFT-route spectra (one per distinct sequence length)
 
@@ -191,7 +194,8 @@ class LMUFFT(nn.Module):
         return lmufft_layer(x, self.W_u.weight, self.W_u.bias, self.W_h.weight, self.W_h.bias, self.H,
                             conv_algo=self.conv_algo, hprep=hprep, fftprep=fftprep,
                             grad_sink=self.grad_sink, scanprep=scanprep,
-                            async_weight_grad=self.async_weight_grad)
+                            async_weight_grad=self.async_weight_grad,
+                            relu_input=self.input_is_relu_output, grad_masked=self.grad_is_masked)
 
 
     # hidden sizes whose rows fit one projection tile: the layer norm can ride on the projection kernel
@@ -214,6 +218,27 @@ class LMUFFT(nn.Module):
         return lmufft_layer_norm_inference(x.to(torch.bfloat16), self.W_u.weight, self.W_u.bias, self.W_h.weight,
                                            self.W_h.bias, self.H, layer_norm.weight, layer_norm.bias, layer_norm.eps,
                                            out_dtype, hprep=self._impulse_bf16())
+
+
+def fuse_relu_backward(lower: "LMUFFT", upper: "LMUFFT", enable: bool = True) -> None:
+    """For two DIRECTLY stacked layers -- `upper(lower(x)[0])` with nothing in between and no other consumer of
+    `lower`'s h -- fold the ReLU backward of `lower`'s output (autograd of src/lmu.py:318) into `upper`'s
+    input-gradient kernel.
+
+    `upper` then returns its input gradient already multiplied by (x > 0), and `lower` takes the gradient of h as the
+    masked gradient without a pass of its own (one kernel and ~20 MB of HBM traffic less per fused pair at batch
+    64 x 400 frames).  bf16 path only; on the fp32 path both layers ignore the setting.  The parameter gradients and
+    the gradient that leaves `lower` are the same numbers either way; the tensor that travels between the two layers
+    is no longer the plain gradient of h, so do not read it (`retain_grad`, hooks) while the fusion is on.  `lower`
+    falls back to its own masking pass whenever the gradient of its last-frame output h_n is in use."""
+    if not isinstance(lower, LMUFFT) or not isinstance(upper, LMUFFT):
+        raise TypeError("fuse_relu_backward: both layers must be asr_amd.LMUFFT modules")
+    d_in = upper.W_u.in_features
+    if enable and (d_in != lower.hidden_size or d_in % 8 or upper.hidden_size % 8):
+        raise ValueError(f"fuse_relu_backward: the upper layer's input size ({d_in}) must equal the lower layer's hidden "
+                         f"size ({lower.hidden_size}), and it and the upper hidden size must be multiples of 8")
+    upper.input_is_relu_output = bool(enable)
+    lower.grad_is_masked = bool(enable)
 
 
 class LMU(nn.Module):

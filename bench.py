@@ -79,6 +79,10 @@ def parse_args():
                          "step's graph")
     ap.add_argument("--async-wgrad", action="store_true",
                     help="run every layer's parameter gradients on a side stream, beside the backward of the layers below")
+    ap.add_argument("--no-fuse-relu-bwd", action="store_true",
+                    help="layer workload, bf16: run the ReLU backward between two stacked layers as the lower layer's "
+                         "own pass instead of folding it into the upper layer's input-gradient kernel "
+                         "(asr_amd.lmu.fuse_relu_backward; the gradients are bit-identical either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="one rank: skip the batch sweep (256 and 1024 utterances) and the whole-model sub-object that "
@@ -566,6 +570,12 @@ def bench_layer_stack(args, dev, rank, world, batch, steps, warmup, detail=True)
         torch.nn.init.zeros_(l.W_h.bias)
         l.async_weight_grad = bool(args.async_wgrad)
         layers.append(l.to(dev))
+    fuse_relu = args.dtype == "bf16" and not args.no_fuse_relu_bwd and D % 8 == 0 and Hd % 8 == 0 and args.layers > 1
+    if fuse_relu:
+        from asr_amd.lmu import fuse_relu_backward
+
+        for lo, up in zip(layers[:-1], layers[1:]):
+            fuse_relu_backward(lo, up)
     overlap = args.overlap and not args.no_overlap
     buckets = GradBuckets(list(reversed(layers)), bucket_mb=args.bucket_mb, overlap=overlap,
                           exchange_single_rank=args.exchange_single_rank)
@@ -747,6 +757,8 @@ def bench_layer_stack(args, dev, rank, world, batch, steps, warmup, detail=True)
                 "gradient_buckets": len(buckets.buckets),
                 "bucket_mb": [round(b.numel() * 4 / (1 << 20), 3) for b in buckets.buckets],
                 "exchange": "per bucket, behind the remaining backward segments" if overlap else "one all-reduce after the backward",
+                "relu_backward_between_layers": ("folded into the upper layer's input-gradient kernel (bit-identical "
+                                                 "gradients)") if fuse_relu else "the lower layer's own pass",
                 "launch": "eager" if args.no_graph else (launch_mode or f"hip graph replay ({len(segments)} segments)"),
                 # wall clock of the timed steps on the fastest and the slowest rank (barriers on both sides)
                 "rank_ms_per_step_min_max": rank_ms,

@@ -379,3 +379,84 @@ def test_deferred_weight_sums_match_the_immediate_ones(monkeypatch):
         grads[defer] = [p.grad.clone() for l in layers for p in l.parameters()]
     for g0, g1 in zip(grads[False], grads[True]):
         assert torch.equal(g0, g1)
+
+
+@pytest.mark.parametrize("chained", [False, True])
+def test_fused_relu_backward_between_stacked_layers(chained):
+    """fuse_relu_backward(lower, upper): the upper layer masks its input gradient by (x > 0) and the lower layer skips
+    its own masking pass -- every parameter gradient and the gradient of the stack's input are bit-identical to the
+    unfused stack's.  `chained`: the layers joined through detached copies and one backward call per layer (the way
+    the benchmark overlaps the exchange), else one autograd graph."""
+    import copy
+
+    from asr_amd import LMUFFT
+    from asr_amd.lmu import fuse_relu_backward
+
+    dev = _dev()
+    torch.manual_seed(13)
+    sizes = [(48, 64), (64, 64), (64, 32)]
+    ref = [LMUFFT(d, hd, 24, 96, 16).to(dev) for d, hd in sizes]
+    x0 = torch.randn(5, 96, 48, device=dev).to(torch.bfloat16)
+    gy = torch.randn(5, 96, 32, device=dev).to(torch.bfloat16)
+    results = {}
+    for fused in (False, True):
+        layers = copy.deepcopy(ref)
+        if fused:
+            for lo, up in zip(layers[:-1], layers[1:]):
+                fuse_relu_backward(lo, up)
+        x = x0.clone().requires_grad_(True)
+        if chained:
+            ins, outs, y = [], [], x
+            for i, l in enumerate(layers):
+                xin = y if i == 0 else y.detach().requires_grad_(True)
+                y, _ = l(xin)
+                ins.append(xin)
+                outs.append(y)
+            outs[-1].backward(gy)
+            for k in range(len(layers) - 2, -1, -1):
+                outs[k].backward(ins[k + 1].grad)
+        else:
+            y = x
+            for l in layers:
+                y, _ = l(y)
+            y.backward(gy)
+        results[fused] = [x.grad.clone()] + [p.grad.clone() for l in layers for p in l.parameters()]
+    assert any(float(g.abs().max()) > 0 for g in results[True])
+    for g0, g1 in zip(results[False], results[True]):
+        assert torch.equal(g0, g1)
+
+
+def test_fused_relu_backward_falls_back_when_h_n_carries_gradient():
+    """The lower layer of a fused pair runs its own masking pass when the gradient of its h_n is in use."""
+    import copy
+
+    from asr_amd import LMUFFT
+    from asr_amd.lmu import fuse_relu_backward
+
+    dev = _dev()
+    torch.manual_seed(17)
+    ref = [LMUFFT(48, 64, 24, 64, 16).to(dev), LMUFFT(64, 32, 24, 64, 16).to(dev)]
+    x0 = torch.randn(3, 64, 48, device=dev).to(torch.bfloat16)
+    results = {}
+    for fused in (False, True):
+        layers = copy.deepcopy(ref)
+        if fused:
+            fuse_relu_backward(layers[0], layers[1])
+        x = x0.clone().requires_grad_(True)
+        h, h_n = layers[0](x)
+        y, _ = layers[1](h)
+        (y.float().sum() + 3.0 * h_n.float().sum()).backward()
+        results[fused] = [x.grad.clone()] + [p.grad.clone() for l in layers for p in l.parameters()]
+    for g0, g1 in zip(results[False], results[True]):
+        assert torch.equal(g0, g1)
+
+
+def test_fuse_relu_backward_checks_its_layers():
+    from asr_amd import LMUFFT
+    from asr_amd.lmu import fuse_relu_backward
+
+    a, b = LMUFFT(48, 64, 24, 64, 16), LMUFFT(40, 32, 24, 64, 16)
+    with pytest.raises(ValueError):
+        fuse_relu_backward(a, b)
+    with pytest.raises(TypeError):
+        fuse_relu_backward(a, torch.nn.Linear(4, 4))
