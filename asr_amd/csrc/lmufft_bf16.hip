@@ -119,8 +119,12 @@ struct QPrep {
   int rowsQ, rowsHT, Hd, M, ldHT, ldW, ldQ;
 };
 constexpr int kQPrepLdsElems = 2 * 64 * (64 + 8);
+// the same tile with the whole memory dimension (up to 192) as ONE k-tile: a launch of its own, where the three
+// dependent trips to memory of the 64-deep form would be the launch's length
+using QPrepWideTile = TileB<64, 64, 192, 2, 2>;
+constexpr int kQPrepWideLdsElems = 2 * 64 * (192 + 8);
+template <class TL>
 __device__ __forceinline__ void qprep_block(const QPrep& q, int block, bf16_t* qsmem) {
-  using TL = QPrepTile;
   const int tiles_n = (q.Hd + TL::BN - 1) / TL::BN;
   const int tau0 = (block / tiles_n) * TL::BM, n0 = (block % tiles_n) * TL::BN;
   auto la = plain_load_b([=](int r, int k) -> bf16x8 {
@@ -133,7 +137,7 @@ __device__ __forceinline__ void qprep_block(const QPrep& q, int block, bf16_t* q
   });
   typedef LdsOperandKC<TL::BM, TL::BK, decltype(la)> OpA;
   typedef LdsOperandKC<TL::BN, TL::BK, decltype(lb)> OpB;
-  static_assert(OpA::ELEMS + OpB::ELEMS == kQPrepLdsElems, "LDS carve");
+  static_assert(OpA::ELEMS + OpB::ELEMS == 2 * 64 * (TL::BK + 8), "LDS carve");
   OpA oa(qsmem, la);
   OpB ob(qsmem + OpA::ELEMS, lb);
   WavePos<TL> w;
@@ -816,7 +820,7 @@ __global__ __launch_bounds__(kThreads) void k_relu_bwd_q_bf16(const bf16_t* __re
                                                               int qblocks) {
   __shared__ __attribute__((aligned(16))) bf16_t qsmem[kQPrepLdsElems];
   if ((int)blockIdx.x < qblocks) {
-    qprep_block(q, (int)blockIdx.x, qsmem);
+    qprep_block<QPrepTile>(q, (int)blockIdx.x, qsmem);
     return;
   }
   const unsigned CH = (unsigned)Hd / 8;  // 16-byte chunks per row
@@ -847,6 +851,12 @@ __global__ __launch_bounds__(kThreads) void k_relu_bwd_q_bf16(const bf16_t* __re
     for (int j = 0; j < 8; ++j) g[j] = ((keep >> j) & 1u) ? g[j] : (bf16_t)0.f;
     *reinterpret_cast<bf16x8*>(gz + off) = g;
   }
+}
+
+// Q^T alone (the upstream gradient arrives masked, see LMUFFT_BWD_GH_MASKED): one workgroup per 64 x 64 tile
+__global__ __launch_bounds__(kThreads) void k_qprep_bf16(QPrep q) {
+  __shared__ __attribute__((aligned(16))) bf16_t qsmem[kQPrepWideLdsElems];
+  qprep_block<QPrepWideTile>(q, (int)blockIdx.x, qsmem);
 }
 
 // k_gu_q_bf16: workgroup = (utterance b, tile of 128 frames t -- right-aligned, so that the short tile is the
@@ -2593,12 +2603,15 @@ static int backward_bf16_parts(int parts, const lmufft_shape* s, const void* x_,
     const QPrep q{HbT, (const bf16_t*)((const char*)wprep + wl.off_Wb), (bf16_t*)(ws + p.off_q), p.q_rows, hl.ldHb,
                   s->Hd, s->M, hl.ldHT, wl.ldW, p.q_ld};
     const int qblocks = (p.q_rows / QPrepTile::BM) * cdivb(s->Hd, QPrepTile::BN);
-    const long work = gh_masked ? 0 : rows * (s->Hd / 8);  // (gh already masked: only Q^T is made)
+    const long work = rows * (s->Hd / 8);
     const dim3 grid(qblocks + (int)std::min<long>((work + kThreads - 1) / kThreads, 8192));
     {
       PROFB("k_relu_bwd_bf16");
-      hipLaunchKernelGGL(k_relu_bwd_q_bf16, grid, dim3(kThreads), 0, st, h, (const unsigned char*)hmask, gh, gh_n, gz,
-                         gh_masked ? 0 : (int)rows, s->T, s->Hd, q, qblocks);
+      if (gh_masked)  // only Q^T is made
+        hipLaunchKernelGGL(k_qprep_bf16, dim3(qblocks), dim3(kThreads), 0, st, q);
+      else
+        hipLaunchKernelGGL(k_relu_bwd_q_bf16, grid, dim3(kThreads), 0, st, h, (const unsigned char*)hmask, gh, gh_n, gz,
+                           (int)rows, s->T, s->Hd, q, qblocks);
     }
     LAUNCH_CHECKB("k_relu_bwd_q_bf16");
   } else if (!gh_masked) {  // gz = relu'(h) * (gh + gh_n)

@@ -306,6 +306,7 @@ class _LMUFFTFunction(torch.autograd.Function):
             gW_h = torch.empty_like(W_h)
             gb_h = torch.empty((Hd,), dtype=torch.float32, device=dev)
         shp = _shape(B, T, D, M, Hd, ldH)
+        pending = None
         # the bf16 backward forms the memory gradient only on the routes that need it (long sequences, odd sizes)
         gm = None
         if dt == torch.float32 or FORCE_MEMORY_GRADIENT or _lib.lib.lmufft_backward_needs_gm_bf16(
@@ -353,15 +354,17 @@ class _LMUFFTFunction(torch.autograd.Function):
                     flags |= _lib.BWD_GH_MASKED
                 if DEFER_WEIGHT_SUMS and direct:
                     flags |= _lib.BWD_PARTIAL_SUMS
-                    _PENDING_WEIGHT_SUMS.append((dev, _lib.LmuSumItem(shp, gw_u.data_ptr(), gb_u.data_ptr(),
-                                                                      gW_h.data_ptr(), gb_h.data_ptr(), ws.data_ptr(),
-                                                                      ws.numel()), (ws, gw_u, gb_u, gW_h, gb_h)))
+                    pending = (dev, _lib.LmuSumItem(shp, gw_u.data_ptr(), gb_u.data_ptr(), gW_h.data_ptr(),
+                                                    gb_h.data_ptr(), ws.data_ptr(), ws.numel()),
+                               (ws, gw_u, gb_u, gW_h, gb_h))
                 rc = _lib.lib.lmufft_backward_flags_bf16(
                     ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(wprep), _ptr(hprep), _ptr(scanprep), _ptr(u), _ptr(m),
                     _ptr(h), _ptr(hmask), _ptr(gh), _ptr(gh_n), _ptr(gx), _ptr(gw_u), _ptr(gb_u), _ptr(gW_h), _ptr(gb_h),
                     _ptr(gm), ctx.conv_algo, _ptr(ws), ws.numel(), _stream(dev), flags)
                 what = "lmufft_backward_flags_bf16"
         _lib.check(rc, what)
+        if pending is not None:
+            _PENDING_WEIGHT_SUMS.append(pending)  # (before commit(): the bucket's owner may ask for the sums there)
         if direct:
             sink.commit()
             return (gx,) + (None,) * 13
