@@ -20,7 +20,7 @@ CONV_TOEPLITZ = 1
 CONV_FFT = 2
 CONV_SCAN = 3
 NOALLOC_SCRATCH_BYTES = 8 << 20
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 
 class Shape(ctypes.Structure):
@@ -191,7 +191,7 @@ def _load():
     lib.lmufft_backward_data_bf16.restype = ci
     lib.lmufft_backward_data_bf16.argtypes = [sp] + [vp] * 13 + [ci, vp, sz, vp]
     lib.lmufft_backward_flags_bf16.restype = ci
-    lib.lmufft_backward_flags_bf16.argtypes = [sp] + [vp] * 17 + [ci, vp, sz, vp, ctypes.c_uint32]
+    lib.lmufft_backward_flags_bf16.argtypes = [sp] + [vp] * 17 + [ci, vp, sz, vp, ctypes.c_uint32, vp]
     lib.lmufft_backward_partial_bf16.restype = ci
     lib.lmufft_backward_partial_bf16.argtypes = [sp] + [vp] * 13 + [ci, vp, sz, vp]
     lib.lmufft_backward_weights_sum_many_bf16.restype = ci

@@ -1144,7 +1144,8 @@ __global__ __launch_bounds__(TL::THREADS) void k_dgrad_glds_bf16(const bf16_t* _
                                                                  const float* __restrict__ w_u, int rows_all, int Hd,
                                                                  int ldWT, int j_begin, int ncols, GaParts gp,
                                                                  int rpw, int col_tiles,
-                                                                 const bf16_t* __restrict__ relu_src) {
+                                                                 const bf16_t* __restrict__ relu_src,
+                                                                 const unsigned char* __restrict__ relu_bits) {
   // A workgroup owns rpw <= BM rows (rpw is chosen so that the grid fills the chip: the tile's remaining rows
   // are computed on zeros and not stored) and one column tile; the column tiles of a row range are neighbours
   // on one XCD (1-D grid, xcd_slot), so that the rows they share come from HBM once.
@@ -1171,14 +1172,24 @@ __global__ __launch_bounds__(TL::THREADS) void k_dgrad_glds_bf16(const bf16_t* _
     }
   }
 
-  // relu_src: out[row][j] is kept only where relu_src[row][j] > 0 (relu_src = the [rows_all][ncols] tensor whose ReLU
-  // backward is the next thing to happen to this gradient).  The 16-byte pieces of it that match the pieces of `out`
-  // this thread stores are fetched here, so that they arrive behind the GEMM loop.
+  // relu_src / relu_bits: out[row][j] is kept only where relu_src[row][j] > 0 (relu_src = the [rows_all][ncols]
+  // tensor whose ReLU backward is the next thing to happen to this gradient; relu_bits, if given, holds that
+  // comparison already: bit j of byte [row][c] for column 8 c + j).  What matches the 16-byte pieces of `out` this
+  // thread stores is fetched here, so that it arrives behind the GEMM loop.
   constexpr int LDT = TL::BN + 8, CH = TL::BN / 8;
   constexpr int PER = TL::BM * CH / TL::THREADS;
   static_assert(TL::BM * CH % TL::THREADS == 0, "whole chunks per thread");
   bf16x8 src[PER];
-  if (relu_src) {
+  unsigned keep[PER];
+  if (relu_bits) {
+#pragma unroll
+    for (int n = 0; n < PER; ++n) {
+      const int idx = threadIdx.x + n * TL::THREADS;
+      const long row = m0 + idx / CH;
+      const int col = n0 + (idx % CH) * 8;
+      keep[n] = (row < rows && col < ncols) ? relu_bits[row * (ncols / 8) + col / 8] : 0u;
+    }
+  } else if (relu_src) {
 #pragma unroll
     for (int n = 0; n < PER; ++n) {
       const int idx = threadIdx.x + n * TL::THREADS;
@@ -1240,9 +1251,17 @@ __global__ __launch_bounds__(TL::THREADS) void k_dgrad_glds_bf16(const bf16_t* _
   }
   bf16_t* tile = reinterpret_cast<bf16_t*>(smem_raw);
   auto value = [&](int tm, int tn, int i, int, int, float v) { return v + grow[tm][i] * wcol[tn]; };
-  if (!relu_src) {
+  if (!relu_src && !relu_bits) {
     store_tile_bf16<TL>(acc, w, tile, out, ncols, m0, n0, rows, ncols, value);
     return;
+  }
+  if (!relu_bits) {
+#pragma unroll
+    for (int n = 0; n < PER; ++n) {
+      keep[n] = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) keep[n] |= ((float)src[n][j] > 0.f ? 1u : 0u) << j;
+    }
   }
   // the tile goes to LDS as usual; the store pass applies the mask fetched at the start
   store_tile_bf16<TL>(acc, w, tile, nullptr, 0, 0, 0, 0, 0, value);
@@ -1255,7 +1274,7 @@ __global__ __launch_bounds__(TL::THREADS) void k_dgrad_glds_bf16(const bf16_t* _
     if (row < rows && col < ncols) {
       bf16x8 v = *reinterpret_cast<const bf16x8*>(&tile[mm * LDT + c * 8]);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (float)src[n][j] > 0.f ? v[j] : (bf16_t)0.f;
+      for (int j = 0; j < 8; ++j) v[j] = ((keep[n] >> j) & 1u) ? v[j] : (bf16_t)0.f;
       *reinterpret_cast<bf16x8*>(out + row * ncols + col) = v;
     }
   }
@@ -2550,7 +2569,8 @@ static int backward_bf16_parts(int parts, const lmufft_shape* s, const void* x_,
                                const void* h_, const void* hmask, const void* gh_, const void* gh_n_, void* gx_,
                                float* gw_u,
                                float* gb_u, float* gW_h, float* gb_h, void* gm_, int conv_algo, void* workspace,
-                               size_t workspace_bytes, void* stream, unsigned flags = 0) {
+                               size_t workspace_bytes, void* stream, unsigned flags = 0,
+                               const void* x_mask = nullptr) {
   if (int rc = check_shape_b(s)) return rc;
   if (flags & ~(unsigned)(LMUFFT_BWD_GH_MASKED | LMUFFT_BWD_MASK_GX)) return set_error("backward: unknown flags %u", flags);
   if (flags && parts != 3 && parts != 7) return set_error("backward: flags need the whole backward in one call");
@@ -2630,7 +2650,8 @@ static int backward_bf16_parts(int parts, const lmufft_shape* s, const void* x_,
 
   // out = gz W_h[:, j_begin : j_begin + ncols] (+ ga w_u), LDS-DMA kernel when everything is 16-byte friendly
   auto dgrad = [&](auto glds_tag, auto fallback_tag, const char* name, bf16_t* out, int j_begin, int ncols,
-                   const float* ga_, const float* wu_, GaParts gparts, const bf16_t* relu_src = nullptr) -> int {
+                   const float* ga_, const float* wu_, GaParts gparts, const bf16_t* relu_src = nullptr,
+                   const unsigned char* relu_bits = nullptr) -> int {
     using TG = decltype(glds_tag);
     using TF = decltype(fallback_tag);
     const bool fast = (s->Hd % 8 == 0) && (ncols % 8 == 0) && al16(out);
@@ -2652,7 +2673,7 @@ static int backward_bf16_parts(int parts, const lmufft_shape* s, const void* x_,
         return set_error("cannot reserve %zu bytes of LDS for k_dgrad_glds_bf16", lds);
       PROFB(name);
       hipLaunchKernelGGL(k_dgrad_glds_bf16<TG>, grid, dim3(TG::THREADS), lds, st, (const bf16_t*)gz, WbT, out, ga_,
-                         wu_, (int)rows, s->Hd, wl.ldWT, j_begin, ncols, gparts, rpw, col_tiles, relu_src);
+                         wu_, (int)rows, s->Hd, wl.ldWT, j_begin, ncols, gparts, rpw, col_tiles, relu_src, relu_bits);
     } else {
       const dim3 grid(cdivb(ncols, TF::BN), cdivb(rows, TF::BM));
       const size_t lds = sizeof(bf16_t) * (size_t)(TF::BM + TF::BN) * (TF::BK + 8);
@@ -2698,7 +2719,8 @@ static int backward_bf16_parts(int parts, const lmufft_shape* s, const void* x_,
   // gx = gz W_h[:, M:] + ga w_u
   if (gx) {
     if (int rc = dgrad(DgradXGldsTile{}, DgradXTileB{}, "k_dgrad_x_bf16", gx, s->M, s->D, (const float*)ga, w_u, ga_parts,
-                       (flags & LMUFFT_BWD_MASK_GX) ? x : nullptr))
+                       (flags & LMUFFT_BWD_MASK_GX) ? x : nullptr,
+                       (flags & LMUFFT_BWD_MASK_GX) ? (const unsigned char*)x_mask : nullptr))
       return rc;
   } else if (flags & LMUFFT_BWD_MASK_GX) {
     return set_error("backward: LMUFFT_BWD_MASK_GX without gx");
@@ -2767,12 +2789,12 @@ int lmufft_backward_flags_bf16(const lmufft_shape* s, const void* x, const float
                                const void* hprep, const void* scanprep, const float* u, const void* m, const void* h,
                                const void* hmask, const void* gh, const void* gh_n, void* gx, float* gw_u, float* gb_u,
                                float* gW_h, float* gb_h, void* gm, int conv_algo, void* workspace,
-                               size_t workspace_bytes, void* stream, uint32_t flags) {
+                               size_t workspace_bytes, void* stream, uint32_t flags, const void* x_mask) {
   const uint32_t known = LMUFFT_BWD_GH_MASKED | LMUFFT_BWD_MASK_GX | LMUFFT_BWD_PARTIAL_SUMS;
   if (flags & ~known) return set_error("backward: unknown flags %u", flags);
   return backward_bf16_parts((flags & LMUFFT_BWD_PARTIAL_SUMS) ? 7 : 3, s, x, w_u, wprep, hprep, scanprep, u, m, h, hmask,
                              gh, gh_n, gx, gw_u, gb_u, gW_h, gb_h, gm, conv_algo, workspace, workspace_bytes, stream,
-                             flags & ~(uint32_t)LMUFFT_BWD_PARTIAL_SUMS);
+                             flags & ~(uint32_t)LMUFFT_BWD_PARTIAL_SUMS, x_mask);
 }
 
 int lmufft_backward_weights_sum_many_bf16(const lmufft_lmu_sum_item* items, int32_t count, void* stream) {

@@ -196,12 +196,36 @@ class GradSink:
         self.on_ready(len(self.params))
 
 
+class ReluMaskLink:
+    """Hands the bit mask of (h > 0) that a layer's forward makes from that layer to the one stacked on it.
+
+    offer(h, bits) is called by the lower layer's forward, take(x) by the upper layer's: it returns the bits only if x
+    is that h (same memory, same shape -- a detached alias counts), so a stale or foreign mask is never used; without
+    bits the upper layer compares x itself."""
+
+    def __init__(self):
+        self._key = None
+        self._bits = None
+
+    @staticmethod
+    def _key_of(t):
+        return (t.device, t.data_ptr(), tuple(t.shape), t.dtype)
+
+    def offer(self, h, bits) -> None:
+        self._key, self._bits = (self._key_of(h), bits) if bits is not None else (None, None)
+
+    def take(self, x):
+        if self._bits is None or self._key != self._key_of(x) or not x.is_contiguous():
+            return None
+        return self._bits
+
+
 class _LMUFFTFunction(torch.autograd.Function):
     """(x, w_u, b_u, W_h, b_h, H) -> (h, h_n); reference: src/lmu.py:290-320."""
 
     @staticmethod
     def forward(ctx, x, w_u, b_u, W_h, b_h, H, conv_algo, hprep, fftprep, grad_sink, scanprep=None,
-                async_wgrad=False, relu_input=False, grad_masked=False):
+                async_wgrad=False, relu_input=False, grad_masked=False, mask_link=None):
         _require_gpu(x, "x")
         if x.dtype not in _DTYPES:
             raise RuntimeError(f"LMUFFT: x has dtype {x.dtype}; supported: float32, bfloat16")
@@ -269,6 +293,10 @@ class _LMUFFTFunction(torch.autograd.Function):
         ctx.async_wgrad = bool(async_wgrad)
         ctx.relu_input = bool(relu_input)
         ctx.grad_masked = bool(grad_masked)
+        # (x > 0) as bits, if the layer that produced x left them for this very tensor (ReluMaskLink)
+        ctx.x_mask = mask_link.take(x) if (mask_link is not None and relu_input) else None
+        if mask_link is not None and grad_masked:
+            mask_link.offer(h, hmask)
         ctx.grad_sink = grad_sink
         ctx.shape = (B, T, D, M, Hd, ldH)
         ctx.set_materialize_grads(False)
@@ -282,7 +310,7 @@ class _LMUFFTFunction(torch.autograd.Function):
         dt = x.dtype
         need_x = ctx.needs_input_grad[0]
         if gh is None and gh_n is None:
-            return (None,) * 14
+            return (None,) * 15
         if gh is not None:
             gh = gh.to(dt).contiguous()
         if gh_n is not None:
@@ -360,20 +388,20 @@ class _LMUFFTFunction(torch.autograd.Function):
                 rc = _lib.lib.lmufft_backward_flags_bf16(
                     ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(wprep), _ptr(hprep), _ptr(scanprep), _ptr(u), _ptr(m),
                     _ptr(h), _ptr(hmask), _ptr(gh), _ptr(gh_n), _ptr(gx), _ptr(gw_u), _ptr(gb_u), _ptr(gW_h), _ptr(gb_h),
-                    _ptr(gm), ctx.conv_algo, _ptr(ws), ws.numel(), _stream(dev), flags)
+                    _ptr(gm), ctx.conv_algo, _ptr(ws), ws.numel(), _stream(dev), flags, _ptr(ctx.x_mask))
                 what = "lmufft_backward_flags_bf16"
         _lib.check(rc, what)
         if pending is not None:
             _PENDING_WEIGHT_SUMS.append(pending)  # (before commit(): the bucket's owner may ask for the sums there)
         if direct:
             sink.commit()
-            return (gx,) + (None,) * 13
+            return (gx,) + (None,) * 14
         pd = ctx.param_dtypes
-        return (gx, gw_u.to(pd[0]), gb_u.to(pd[1]), gW_h.to(pd[2]), gb_h.to(pd[3])) + (None,) * 9
+        return (gx, gw_u.to(pd[0]), gb_u.to(pd[1]), gW_h.to(pd[2]), gb_h.to(pd[3])) + (None,) * 10
 
 
 def lmufft_layer(x, w_u, b_u, W_h, b_h, H, conv_algo="auto", hprep=None, fftprep=None, grad_sink=None,
-                 scanprep=None, async_weight_grad=False, relu_input=False, grad_masked=False):
+                 scanprep=None, async_weight_grad=False, relu_input=False, grad_masked=False, mask_link=None):
     """h, h_n = LMUFFT forward with autograd support (HIP kernels only).
 
     x float32 -> exact-fp32 kernels; x bfloat16 -> bf16 kernels with fp32
@@ -388,10 +416,12 @@ def lmufft_layer(x, w_u, b_u, W_h, b_h, H, conv_algo="auto", hprep=None, fftprep
     `relu_input`, `grad_masked` (bf16 path; set in pairs, see asr_amd.lmu.fuse_relu_backward): `relu_input` -- x is
     the output of a ReLU whose backward is the next thing to happen to x's gradient, so that gradient is returned
     already multiplied by (x > 0); `grad_masked` -- the gradient of h arrives already zero wherever h <= 0, the
-    layer's own masking pass is skipped.
+    layer's own masking pass is skipped.  `mask_link` (a ReluMaskLink shared by the two layers of a pair): the
+    lower layer leaves the bit mask of (h > 0) that its forward makes anyway, the upper layer uses it in place of
+    reading x when its x is that very h.
     """
     return _LMUFFTFunction.apply(x, w_u, b_u, W_h, b_h, H, _ALGOS[conv_algo], hprep, fftprep, grad_sink, scanprep,
-                                 async_weight_grad, relu_input, grad_masked)
+                                 async_weight_grad, relu_input, grad_masked, mask_link)
 
 
 def lmufft_layer_norm_inference(x, w_u, b_u, W_h, b_h, H, ln_weight, ln_bias, eps=1e-5, out_dtype=torch.float32,

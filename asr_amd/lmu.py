@@ -13,8 +13,8 @@ import numpy as np
 import torch
 from torch import nn
 
-from .functional import (fft_supported, lmufft_layer, prepare_impulse_bf16, prepare_impulse_fft, prepare_scan_bf16,
-                         scan_supported)
+from .functional import (ReluMaskLink, fft_supported, lmufft_layer, prepare_impulse_bf16, prepare_impulse_fft,
+                         prepare_scan_bf16, scan_supported)
 
 __all__ = ["LMUFFT", "LMU", "legendre_state_space", "impulse_response", "fuse_relu_backward"]
 
@@ -118,6 +118,8 @@ class LMUFFT(nn.Module):
         # set in pairs by fuse_relu_backward(lower, upper) for two directly stacked layers (bf16 path)
         self.input_is_relu_output = False  # the input gradient is returned already multiplied by (x > 0)
         self.grad_is_masked = False        # the gradient of h arrives already zero wherever h <= 0
+        self._mask_out = None              # ReluMaskLink to the layer stacked on this one
+        self._mask_in = None               # ReluMaskLink from the layer below
 
     _FFTPREP_MAX = 8  # cached FFT-route spectra (one per distinct sequence length)
 
@@ -195,8 +197,17 @@ class LMUFFT(nn.Module):
                             conv_algo=self.conv_algo, hprep=hprep, fftprep=fftprep,
                             grad_sink=self.grad_sink, scanprep=scanprep,
                             async_weight_grad=self.async_weight_grad,
-                            relu_input=self.input_is_relu_output, grad_masked=self.grad_is_masked)
+                            relu_input=self.input_is_relu_output, grad_masked=self.grad_is_masked,
+                            mask_link=self._mask_link())
 
+
+    def _mask_link(self):
+        # one argument carries both directions: a layer in the middle of a stack takes the mask of its x from the
+        # link below and offers the mask of its h to the link above
+        lo, up = self._mask_in if self.input_is_relu_output else None, self._mask_out if self.grad_is_masked else None
+        if lo is None and up is None:
+            return None
+        return _BothLinks(lo, up)
 
     # hidden sizes whose rows fit one projection tile: the layer norm can ride on the projection kernel
     FUSED_LAYER_NORM_MAX_HIDDEN = 384
@@ -220,6 +231,20 @@ class LMUFFT(nn.Module):
                                            out_dtype, hprep=self._impulse_bf16())
 
 
+class _BothLinks:
+    """take() from the link below a layer, offer() to the link above it."""
+
+    def __init__(self, below, above):
+        self.below, self.above = below, above
+
+    def take(self, x):
+        return self.below.take(x) if self.below is not None else None
+
+    def offer(self, h, bits) -> None:
+        if self.above is not None:
+            self.above.offer(h, bits)
+
+
 def fuse_relu_backward(lower: "LMUFFT", upper: "LMUFFT", enable: bool = True) -> None:
     """For two DIRECTLY stacked layers -- `upper(lower(x)[0])` with nothing in between and no other consumer of
     `lower`'s h -- fold the ReLU backward of `lower`'s output (autograd of src/lmu.py:318) into `upper`'s
@@ -239,6 +264,9 @@ def fuse_relu_backward(lower: "LMUFFT", upper: "LMUFFT", enable: bool = True) ->
                          f"size ({lower.hidden_size}), and it and the upper hidden size must be multiples of 8")
     upper.input_is_relu_output = bool(enable)
     lower.grad_is_masked = bool(enable)
+    link = ReluMaskLink() if enable else None
+    lower._mask_out = link
+    upper._mask_in = link
 
 
 class LMU(nn.Module):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMUFFT_ABI_VERSION 28
+#define LMUFFT_ABI_VERSION 29
 
 /* element types of the activations (x, h, gh, gx, m) */
 #define LMUFFT_F32 0
@@ -271,7 +271,9 @@ int lmufft_backward_partial_bf16(const lmufft_shape* s, const void* x, const flo
  * fold the ReLU backward that sits between two directly stacked layers into the upper layer's input-gradient kernel
  * (no counterpart in the reference, where autograd runs that ReLU backward as a pass of its own, src/lmu.py:318):
  *   LMUFFT_BWD_MASK_GX     this layer's input x is the output of a ReLU whose backward is the next thing to happen to
- *                          gx: gx is returned already multiplied by (x > 0);
+ *                          gx: gx is returned already multiplied by (x > 0); `x_mask`, if not NULL, holds that
+ *                          comparison as bits, [B*T][D/8] bytes in the layout of `hmask` (what the forward of
+ *                          the layer that produced x wrote: 1/16 of the bytes of x), else x itself is read;
  *   LMUFFT_BWD_GH_MASKED   the caller vouches that gh is already zero wherever h <= 0 (the layer above was run with
  *                          LMUFFT_BWD_MASK_GX on this layer's h): gh is used as the masked gradient in place and the
  *                          masking pass is not run.  Needs gh_n == NULL.
@@ -283,7 +285,7 @@ int lmufft_backward_flags_bf16(const lmufft_shape* s, const void* x, const float
                                const void* hprep, const void* scanprep, const float* u, const void* m, const void* h,
                                const void* hmask, const void* gh, const void* gh_n, void* gx, float* gw_u,
                                float* gb_u, float* gW_h, float* gb_h, void* gm, int conv_algo, void* workspace,
-                               size_t workspace_bytes, void* stream, uint32_t flags);
+                               size_t workspace_bytes, void* stream, uint32_t flags, const void* x_mask);
 typedef struct lmufft_lmu_sum_item {
   lmufft_shape shape;
   float* gw_u;

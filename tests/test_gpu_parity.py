@@ -421,6 +421,8 @@ def test_fused_relu_backward_between_stacked_layers(chained):
                 y, _ = l(y)
             y.backward(gy)
         results[fused] = [x.grad.clone()] + [p.grad.clone() for l in layers for p in l.parameters()]
+        if fused:  # the upper layers masked by the bits the lower layers' forwards left, not by reading x
+            assert all(l._mask_out._bits is not None for l in layers[:-1])
     assert any(float(g.abs().max()) > 0 for g in results[True])
     for g0, g1 in zip(results[False], results[True]):
         assert torch.equal(g0, g1)
@@ -460,3 +462,38 @@ def test_fuse_relu_backward_checks_its_layers():
         fuse_relu_backward(a, b)
     with pytest.raises(TypeError):
         fuse_relu_backward(a, torch.nn.Linear(4, 4))
+
+
+def test_fused_relu_backward_without_the_bit_mask(monkeypatch):
+    """The upper layer of a fused pair compares x itself when the lower layer left no bit mask (here: the mask is
+    switched off) or when its x is not the tensor the mask was made for."""
+    import copy
+
+    from asr_amd import LMUFFT
+    from asr_amd import functional as F
+    from asr_amd.lmu import fuse_relu_backward
+
+    dev = _dev()
+    torch.manual_seed(19)
+    ref = [LMUFFT(48, 64, 24, 64, 16).to(dev), LMUFFT(64, 32, 24, 64, 16).to(dev)]
+    x0 = torch.randn(3, 64, 48, device=dev).to(torch.bfloat16)
+    gy = torch.randn(3, 64, 32, device=dev).to(torch.bfloat16)
+    results = {}
+    for mode in ("plain", "bits", "no_bits", "copy"):
+        monkeypatch.setattr(F, "USE_RELU_MASK", mode != "no_bits")
+        layers = copy.deepcopy(ref)
+        if mode != "plain":
+            fuse_relu_backward(layers[0], layers[1])
+        x = x0.clone().requires_grad_(True)
+        h, _ = layers[0](x)
+        if mode == "copy":  # same values at another address: the link's mask is not for this tensor
+            h = h * 1.0
+        y, _ = layers[1](h)
+        y.backward(gy)
+        results[mode] = [x.grad.clone()] + [p.grad.clone() for l in layers for p in l.parameters()]
+    for mode in ("bits", "no_bits"):
+        for g0, g1 in zip(results["plain"], results[mode]):
+            assert torch.equal(g0, g1), mode
+    # "copy": autograd's multiplication node sits between the layers; the numbers are still the same
+    for g0, g1 in zip(results["plain"], results["copy"]):
+        assert torch.equal(g0, g1)
