@@ -20,7 +20,7 @@ CONV_TOEPLITZ = 1
 CONV_FFT = 2
 CONV_SCAN = 3
 NOALLOC_SCRATCH_BYTES = 8 << 20
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 
 class Shape(ctypes.Structure):
@@ -225,6 +225,8 @@ def _load():
     lib.lmufft_layernorm_dropout_bwd.restype = ci
     lib.lmufft_layernorm_dropout_bwd.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, vp, f32, i64, i32, f32, u32, u32, vp, vp,
                                                  vp, vp, vp, sz, vp]
+    lib.lmufft_layernorm_dropout_bwd_relu.restype = ci
+    lib.lmufft_layernorm_dropout_bwd_relu.argtypes = lib.lmufft_layernorm_dropout_bwd.argtypes + [ci]
     lib.lmufft_layernorm_param_sum_many.restype = ci
     lib.lmufft_layernorm_param_sum_many.argtypes = [ctypes.POINTER(LnSumItem), i32, vp]
     lib.lmufft_backward_needs_gm_bf16.restype = ci
@@ -311,6 +313,7 @@ EXPORTS = (
     "lmufft_layernorm_bwd",
     "lmufft_add_layernorm_dropout",
     "lmufft_layernorm_dropout_bwd",
+    "lmufft_layernorm_dropout_bwd_relu",
     "lmufft_layernorm_param_sum_many",
     "lmufft_dropout_epoch",
     "lmufft_linear_bf16",

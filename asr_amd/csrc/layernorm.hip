@@ -179,7 +179,9 @@ template <int NG>
 __global__ __launch_bounds__(kLnThreads) void k_layernorm_bwd(const void* x, int xb, const void* res, int rb, const void* dy,
                                                               int gb, const float* __restrict__ gamma, float eps, long rows,
                                                               int C, void* dx, void* dres, float* __restrict__ partial,
-                                                              HashDropout dr, const void* dy2, int g2b) {
+                                                              HashDropout dr, const void* dy2, int g2b, int relu_x) {
+  // relu_x: x is the output of a ReLU whose backward is the next thing to happen to dx -- dx is stored already
+  // multiplied by (x > 0) (dres is not)
   hash_resolve_epoch(dr);
   extern __shared__ __attribute__((aligned(16))) float red[];  // [8 row slots][2][C]
   const int sub = threadIdx.x & 31, slot = threadIdx.x >> 5;
@@ -198,12 +200,17 @@ __global__ __launch_bounds__(kLnThreads) void k_layernorm_bwd(const void* x, int
   for (long row = row0; row < rows; row += row_step) {
     ln_f32x4 v[NG], gy[NG];
     float s = 0.f;
+    unsigned keep = relu_x ? 0u : ~0u;  // bit 4 j + e: x[row][4 (sub + 32 j) + e] > 0
     const HashRow hr = hash_row(dr, (unsigned long long)row, (unsigned)C >> 1);
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
       const int c = sub + 32 * j;
       if (c < groups) {
         v[j] = ln_load4_rt(x, row * C + 4 * c, xb);
+        if (relu_x) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) keep |= (v[j][e] > 0.f ? 1u : 0u) << (4 * j + e);
+        }
         if (res) v[j] += ln_load4_rt(res, row * C + 4 * c, rb);
         gy[j] = ln_load4_rt(dy, row * C + 4 * c, gb);
         if (dy2) gy[j] += ln_load4_rt(dy2, row * C + 4 * c, g2b);  // the gradient of the output's second copy
@@ -252,7 +259,10 @@ __global__ __launch_bounds__(kLnThreads) void k_layernorm_bwd(const void* x, int
       const int c = sub + 32 * j;
       if (c < groups) {
         const ln_f32x4 d = (gy[j] - a - v[j] * b) * rstd;
-        ln_store4_rt(dx, row * C + 4 * c, d, xb);
+        ln_f32x4 dm = d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dm[e] = ((keep >> (4 * j + e)) & 1u) ? d[e] : 0.f;
+        ln_store4_rt(dx, row * C + 4 * c, dm, xb);
         if (dres) ln_store4_rt(dres, row * C + 4 * c, d, rb);
       }
     }
@@ -432,6 +442,19 @@ extern "C" int lmufft_layernorm_dropout_bwd(const void* x, int x_dtype, const vo
                                             float p_drop, uint32_t seed0, uint32_t seed1, void* dx, void* dres,
                                             float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
                                             void* stream) {
+  return lmufft_layernorm_dropout_bwd_relu(x, x_dtype, res, res_dtype, dy, dy_dtype, dy2, dy2_dtype, gamma, eps, rows, C,
+                                           p_drop, seed0, seed1, dx, dres, dgamma, dbeta, workspace, workspace_bytes,
+                                           stream, 0);
+}
+
+extern "C" int lmufft_layernorm_dropout_bwd_relu(const void* x, int x_dtype, const void* res, int res_dtype,
+                                                 const void* dy, int dy_dtype, const void* dy2, int dy2_dtype,
+                                                 const float* gamma, float eps, int64_t rows, int32_t C, float p_drop,
+                                                 uint32_t seed0, uint32_t seed1, void* dx, void* dres, float* dgamma,
+                                                 float* dbeta, void* workspace, size_t workspace_bytes, void* stream,
+                                                 int relu_x) {
+  if (relu_x && res && !dres)
+    return set_error("layernorm backward: relu_x with a residual needs a dres buffer (dx alone is masked)");
   if (!(p_drop >= 0.f && p_drop < 1.f)) return set_error("layernorm backward: dropout probability %g outside [0, 1)", (double)p_drop);
   const HashDropout dr = make_hash_dropout(p_drop, seed0, seed1);
   if (rows <= 0 || C <= 0) return set_error("layernorm backward: bad shape (rows=%lld C=%d)", (long long)rows, C);
@@ -462,7 +485,7 @@ extern "C" int lmufft_layernorm_dropout_bwd(const void* x, int x_dtype, const vo
 #define LN_BWD(NGV)                                                                                                    \
   hipLaunchKernelGGL((k_layernorm_bwd<NGV>), dim3(nb), dim3(kLnThreads), lds, st, x, x_dtype == LMUFFT_BF16, res,         \
                      res_dtype == LMUFFT_BF16, dy, dy_dtype == LMUFFT_BF16, gamma, eps, (long)rows, C, dx, dres, partial, dr, \
-                     dy2, dy2_dtype == LMUFFT_BF16)
+                     dy2, dy2_dtype == LMUFFT_BF16, relu_x ? 1 : 0)
     if (ng <= 1) LN_BWD(1);
     else if (ng <= 2) LN_BWD(2);
     else if (ng <= 3) LN_BWD(3);

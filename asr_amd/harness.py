@@ -40,6 +40,9 @@ from .lmu import LMUFFT
 # strict mode therefore only makes sense under bf16 autocast, where every op has a kernel here.)
 PATHS: dict = {}
 _STRICT = [False]
+# True: in training under bf16 autocast the layer norm behind an LMUFFT layer returns that layer's gradient already
+# multiplied by (h > 0) and the layer skips its own masking pass (the same gradients bit for bit)
+FOLD_RELU_BACKWARD = True
 
 
 class strict_kernels:
@@ -131,8 +134,16 @@ def _qkv_projection(wq: nn.Linear, wk: nn.Linear, wv: nn.Linear, x: torch.Tensor
         return torch.nn.functional.linear(xd, hit[1], hit[2])
 
 
+def _layer_norm_trains_on_hip(ln: nn.LayerNorm, C: int, dtype, residual_dtype=None) -> bool:
+    """Whether _layer_norm takes the HIP training kernels for a GPU input of this width and dtype."""
+    return (torch.is_grad_enabled() and ln.elementwise_affine and ln.bias is not None and C % 4 == 0
+            and C <= _LN_MAX_WIDTH and dtype in (torch.float32, torch.bfloat16) and ln.weight.dtype == torch.float32
+            and (residual_dtype is None or residual_dtype in (torch.float32, torch.bfloat16)))
+
+
 def _layer_norm(ln: nn.LayerNorm, x: torch.Tensor, residual: Optional[torch.Tensor] = None,
-                out_dtype: Optional[torch.dtype] = None, dropout: Optional[nn.Dropout] = None, twin: bool = False):
+                out_dtype: Optional[torch.dtype] = None, dropout: Optional[nn.Dropout] = None, twin: bool = False,
+                relu_input: bool = False):
     """dropout(ln(x + residual)): the one-pass HIP kernels on the GPU (the dropout rides on the same pass), torch
     otherwise.  `twin`: returns (float32 result, its bfloat16 rounding) -- from the same pass on the training path."""
     C = x.shape[-1]
@@ -142,11 +153,12 @@ def _layer_norm(ln: nn.LayerNorm, x: torch.Tensor, residual: Optional[torch.Tens
             and (residual is None or residual.dtype in (torch.float32, torch.bfloat16))):
         _took("hip", "layer_norm")
         return add_layer_norm(x, residual, ln.weight, ln.bias, ln.eps, out_dtype=out_dtype)
-    if (x.is_cuda and torch.is_grad_enabled() and ln.elementwise_affine and ln.bias is not None and C % 4 == 0
-            and C <= _LN_MAX_WIDTH and x.dtype in (torch.float32, torch.bfloat16) and ln.weight.dtype == torch.float32
-            and (residual is None or residual.dtype in (torch.float32, torch.bfloat16))):
+    if x.is_cuda and _layer_norm_trains_on_hip(ln, C, x.dtype, None if residual is None else residual.dtype):
         _took("hip", "layer_norm")  # training: the same forward kernel, and its backward, behind an autograd function
-        return add_layer_norm_train(x, residual, ln.weight, ln.bias, ln.eps, out_dtype, p_drop, twin=twin)
+        return add_layer_norm_train(x, residual, ln.weight, ln.bias, ln.eps, out_dtype, p_drop, twin=twin,
+                                    relu_input=relu_input)
+    if relu_input:  # (the producer of x was told that its gradient arrives masked: never skipped silently)
+        raise RuntimeError("_layer_norm: relu_input needs the HIP training kernels")
     _took("torch", "layer_norm")
     y = ln(x if residual is None else x + residual)
     y = y if out_dtype is None else y.to(out_dtype)
@@ -315,13 +327,19 @@ class LMUEncoder(nn.Module):
                 x, h_n = lmu.forward_layer_norm(
                     x, ln, stream or (torch.float32 if torch.is_autocast_enabled() else x.dtype))
             else:
+                # training under bf16 autocast: the layer norm's backward reads h anyway and hands the LMUFFT layer
+                # its gradient already multiplied by (h > 0); the layer's own masking pass is not run
+                fold = (FOLD_RELU_BACKWARD and autocast16 and x.is_cuda
+                        and _layer_norm_trains_on_hip(ln, self.hidden_size, torch.bfloat16))
+                lmu.grad_is_masked = bool(fold)
                 x, h_n = lmu(x)
+                fold = fold and x.dtype == torch.bfloat16
                 if autocast16 and i == n - 1:
-                    x = _layer_norm(ln, x, None, torch.bfloat16, self.dropout_layer)
+                    x = _layer_norm(ln, x, None, torch.bfloat16, self.dropout_layer, relu_input=fold)
                 elif autocast16 and self.use_attention:
-                    x, x16 = _layer_norm(ln, x, None, None, self.dropout_layer, twin=True)
+                    x, x16 = _layer_norm(ln, x, None, None, self.dropout_layer, twin=True, relu_input=fold)
                 else:
-                    x = _layer_norm(ln, x, None, stream, self.dropout_layer)
+                    x = _layer_norm(ln, x, None, stream, self.dropout_layer, relu_input=fold)
             states.append(h_n)
         return _linear(self.output_projection, x), states
 

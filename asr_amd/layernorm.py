@@ -98,12 +98,14 @@ register_deferred_sums(flush_param_sums)
 def add_layer_norm_backward(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor, dy: torch.Tensor,
                             eps: float = 1e-5, out_weight: Optional[torch.Tensor] = None,
                             out_bias: Optional[torch.Tensor] = None, p_drop: float = 0.0, seeds=(0, 0),
-                            dy2: Optional[torch.Tensor] = None, defer_param_sums: bool = False):
+                            dy2: Optional[torch.Tensor] = None, defer_param_sums: bool = False,
+                            relu_input: bool = False):
     """(dx, dresidual or None, dweight, dbias) of add_layer_norm: dx / dresidual carry the same values in the dtype
     of x / residual (one tensor when the dtypes agree); dweight, dbias float32, written into `out_weight` /
     `out_bias` (contiguous float32 [C]) when given.  `p_drop`, `seeds`: those of the forward call; dy passes
     through the same dropout decisions first.  `dy2`: a second upstream gradient of the same shape (float32 or
-    bfloat16), added to dy on load.  HIP kernel k_layernorm_bwd."""
+    bfloat16), added to dy on load.  `relu_input`: x is the output of a ReLU whose backward is the next thing to
+    happen to dx -- dx is returned already multiplied by (x > 0) (dresidual is not).  HIP kernel k_layernorm_bwd."""
     for name, t in (("x", x), ("residual", residual), ("weight", weight), ("dy", dy)):
         if t is not None and not t.is_cuda:
             raise RuntimeError(f"add_layer_norm_backward: `{name}` lives on {t.device}; the kernel runs only on a GPU "
@@ -122,7 +124,7 @@ def add_layer_norm_backward(x: torch.Tensor, residual: Optional[torch.Tensor], w
     weight = weight.detach().float().contiguous()
     dx = torch.empty_like(x)
     dres = None
-    if residual is not None and residual.dtype != x.dtype:
+    if residual is not None and (residual.dtype != x.dtype or relu_input):
         dres = torch.empty_like(residual)
     for name, t in (("out_weight", out_weight), ("out_bias", out_bias)):
         if t is not None and (t.shape != (C,) or t.dtype != torch.float32 or not t.is_contiguous() or t.device != x.device):
@@ -133,14 +135,14 @@ def add_layer_norm_backward(x: torch.Tensor, residual: Optional[torch.Tensor], w
     rows = x.numel() // C
     p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())  # noqa: E731
     with torch.cuda.device(x.device):
-        rc = _lib.lib.lmufft_layernorm_dropout_bwd(
+        rc = _lib.lib.lmufft_layernorm_dropout_bwd_relu(
             p(x), _DTYPES[x.dtype], p(residual), _DTYPES[residual.dtype] if residual is not None else 0, p(dy),
             _DTYPES[dy.dtype], p(dy2), _DTYPES[dy2.dtype] if dy2 is not None else 0, p(weight), float(eps), rows, C,
             float(p_drop), int(seeds[0]) & 0xFFFFFFFF,
             int(seeds[1]) & 0xFFFFFFFF, p(dx), p(dres), None if defer_param_sums else p(dgamma),
             None if defer_param_sums else p(dbeta), p(ws), ws.numel(),
-            ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
-    _lib.check(rc, "lmufft_layernorm_dropout_bwd")
+            ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream), 1 if relu_input else 0)
+    _lib.check(rc, "lmufft_layernorm_dropout_bwd_relu")
     if defer_param_sums:  # dgamma / dbeta are complete after flush_param_sums()
         _PENDING_PARAM_SUMS.append((x.device, _lib.LnSumItem(rows, C, dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr()),
                                     (ws, dgamma, dbeta)))
@@ -151,8 +153,9 @@ def add_layer_norm_backward(x: torch.Tensor, residual: Optional[torch.Tensor], w
 
 class _AddLayerNormTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, eps, out_dtype, p_drop, seed0, seed1, twin):
+    def forward(ctx, x, residual, weight, bias, eps, out_dtype, p_drop, seed0, seed1, twin, relu_input=False):
         ctx.save_for_backward(x, residual, weight)
+        ctx.relu_input = bool(relu_input)
         ctx.eps = eps
         ctx.params = (weight, bias)
         ctx.drop = (p_drop, (seed0, seed1))
@@ -171,11 +174,11 @@ class _AddLayerNormTrain(torch.autograd.Function):
         if not defer and _PENDING_PARAM_SUMS:
             flush_param_sums()  # a gradient handed to autograd may be added into a slice that a deferred sum still owes
         dx, dres, dgamma, dbeta = add_layer_norm_backward(x, residual, weight, dy, ctx.eps, slot_w, slot_b, *ctx.drop, dy16,
-                                                          defer_param_sums=defer)
+                                                          defer_param_sums=defer, relu_input=ctx.relu_input)
         dgamma = adopt(dgamma) if slot_w is not None else dgamma.to(weight.dtype)
         dbeta = adopt(dbeta) if slot_b is not None else dbeta.to(weight.dtype)
         return (dx if ctx.needs_input_grad[0] else None, dres if ctx.needs_input_grad[1] else None,
-                dgamma, dbeta, None, None, None, None, None, None)
+                dgamma, dbeta, None, None, None, None, None, None, None)
 
 
 _dropout_calls = 0
@@ -183,13 +186,15 @@ _dropout_calls = 0
 
 def add_layer_norm_train(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor, bias: torch.Tensor,
                          eps: float = 1e-5, out_dtype: Optional[torch.dtype] = None, p_drop: float = 0.0,
-                         seeds=None, twin: bool = False):
+                         seeds=None, twin: bool = False, relu_input: bool = False):
     """add_layer_norm with autograd (forward k_add_layernorm, backward k_layernorm_bwd), optionally followed by
     dropout in the same passes (`self.dropout_layer(layer_norm(x))`, src/models/lmu_encoder.py:274-277).
     `twin`: returns (float32 result, its bfloat16 rounding) as two outputs; the gradients that arrive through the two
     are added inside the backward kernel (no cast, no accumulation kernel).
     `seeds` = (seed0, seed1) name the dropout mask; by default torch's seed and a per-process call counter, so runs
-    that start from the same torch.manual_seed and make the same calls draw the same masks."""
+    that start from the same torch.manual_seed and make the same calls draw the same masks.
+    `relu_input`: x is the output of a ReLU (an LMUFFT layer's h) with no other consumer; the gradient returned for x
+    is already multiplied by (x > 0), so that layer can skip its own masking pass (LMUFFT.grad_is_masked)."""
     global _dropout_calls
     if not 0.0 <= p_drop < 1.0:
         raise ValueError(f"dropout probability has to be in [0, 1), got {p_drop}")
@@ -202,4 +207,4 @@ def add_layer_norm_train(x: torch.Tensor, residual: Optional[torch.Tensor], weig
             _dropout_calls += 1
         seeds = (torch.initial_seed() & 0xFFFFFFFF, 0x4C4E0000 ^ (_dropout_calls & 0xFFFFFFFF))
     return _AddLayerNormTrain.apply(x, residual, weight, bias, eps, out_dtype, float(p_drop), int(seeds[0]) & 0xFFFFFFFF,
-                                    int(seeds[1]) & 0xFFFFFFFF, bool(twin))
+                                    int(seeds[1]) & 0xFFFFFFFF, bool(twin), bool(relu_input))

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMUFFT_ABI_VERSION 29
+#define LMUFFT_ABI_VERSION 30
 
 /* element types of the activations (x, h, gh, gx, m) */
 #define LMUFFT_F32 0
@@ -400,6 +400,15 @@ int lmufft_layernorm_dropout_bwd(const void* x, int x_dtype, const void* res, in
                                  int64_t rows, int32_t C, float p_drop, uint32_t seed0, uint32_t seed1, void* dx,
                                  void* dres, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
                                  void* stream);
+/* lmufft_layernorm_dropout_bwd with one more option: relu_x != 0 -- x is the output of a ReLU whose backward is the
+ * next thing to happen to dx (in the encoder: the LMUFFT layer's h, src/models/lmu_encoder.py:266-277), and dx is
+ * stored already multiplied by (x > 0), so that the layer below can be run with LMUFFT_BWD_GH_MASKED.  dres, if any,
+ * is not masked (a residual input then needs its own dres buffer). */
+int lmufft_layernorm_dropout_bwd_relu(const void* x, int x_dtype, const void* res, int res_dtype, const void* dy,
+                                      int dy_dtype, const void* dy2, int dy2_dtype, const float* gamma, float eps,
+                                      int64_t rows, int32_t C, float p_drop, uint32_t seed0, uint32_t seed1, void* dx,
+                                      void* dres, float* dgamma, float* dbeta, void* workspace,
+                                      size_t workspace_bytes, void* stream, int relu_x);
 /* dgamma == dbeta == NULL in either backward: the workgroups' partial sums of the parameter gradients stay in the
  * workspace, and ONE later launch sums them for every layer norm of the step (six per step in the reference's
  * encoder).  `items` is a HOST array; rows and C as given to the backward call whose workspace the item names. */

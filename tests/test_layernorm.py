@@ -313,3 +313,33 @@ def test_training_layer_norm_writes_into_gradient_buckets(defer, monkeypatch):
         for a, b in zip(ref, lns):
             assert torch.allclose(b.weight.grad, a.weight.grad, rtol=1e-6, atol=1e-6 * float(a.weight.grad.abs().max()))
             assert torch.allclose(b.bias.grad, a.bias.grad, rtol=1e-6, atol=1e-6 * float(a.bias.grad.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_res", [False, True])
+def test_training_layer_norm_masks_the_input_gradient_of_a_relu_output(with_res):
+    """relu_input: dx comes back multiplied by (x > 0); dresidual, the parameter gradients and the output do not change."""
+    from asr_amd import layernorm as ln
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(31)
+    rows, C = 1000, 384
+    x = torch.relu(torch.randn(rows, C, generator=g)).to(torch.bfloat16).to(dev)
+    r = torch.randn(rows, C, generator=g).to(torch.bfloat16).to(dev) if with_res else None
+    w, b = (torch.randn(C, generator=g) * 0.5 + 1.0).to(dev), torch.randn(C, generator=g).to(dev)
+    dy = torch.randn(rows, C, generator=g).to(dev)
+
+    def run(relu_input):
+        xd = x.clone().requires_grad_(True)
+        rd = None if r is None else r.clone().requires_grad_(True)
+        wd, bd = torch.nn.Parameter(w.clone()), torch.nn.Parameter(b.clone())
+        y = ln.add_layer_norm_train(xd, rd, wd, bd, 1e-5, torch.float32, 0.1, (5, 6), relu_input=relu_input)
+        y.backward(dy)
+        return y.detach(), xd.grad, None if rd is None else rd.grad, wd.grad, bd.grad
+
+    plain, masked = run(False), run(True)
+    assert torch.equal(plain[0], masked[0])
+    assert torch.equal(masked[1], plain[1] * (x > 0))
+    assert float(plain[1][x <= 0].abs().max()) > 0  # the mask did something
+    for a, c in zip(plain[2:], masked[2:]):
+        assert (a is None and c is None) or torch.equal(a, c)
