@@ -21,7 +21,7 @@ def classify(name, seq):
         seq["dgrad"] += 1
         return "k_dgrad_m" if seq["dgrad"] % 2 == 1 else "k_dgrad_x"
     table = [("k_conv_proj_fwd_bf16", "k_conv_proj_fwd_bf16"), ("k_gu_q_bf16", "k_gu_q_bf16"),
-             ("k_relu_bwd_q_bf16", "k_relu_bwd_bf16"), ("k_proj_fwd_glds_bf16", "k_proj_fwd_bf16"), ("k_proj_fwd_bf16", "k_proj_fwd_bf16"),
+             ("k_relu_bwd_q_bf16", "k_relu_bwd_bf16"), ("k_qprep_bf16", "k_qprep_bf16"), ("k_proj_fwd_glds_bf16", "k_proj_fwd_bf16"), ("k_proj_fwd_bf16", "k_proj_fwd_bf16"),
              ("k_conv_bwd2_bf16", "k_conv_bwd_bf16"), ("k_conv_bwd_bf16", "k_conv_bwd_bf16"),
              ("k_conv_fwd_bf16", "k_conv_fwd_bf16"), ("k_wgrad_pair_bf16", "k_wgrad_bf16"), ("k_wgrad_bf16", "k_wgrad_bf16"),
              ("k_relu_bwd_bf16", "k_relu_bwd_bf16"), ("k_encode_fwd_bf16", "k_encode_fwd_bf16"),
