@@ -381,8 +381,9 @@ def test_deferred_weight_sums_match_the_immediate_ones(monkeypatch):
         assert torch.equal(g0, g1)
 
 
+@pytest.mark.parametrize("memory", [24, 20])  # 20: not a multiple of 8 -- the backward forms the memory gradient
 @pytest.mark.parametrize("chained", [False, True])
-def test_fused_relu_backward_between_stacked_layers(chained):
+def test_fused_relu_backward_between_stacked_layers(chained, memory):
     """fuse_relu_backward(lower, upper): the upper layer masks its input gradient by (x > 0) and the lower layer skips
     its own masking pass -- every parameter gradient and the gradient of the stack's input are bit-identical to the
     unfused stack's.  `chained`: the layers joined through detached copies and one backward call per layer (the way
@@ -395,7 +396,7 @@ def test_fused_relu_backward_between_stacked_layers(chained):
     dev = _dev()
     torch.manual_seed(13)
     sizes = [(48, 64), (64, 64), (64, 32)]
-    ref = [LMUFFT(d, hd, 24, 96, 16).to(dev) for d, hd in sizes]
+    ref = [LMUFFT(d, hd, memory, 96, 16).to(dev) for d, hd in sizes]
     x0 = torch.randn(5, 96, 48, device=dev).to(torch.bfloat16)
     gy = torch.randn(5, 96, 32, device=dev).to(torch.bfloat16)
     results = {}
@@ -496,4 +497,33 @@ def test_fused_relu_backward_without_the_bit_mask(monkeypatch):
             assert torch.equal(g0, g1), mode
     # "copy": autograd's multiplication node sits between the layers; the numbers are still the same
     for g0, g1 in zip(results["plain"], results["copy"]):
+        assert torch.equal(g0, g1)
+
+
+def test_fused_relu_backward_on_the_state_space_route():
+    """The same fold on a long sequence, where the convolution runs on the state-space route and the backward forms
+    the memory gradient (no Q route): bit-identical gradients."""
+    import copy
+
+    from asr_amd import LMUFFT
+    from asr_amd.lmu import fuse_relu_backward
+
+    dev = _dev()
+    torch.manual_seed(29)
+    ref = [LMUFFT(64, 64, 64, 1100, 200.0, conv_algo="scan").to(dev), LMUFFT(64, 32, 64, 1100, 200.0).to(dev)]
+    x0 = (0.5 * torch.randn(2, 1100, 64, device=dev)).to(torch.bfloat16)
+    gy = torch.randn(2, 1100, 32, device=dev).to(torch.bfloat16)
+    results = {}
+    for fused in (False, True):
+        layers = copy.deepcopy(ref)
+        if fused:
+            fuse_relu_backward(layers[0], layers[1])
+        x = x0.clone().requires_grad_(True)
+        y = x
+        for l in layers:
+            y, _ = l(y)
+        y.backward(gy)
+        results[fused] = [x.grad.clone()] + [p.grad.clone() for l in layers for p in l.parameters()]
+    assert all(bool(torch.isfinite(g).all()) for g in results[True])
+    for g0, g1 in zip(results[False], results[True]):
         assert torch.equal(g0, g1)
