@@ -927,7 +927,7 @@ void k_gu_q_bf16(const bf16_t* __restrict__ gz, const bf16_t* __restrict__ QT, f
   // at position d ^ ((r >> 2) & 3) (conflict-free ds_read_b128 fragments), applied on the source side.  Wave w
   // stages the frames' piece w and the lags' pieces w and w + 8.  A piece with no needed row in it is never issued
   // (its LDS rows keep whatever they held); inside an issued piece rows outside the operand re-read its nearest
-  // valid row.  Neither touches the result: a frame t < 0 or a lag beyond the causal limit only meets diagonals
+  // valid row.  Neither touches the result: a frame t < lag0 or a lag beyond the causal limit only meets diagonals
   // s = t - lag < 0, which nobody reads, and a diagonal is needed as a whole or not at all.
   constexpr int kStageA = TL::BM * 64, kStageB = TL::BN * 64, kStage = kStageA + kStageB;
   static_assert(TL::NW == 8 && TL::BM == 128 && TL::BN == 256 && TL::BK == 32, "piece assignment");
@@ -936,7 +936,7 @@ void k_gu_q_bf16(const bf16_t* __restrict__ gz, const bf16_t* __restrict__ QT, f
   {
     const int rr = lane >> 2, pos = lane & 3;
     int row = 16 * wave + rr;                       // frames
-    live[0] = t0 + 16 * wave + 15 >= 0;
+    live[0] = t0 + 16 * wave + 15 >= lag0;          // (lag0 >= 0: frames before the chunk's first lag meet no causal pair)
     src[0] = gzb + (long)max(t0 + row, 0) * Hd + 8 * (pos ^ ((row >> 2) & 3));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {                   // lags
