@@ -520,6 +520,9 @@ struct AttnBlock {
 };
 template <bool TILE_MAJOR>
 __device__ __forceinline__ AttnBlock attn_block() {
+#ifdef LMUFFT_ATTN_PLAIN_ORDER  // (measurement switch: every kernel on the grid's own order)
+  return AttnBlock{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+#endif
   if (!TILE_MAJOR) return AttnBlock{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
   const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
   const unsigned pairs = gridDim.y * gridDim.z;
