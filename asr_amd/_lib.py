@@ -20,7 +20,7 @@ CONV_TOEPLITZ = 1
 CONV_FFT = 2
 CONV_SCAN = 3
 NOALLOC_SCRATCH_BYTES = 8 << 20
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 
 class Shape(ctypes.Structure):
@@ -52,6 +52,28 @@ class LnSumItem(ctypes.Structure):
 BWD_GH_MASKED = 1
 BWD_MASK_GX = 2
 BWD_PARTIAL_SUMS = 4
+
+
+class QItem(ctypes.Structure):
+    """Mirror of `lmufft_q_item` (include/lmufft.h)."""
+
+    _fields_ = [
+        ("shape", Shape),
+        ("hprep", ctypes.c_void_p),
+        ("wprep", ctypes.c_void_p),
+        ("qt", ctypes.c_void_p),
+    ]
+
+
+class BwdExtras(ctypes.Structure):
+    """Mirror of `lmufft_bwd_extras` (include/lmufft.h)."""
+
+    _fields_ = [
+        ("x_mask", ctypes.c_void_p),
+        ("qt", ctypes.c_void_p),
+        ("q_items", ctypes.POINTER(QItem)),
+        ("q_count", ctypes.c_int32),
+    ]
 
 
 class LmuSumItem(ctypes.Structure):
@@ -191,7 +213,12 @@ def _load():
     lib.lmufft_backward_data_bf16.restype = ci
     lib.lmufft_backward_data_bf16.argtypes = [sp] + [vp] * 13 + [ci, vp, sz, vp]
     lib.lmufft_backward_flags_bf16.restype = ci
-    lib.lmufft_backward_flags_bf16.argtypes = [sp] + [vp] * 17 + [ci, vp, sz, vp, ctypes.c_uint32, vp]
+    lib.lmufft_backward_flags_bf16.argtypes = [sp] + [vp] * 17 + [ci, vp, sz, vp, ctypes.c_uint32,
+                                               ctypes.POINTER(BwdExtras)]
+    lib.lmufft_qt_bytes.restype = sz
+    lib.lmufft_qt_bytes.argtypes = [sp]
+    lib.lmufft_qprep_many_bf16.restype = ci
+    lib.lmufft_qprep_many_bf16.argtypes = [ctypes.POINTER(QItem), ctypes.c_int32, vp]
     lib.lmufft_backward_partial_bf16.restype = ci
     lib.lmufft_backward_partial_bf16.argtypes = [sp] + [vp] * 13 + [ci, vp, sz, vp]
     lib.lmufft_backward_weights_sum_many_bf16.restype = ci
@@ -349,6 +376,8 @@ EXPORTS = (
     "lmufft_backward_weights_bf16",
     "lmufft_backward_partial_bf16",
     "lmufft_backward_flags_bf16",
+    "lmufft_qt_bytes",
+    "lmufft_qprep_many_bf16",
     "lmufft_backward_weights_sum_many_bf16",
     "lmufft_conv_forward_bf16",
     "lmufft_conv_backward_bf16",

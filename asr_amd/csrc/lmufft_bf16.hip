@@ -150,6 +150,20 @@ __device__ __forceinline__ void qprep_block(const QPrep& q, int block, bf16_t* q
   });
 }
 
+// Several layers' Q^T in one launch: workgroups first[i] .. first[i + 1] make q[i]
+constexpr int kQBatchMax = 4;
+struct QPrepBatch {
+  QPrep q[kQBatchMax];
+  int first[kQBatchMax + 1];
+  int count;
+};
+template <class TL>
+__device__ __forceinline__ void qprep_batch_block(const QPrepBatch& qb, int block, bf16_t* qsmem) {
+#pragma unroll
+  for (int i = 0; i < kQBatchMax; ++i)  // (unrolled: q[i] is read with a constant index, straight from the arguments)
+    if (i < qb.count && block >= qb.first[i] && block < qb.first[i + 1]) qprep_block<TL>(qb.q[i], block - qb.first[i], qsmem);
+}
+
 // ---------------------------------------------------------------------------
 // u = relu(x . w_u + b_u), x bf16, fp32 accumulate             src/lmu.py:300
 // ---------------------------------------------------------------------------
@@ -816,11 +830,12 @@ __global__ __launch_bounds__(kThreads) void k_relu_bwd_q_bf16(const bf16_t* __re
                                                               const unsigned char* __restrict__ hmask,
                                                               const bf16_t* __restrict__ gh,
                                                               const bf16_t* __restrict__ gh_n,
-                                                              bf16_t* __restrict__ gz, int rows, int T, int Hd, QPrep q,
-                                                              int qblocks) {
+                                                              bf16_t* __restrict__ gz, int rows, int T, int Hd,
+                                                              QPrepBatch qb) {
   __shared__ __attribute__((aligned(16))) bf16_t qsmem[kQPrepLdsElems];
+  const int qblocks = qb.first[qb.count];
   if ((int)blockIdx.x < qblocks) {
-    qprep_block<QPrepTile>(q, (int)blockIdx.x, qsmem);
+    qprep_batch_block<QPrepTile>(qb, (int)blockIdx.x, qsmem);
     return;
   }
   const unsigned CH = (unsigned)Hd / 8;  // 16-byte chunks per row
@@ -854,9 +869,9 @@ __global__ __launch_bounds__(kThreads) void k_relu_bwd_q_bf16(const bf16_t* __re
 }
 
 // Q^T alone (the upstream gradient arrives masked, see LMUFFT_BWD_GH_MASKED): one workgroup per 64 x 64 tile
-__global__ __launch_bounds__(kThreads) void k_qprep_bf16(QPrep q) {
+__global__ __launch_bounds__(kThreads) void k_qprep_bf16(QPrepBatch qb) {
   __shared__ __attribute__((aligned(16))) bf16_t qsmem[kQPrepWideLdsElems];
-  qprep_block<QPrepWideTile>(q, (int)blockIdx.x, qsmem);
+  qprep_batch_block<QPrepWideTile>(qb, (int)blockIdx.x, qsmem);
 }
 
 // k_gu_q_bf16: workgroup = (utterance b, tile of 128 frames t -- right-aligned, so that the short tile is the
@@ -2562,6 +2577,45 @@ int lmufft_forward_ln_bf16(const lmufft_shape* s, const void* x, const float* w_
 
 }  // extern "C"
 
+// Q^T of one layer (rows and row stride as the backward's plan has them) from that layer's hprep and wprep
+static int q_rows_of(const lmufft_shape& s) { return cdivb(s.T, 64) * 64; }
+static int q_ld_of(const lmufft_shape& s) { return up8(s.Hd); }
+static QPrep make_qprep(const lmufft_shape& s, const void* hprep, const void* wprep, void* qt) {
+  const HprepLayout hl = hprep_layout(s.M, s.ldH);
+  const WprepLayout wl = wprep_layout(s);
+  return QPrep{(const bf16_t*)((const char*)hprep + hl.off_HbT), (const bf16_t*)((const char*)wprep + wl.off_Wb),
+               (bf16_t*)qt, q_rows_of(s), hl.ldHb, s.Hd, s.M, hl.ldHT, wl.ldW, q_ld_of(s)};
+}
+static int qprep_blocks(const lmufft_shape& s) { return (q_rows_of(s) / QPrepTile::BM) * cdivb(s.Hd, QPrepTile::BN); }
+static int check_q_items(const lmufft_q_item* items, int count) {
+  if (count < 0 || (count > 0 && !items)) return set_error("Q preparation: bad item list");
+  for (int i = 0; i < count; ++i) {
+    if (int rc = check_shape_b(&items[i].shape)) return rc;
+    if (!q_route_shape_ok(items[i].shape)) return set_error("Q preparation: item %d has no short-sequence route", i);
+    if (!items[i].hprep || !items[i].wprep || !items[i].qt || !al16(items[i].hprep) || !al16(items[i].wprep) ||
+        !al16(items[i].qt))
+      return set_error("Q preparation: item %d needs 16-byte aligned hprep, wprep and qt", i);
+  }
+  return 0;
+}
+// the items as launches of their own, kQBatchMax layers each
+static int launch_qprep_many(const lmufft_q_item* items, int count, hipStream_t st) {
+  for (int i0 = 0; i0 < count; i0 += kQBatchMax) {
+    QPrepBatch qb{};
+    qb.count = std::min(count - i0, kQBatchMax);
+    for (int i = 0; i < qb.count; ++i) {
+      qb.q[i] = make_qprep(items[i0 + i].shape, items[i0 + i].hprep, items[i0 + i].wprep, items[i0 + i].qt);
+      qb.first[i + 1] = qb.first[i] + qprep_blocks(items[i0 + i].shape);
+    }
+    {
+      PROFB("k_relu_bwd_bf16");
+      hipLaunchKernelGGL(k_qprep_bf16, dim3(qb.first[qb.count]), dim3(kThreads), 0, st, qb);
+    }
+    LAUNCH_CHECKB("k_qprep_bf16");
+  }
+  return 0;
+}
+
 // parts: 1 = everything up to gx (leaves gz and ga in the workspace), 2 = the parameter gradients from
 // the workspace's gz and ga, 3 = both
 static int backward_bf16_parts(int parts, const lmufft_shape* s, const void* x_, const float* w_u, const void* wprep,
@@ -2570,7 +2624,11 @@ static int backward_bf16_parts(int parts, const lmufft_shape* s, const void* x_,
                                float* gw_u,
                                float* gb_u, float* gW_h, float* gb_h, void* gm_, int conv_algo, void* workspace,
                                size_t workspace_bytes, void* stream, unsigned flags = 0,
-                               const void* x_mask = nullptr) {
+                               const lmufft_bwd_extras* extras = nullptr) {
+  const void* x_mask = extras ? extras->x_mask : nullptr;
+  const int n_extra_q = extras ? extras->q_count : 0;
+  if (int rc = check_q_items(extras ? extras->q_items : nullptr, n_extra_q)) return rc;
+  if (extras && extras->qt && !al16(extras->qt)) return set_error("backward: extras.qt must be 16-byte aligned");
   if (int rc = check_shape_b(s)) return rc;
   if (flags & ~(unsigned)(LMUFFT_BWD_GH_MASKED | LMUFFT_BWD_MASK_GX)) return set_error("backward: unknown flags %u", flags);
   if (flags && parts != 3 && parts != 7) return set_error("backward: flags need the whole backward in one call");
@@ -2619,22 +2677,39 @@ static int backward_bf16_parts(int parts, const lmufft_shape* s, const void* x_,
                      "hidden size a multiple of 32, 16-byte aligned h / gh); pass a gm buffer", kGuQMaxT);
 
   if (parts & 1) {
+  // Q^T of this layer: given ready-made (extras.qt), or made here in the workspace; Q^T of other layers
+  // (extras.q_items) rides on this call's first launch where that launch has workgroups to spare
+  const bf16_t* QT = (qroute && extras && extras->qt) ? (const bf16_t*)extras->qt : (const bf16_t*)(ws + p.off_q);
+  int extra_done = 0;
   if (qroute) {  // gz = relu'(h) * (gh + gh_n), and Q^T = H^T W_h[:, :M]^T on the pass's first workgroups
-    const QPrep q{HbT, (const bf16_t*)((const char*)wprep + wl.off_Wb), (bf16_t*)(ws + p.off_q), p.q_rows, hl.ldHb,
-                  s->Hd, s->M, hl.ldHT, wl.ldW, p.q_ld};
-    const int qblocks = (p.q_rows / QPrepTile::BM) * cdivb(s->Hd, QPrepTile::BN);
+    QPrepBatch qb{};
+    if (!(extras && extras->qt)) {
+      qb.q[0] = make_qprep(*s, hprep, wprep, ws + p.off_q);
+      qb.first[1] = qprep_blocks(*s);
+      qb.count = 1;
+    }
+    if (!gh_masked)  // the masking pass hides them
+      for (; extra_done < n_extra_q && qb.count < kQBatchMax; ++extra_done, ++qb.count) {
+        const lmufft_q_item& it = extras->q_items[extra_done];
+        qb.q[qb.count] = make_qprep(it.shape, it.hprep, it.wprep, it.qt);
+        qb.first[qb.count + 1] = qb.first[qb.count] + qprep_blocks(it.shape);
+      }
+    const int qblocks = qb.first[qb.count];
     const long work = rows * (s->Hd / 8);
     const dim3 grid(qblocks + (int)std::min<long>((work + kThreads - 1) / kThreads, 8192));
-    {
+    if (!gh_masked || qblocks > 0) {
       PROFB("k_relu_bwd_bf16");
       if (gh_masked)  // only Q^T is made
-        hipLaunchKernelGGL(k_qprep_bf16, dim3(qblocks), dim3(kThreads), 0, st, q);
+        hipLaunchKernelGGL(k_qprep_bf16, dim3(qblocks), dim3(kThreads), 0, st, qb);
       else
         hipLaunchKernelGGL(k_relu_bwd_q_bf16, grid, dim3(kThreads), 0, st, h, (const unsigned char*)hmask, gh, gh_n, gz,
-                           (int)rows, s->T, s->Hd, q, qblocks);
+                           (int)rows, s->T, s->Hd, qb);
     }
     LAUNCH_CHECKB("k_relu_bwd_q_bf16");
-  } else if (!gh_masked) {  // gz = relu'(h) * (gh + gh_n)
+  }
+  if (extra_done < n_extra_q)
+    if (int rc = launch_qprep_many(extras->q_items + extra_done, n_extra_q - extra_done, st)) return rc;
+  if (!qroute && !gh_masked) {  // gz = relu'(h) * (gh + gh_n)
     const long work = vec_h ? rows * (s->Hd / 8) : rows * s->Hd;
     const dim3 grid(std::min<long>((work + kThreads - 1) / kThreads, 8192));
     {
@@ -2698,7 +2773,7 @@ static int backward_bf16_parts(int parts, const lmufft_shape* s, const void* x_,
     {
       PROFB("k_gu_q_bf16");
       hipLaunchKernelGGL(k_gu_q_bf16, dim3(s->B * p.q_slots), dim3(TG::THREADS), lds, st, (const bf16_t*)gz,
-                         (const bf16_t*)(ws + p.off_q), gupart, s->B, s->T, s->Hd, p.q_ld, p.q_rows, guq_plan(s->T));
+                         QT, gupart, s->B, s->T, s->Hd, p.q_ld, p.q_rows, guq_plan(s->T));
     }
     LAUNCH_CHECKB("k_gu_q_bf16");
     if (dgrad_x_fast && p.q_slots <= kGaMaxParts) {
@@ -2789,12 +2864,23 @@ int lmufft_backward_flags_bf16(const lmufft_shape* s, const void* x, const float
                                const void* hprep, const void* scanprep, const float* u, const void* m, const void* h,
                                const void* hmask, const void* gh, const void* gh_n, void* gx, float* gw_u, float* gb_u,
                                float* gW_h, float* gb_h, void* gm, int conv_algo, void* workspace,
-                               size_t workspace_bytes, void* stream, uint32_t flags, const void* x_mask) {
+                               size_t workspace_bytes, void* stream, uint32_t flags,
+                               const lmufft_bwd_extras* extras) {
   const uint32_t known = LMUFFT_BWD_GH_MASKED | LMUFFT_BWD_MASK_GX | LMUFFT_BWD_PARTIAL_SUMS;
   if (flags & ~known) return set_error("backward: unknown flags %u", flags);
   return backward_bf16_parts((flags & LMUFFT_BWD_PARTIAL_SUMS) ? 7 : 3, s, x, w_u, wprep, hprep, scanprep, u, m, h, hmask,
                              gh, gh_n, gx, gw_u, gb_u, gW_h, gb_h, gm, conv_algo, workspace, workspace_bytes, stream,
-                             flags & ~(uint32_t)LMUFFT_BWD_PARTIAL_SUMS, x_mask);
+                             flags & ~(uint32_t)LMUFFT_BWD_PARTIAL_SUMS, extras);
+}
+
+size_t lmufft_qt_bytes(const lmufft_shape* s) {
+  if (!s || check_shape_b(s) || !q_route_shape_ok(*s)) return 0;
+  return align256b(sizeof(bf16_t) * (size_t)q_rows_of(*s) * q_ld_of(*s));
+}
+
+int lmufft_qprep_many_bf16(const lmufft_q_item* items, int32_t count, void* stream) {
+  if (int rc = check_q_items(items, count)) return rc;
+  return launch_qprep_many(items, count, (hipStream_t)stream);
 }
 
 int lmufft_backward_weights_sum_many_bf16(const lmufft_lmu_sum_item* items, int32_t count, void* stream) {

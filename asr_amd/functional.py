@@ -6,6 +6,7 @@ bookkeeping; all arithmetic runs in liblmufft_hip.so through its C ABI.
 from __future__ import annotations
 
 import ctypes
+import weakref
 
 import torch
 
@@ -196,6 +197,32 @@ class GradSink:
         self.on_ready(len(self.params))
 
 
+class _QEntry:
+    """The weights-only matrix Q^T of one layer's backward (sequences up to 512 frames), waiting to be made: by the
+    masking pass of another layer's backward, where its workgroups are free, or by one launch for all that wait."""
+
+    __slots__ = ("item", "keep", "stream", "done", "__weakref__")
+
+    def __init__(self, shp, hprep, wprep, qt, stream):
+        self.item = _lib.QItem(shp, hprep.data_ptr(), wprep.data_ptr(), qt.data_ptr())
+        self.keep = (hprep, wprep, qt)
+        self.stream = stream
+        self.done = False
+
+
+# weak references to the _QEntry objects of forwards whose backward has not run yet, per device; an entry lives as
+# long as its autograd node does
+_PENDING_Q = {}
+# True: layers whose gradient arrives masked (grad_masked) get their Q^T made off their own backward's critical path
+SHARE_QPREP = True
+
+
+def _waiting_q(dev, stream, but=None):
+    alive = [r for r in _PENDING_Q.get(dev, []) if r() is not None and not r().done]
+    _PENDING_Q[dev] = alive
+    return [r() for r in alive if r() is not but and r().stream == stream]
+
+
 class ReluMaskLink:
     """Hands the bit mask of (h > 0) that a layer's forward makes from that layer to the one stacked on it.
 
@@ -297,6 +324,14 @@ class _LMUFFTFunction(torch.autograd.Function):
         ctx.x_mask = mask_link.take(x) if (mask_link is not None and relu_input) else None
         if mask_link is not None and grad_masked:
             mask_link.offer(h, hmask)
+        ctx.q_entry = None
+        if (SHARE_QPREP and grad_masked and dt == torch.bfloat16 and hmask is not None and scanprep is None
+                and not FORCE_MEMORY_GRADIENT):
+            qt_bytes = _lib.lib.lmufft_qt_bytes(ctypes.byref(shp))
+            if qt_bytes:
+                ctx.q_entry = _QEntry(shp, hprep, wprep, torch.empty(qt_bytes, dtype=torch.uint8, device=dev),
+                                      torch.cuda.current_stream(dev).cuda_stream)
+                _PENDING_Q.setdefault(dev, []).append(weakref.ref(ctx.q_entry))
         ctx.grad_sink = grad_sink
         ctx.shape = (B, T, D, M, Hd, ldH)
         ctx.set_materialize_grads(False)
@@ -385,11 +420,37 @@ class _LMUFFTFunction(torch.autograd.Function):
                     pending = (dev, _lib.LmuSumItem(shp, gw_u.data_ptr(), gb_u.data_ptr(), gW_h.data_ptr(),
                                                     gb_h.data_ptr(), ws.data_ptr(), ws.numel()),
                                (ws, gw_u, gb_u, gW_h, gb_h))
+                extras = _lib.BwdExtras(None if ctx.x_mask is None else ctx.x_mask.data_ptr(), None, None, 0)
+                own = ctx.q_entry
+                cur = torch.cuda.current_stream(dev).cuda_stream
+                riders = []
+                if own is not None and (flags & _lib.BWD_GH_MASKED) and gm is None and own.stream == cur:
+                    if not own.done:
+                        # nobody has made this layer's Q^T yet: one launch now, for every layer that waits for one
+                        batch = [own] + _waiting_q(dev, cur, but=own)
+                        arr = (_lib.QItem * len(batch))(*[e.item for e in batch])
+                        _lib.check(_lib.lib.lmufft_qprep_many_bf16(arr, len(batch), _stream(dev)),
+                                   "lmufft_qprep_many_bf16")
+                        for e in batch:
+                            e.done = True
+                    extras.qt = own.item.qt
+                else:
+                    if own is not None:
+                        own.done = True  # (this backward makes its own, in its workspace)
+                    if not (flags & _lib.BWD_GH_MASKED) and gm is None:
+                        # this backward runs a masking pass: the waiting layers' Q^T ride on its spare workgroups
+                        riders = _waiting_q(dev, cur)
+                        if riders:
+                            arr = (_lib.QItem * len(riders))(*[e.item for e in riders])
+                            extras.q_items, extras.q_count = arr, len(riders)
                 rc = _lib.lib.lmufft_backward_flags_bf16(
                     ctypes.byref(shp), _ptr(x), _ptr(w_u), _ptr(wprep), _ptr(hprep), _ptr(scanprep), _ptr(u), _ptr(m),
                     _ptr(h), _ptr(hmask), _ptr(gh), _ptr(gh_n), _ptr(gx), _ptr(gw_u), _ptr(gb_u), _ptr(gW_h), _ptr(gb_h),
-                    _ptr(gm), ctx.conv_algo, _ptr(ws), ws.numel(), _stream(dev), flags, _ptr(ctx.x_mask))
+                    _ptr(gm), ctx.conv_algo, _ptr(ws), ws.numel(), _stream(dev), flags, ctypes.byref(extras))
                 what = "lmufft_backward_flags_bf16"
+                if rc == 0:
+                    for e in riders:
+                        e.done = True
         _lib.check(rc, what)
         if pending is not None:
             _PENDING_WEIGHT_SUMS.append(pending)  # (before commit(): the bucket's owner may ask for the sums there)

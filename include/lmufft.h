@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMUFFT_ABI_VERSION 30
+#define LMUFFT_ABI_VERSION 31
 
 /* element types of the activations (x, h, gh, gx, m) */
 #define LMUFFT_F32 0
@@ -271,13 +271,34 @@ int lmufft_backward_partial_bf16(const lmufft_shape* s, const void* x, const flo
  * fold the ReLU backward that sits between two directly stacked layers into the upper layer's input-gradient kernel
  * (no counterpart in the reference, where autograd runs that ReLU backward as a pass of its own, src/lmu.py:318):
  *   LMUFFT_BWD_MASK_GX     this layer's input x is the output of a ReLU whose backward is the next thing to happen to
- *                          gx: gx is returned already multiplied by (x > 0); `x_mask`, if not NULL, holds that
- *                          comparison as bits, [B*T][D/8] bytes in the layout of `hmask` (what the forward of
- *                          the layer that produced x wrote: 1/16 of the bytes of x), else x itself is read;
+ *                          gx: gx is returned already multiplied by (x > 0); `extras->x_mask`, if given, holds
+ *                          that comparison as bits, [B*T][D/8] bytes in the layout of `hmask` (what the forward
+ *                          of the layer that produced x wrote: 1/16 of the bytes of x), else x itself is read;
  *   LMUFFT_BWD_GH_MASKED   the caller vouches that gh is already zero wherever h <= 0 (the layer above was run with
  *                          LMUFFT_BWD_MASK_GX on this layer's h): gh is used as the masked gradient in place and the
  *                          masking pass is not run.  Needs gh_n == NULL.
  *   LMUFFT_BWD_PARTIAL_SUMS  as lmufft_backward_partial_bf16 (the four parameter-gradient pointers are ignored). */
+/* `extras` (NULL = none of it).  The backward of sequences up to 512 frames multiplies the masked gradient by a
+ * matrix Q^T that depends on the layer's weights only (lmufft_qt_bytes(shape) bytes; 0 = this shape does not take that
+ * route).  It makes Q^T itself, on spare workgroups of its masking pass -- but a layer run with LMUFFT_BWD_GH_MASKED
+ * has no such pass.  So Q^T can be made elsewhere: by lmufft_qprep_many_bf16 (one launch for several layers), or on
+ * the masking pass of ANOTHER layer's backward (`q_items` of that call: up to three ride for free, more get a launch
+ * of their own), any time after the forward that filled the item's `wprep`; the layer's own backward is then given
+ * the finished matrix as `qt`. */
+typedef struct lmufft_q_item {
+  lmufft_shape shape;
+  const void* hprep;
+  const void* wprep;
+  void* qt;
+} lmufft_q_item;
+typedef struct lmufft_bwd_extras {
+  const void* x_mask;
+  const void* qt;
+  const lmufft_q_item* q_items; /* HOST array */
+  int32_t q_count;
+} lmufft_bwd_extras;
+size_t lmufft_qt_bytes(const lmufft_shape* s);
+int lmufft_qprep_many_bf16(const lmufft_q_item* items, int32_t count, void* stream);
 #define LMUFFT_BWD_GH_MASKED 1u
 #define LMUFFT_BWD_MASK_GX 2u
 #define LMUFFT_BWD_PARTIAL_SUMS 4u
@@ -285,7 +306,8 @@ int lmufft_backward_flags_bf16(const lmufft_shape* s, const void* x, const float
                                const void* hprep, const void* scanprep, const float* u, const void* m, const void* h,
                                const void* hmask, const void* gh, const void* gh_n, void* gx, float* gw_u,
                                float* gb_u, float* gW_h, float* gb_h, void* gm, int conv_algo, void* workspace,
-                               size_t workspace_bytes, void* stream, uint32_t flags, const void* x_mask);
+                               size_t workspace_bytes, void* stream, uint32_t flags,
+                               const lmufft_bwd_extras* extras);
 typedef struct lmufft_lmu_sum_item {
   lmufft_shape shape;
   float* gw_u;

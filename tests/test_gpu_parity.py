@@ -527,3 +527,49 @@ def test_fused_relu_backward_on_the_state_space_route():
     assert all(bool(torch.isfinite(g).all()) for g in results[True])
     for g0, g1 in zip(results[False], results[True]):
         assert torch.equal(g0, g1)
+
+
+@pytest.mark.parametrize("share", [True, False])
+def test_shared_q_preparation_gives_the_same_gradients(share, monkeypatch):
+    """Layers whose gradient arrives masked get their backward's weights-only matrix made by the top layer's masking
+    pass (or, when every layer is masked, by one launch for all of them): same gradients bit for bit as when every
+    layer makes its own."""
+    import copy
+
+    from asr_amd import LMUFFT
+    from asr_amd import functional as F
+    from asr_amd.lmu import fuse_relu_backward
+
+    dev = _dev()
+    torch.manual_seed(37)
+    sizes = [(48, 64), (64, 64), (64, 64), (64, 32)]
+    ref = [LMUFFT(d, hd, 24, 96, 16).to(dev) for d, hd in sizes]
+    x0 = torch.randn(4, 96, 48, device=dev).to(torch.bfloat16)
+    gy = torch.randn(4, 96, 32, device=dev).to(torch.bfloat16)
+
+    def run(fused, all_masked):
+        layers = copy.deepcopy(ref)
+        if fused:
+            for lo, up in zip(layers[:-1], layers[1:]):
+                fuse_relu_backward(lo, up)
+        g = gy
+        if all_masked:  # the top layer's gradient is masked by hand, and the layer is told so
+            layers[-1].grad_is_masked = True
+        x = x0.clone().requires_grad_(True)
+        y = x
+        for l in layers:
+            y, _ = l(y)
+        if all_masked:
+            g = gy * (y > 0)
+        y.backward(g)
+        return [x.grad.clone()] + [p.grad.clone() for l in layers for p in l.parameters()]
+
+    monkeypatch.setattr(F, "SHARE_QPREP", False)
+    want = run(False, False)
+    monkeypatch.setattr(F, "SHARE_QPREP", share)
+    for all_masked in (False, True):
+        got = run(True, all_masked)
+        for g0, g1 in zip(want, got):
+            assert torch.equal(g0, g1)
+    if share:
+        assert not [r for r in F._PENDING_Q.get(dev, []) if r() is not None and not r().done]
