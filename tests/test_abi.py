@@ -45,6 +45,29 @@ def test_workspace_queries_and_shape_errors():
         _lib.check(rc, "forward")
 
 
+def test_batched_entry_points_validate_their_tables():
+    """The table-driven entry points refuse bad tables before anything is launched (so this runs without a GPU)."""
+    from asr_amd import _lib
+
+    lib = _lib.lib
+    s = _lib.Shape(64, 400, 384, 192, 384, 400)
+    assert lib.lmufft_qt_bytes(ctypes.byref(s)) >= 448 * 384 * 2
+    assert lib.lmufft_qt_bytes(ctypes.byref(_lib.Shape(2, 600, 384, 192, 384, 600))) == 0   # beyond 512 frames
+    assert lib.lmufft_qt_bytes(ctypes.byref(_lib.Shape(2, 400, 384, 20, 384, 400))) == 0    # memory size not 8 k
+    assert lib.lmufft_qprep_many_bf16(None, 0, None) == 0
+    assert lib.lmufft_qprep_many_bf16(None, 2, None) != 0
+    items = (_lib.QItem * 1)(_lib.QItem(s, None, None, None))
+    assert lib.lmufft_qprep_many_bf16(items, 1, None) != 0 and b"hprep" in lib.lmufft_last_error()
+    items = (_lib.QItem * 1)(_lib.QItem(_lib.Shape(2, 600, 384, 192, 384, 600), 16, 16, 16))
+    assert lib.lmufft_qprep_many_bf16(items, 1, None) != 0 and b"route" in lib.lmufft_last_error()
+    assert lib.lmufft_backward_weights_sum_many_bf16(None, 0, None) == 0
+    assert lib.lmufft_backward_weights_sum_many_bf16(None, -1, None) != 0
+    sums = (_lib.LmuSumItem * 1)(_lib.LmuSumItem(s, 16, 16, 16, 16, 16, 8))
+    assert lib.lmufft_backward_weights_sum_many_bf16(sums, 1, None) != 0 and b"workspace" in lib.lmufft_last_error()
+    rc = lib.lmufft_backward_flags_bf16(ctypes.byref(s), *([None] * 17), 0, None, 0, None, 0x80, None)
+    assert rc != 0 and b"unknown flags" in lib.lmufft_last_error()
+
+
 def test_module_surface_matches_reference(golden_dir):
     from asr_amd import LMUFFT
 
